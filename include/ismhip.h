@@ -1,0 +1,203 @@
+/*
+ * ismhip.h — C ABI of the MI355X-native implicit_shape_model recognition hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one plugin seam of the
+ * reference (vseib/point-cloud-donkey, paths relative to /root/reference/src/implicit_shape_model).
+ * The reference has no FFI of its own (its seams are C++ virtuals created by Factory<T>,
+ * utils/factory.h:24-46), so the functions below are what a maintainer binds from the
+ * plugin classes; INTEGRATION.md shows the stubs.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, int status (0 = ok, <0 = error); no exception crosses.
+ *   - pointers are DEVICE pointers unless the parameter name ends in _h (host).
+ *   - every call takes an ismhip_ctx (device, stream, scratch arena) and is asynchronous on the
+ *     ctx stream; outputs are valid after ismhip_sync() or after a stream-ordered consumer.
+ *   - one ctx per host thread / GPU; calls on different ctxs are re-entrant.
+ *   - object batches: "n_obj" objects are concatenated; X_offsets_h[n_obj+1] gives the element
+ *     range of each object in the concatenated arrays (points, keypoints/features, vote slots).
+ *   - there is exactly ONE back end (HIP, gfx950). If no GPU is present ismhip_ctx_create fails.
+ */
+#ifndef ISMHIP_H_
+#define ISMHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISMHIP_ABI_VERSION 1
+
+#define ISMHIP_OK               0
+#define ISMHIP_ERR_INVALID     -1   /* bad argument (null pointer, negative size, unsupported value) */
+#define ISMHIP_ERR_HIP         -2   /* a HIP runtime call failed; see ismhip_last_error */
+#define ISMHIP_ERR_NOMEM       -3   /* device allocation failed */
+#define ISMHIP_ERR_UNSUPPORTED -4   /* valid in the reference, not built here */
+#define ISMHIP_ERR_NODEVICE    -5   /* no gfx950 device visible: the product path has no CPU fallback */
+
+/* distance metric: utils/distance.h:45,65 (FLANN functors; L2 is SQUARED, no sqrt) */
+#define ISMHIP_METRIC_L2SQ 0
+#define ISMHIP_METRIC_CHI2 1
+
+/* vote weight flags: codebook/codebook.cpp:32-35 */
+#define ISMHIP_W_CLASS    1u
+#define ISMHIP_W_VOTE     2u
+#define ISMHIP_W_MATCHING 4u
+#define ISMHIP_W_CODEWORD 8u
+
+/* mean-shift kernel: voting/voting_mean_shift.cpp:378-417 */
+#define ISMHIP_KERNEL_GAUSSIAN 0
+#define ISMHIP_KERNEL_UNIFORM  1
+/* maxima suppression: voting/voting_mean_shift.cpp:99-122 */
+#define ISMHIP_SUPPRESS_AVERAGE  0
+#define ISMHIP_SUPPRESS_SUPPRESS 1
+#define ISMHIP_SUPPRESS_NONE     2
+
+#define ISMHIP_SHOT_DIM   352
+#define ISMHIP_CSHOT_DIM 1344
+#define ISMHIP_FPFH_DIM    33
+
+typedef struct ismhip_ctx      ismhip_ctx;
+typedef struct ismhip_cloud    ismhip_cloud;
+typedef struct ismhip_codebook ismhip_codebook;
+
+/* ---- context ----------------------------------------------------------------------------- */
+int  ismhip_abi_version(void);
+/* stream: a hipStream_t (as void*) the caller owns, or NULL to let the ctx create its own. */
+int  ismhip_ctx_create(int device, void* stream, ismhip_ctx** out);
+int  ismhip_ctx_destroy(ismhip_ctx* ctx);
+int  ismhip_sync(ismhip_ctx* ctx);
+const char* ismhip_last_error(const ismhip_ctx* ctx);
+/* per-kernel device timers (hipEvent on the ctx stream). Enable, run, sync, then read.
+ * name: "grid","lrf","shot352","cshot1344","fpfh33","knn","cast_votes","maxima". Returns accumulated
+ * milliseconds and launch count since the last reset. */
+int  ismhip_timers_enable(ismhip_ctx* ctx, int on);
+int  ismhip_timers_reset(ismhip_ctx* ctx);
+int  ismhip_timer_get(ismhip_ctx* ctx, const char* name, double* ms_out, int64_t* launches_out);
+
+/* ---- search surface (replaces pcl::search::KdTree built at implicit_shape_model.cpp:823-831) ---
+ * Takes the NaN-free surface cloud of n_obj objects as SoA and builds a per-object uniform grid
+ * (cell edge = cell_size, use max(Radius, ReferenceFrameRadius)/2) with the points counting-sorted
+ * by cell. rgba may be NULL (needed only by cshot1344): packed as PCL does, 0x00RRGGBB. */
+int  ismhip_cloud_create(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_h,
+                         const float* x, const float* y, const float* z,
+                         const float* nx, const float* ny, const float* nz,
+                         const uint32_t* rgba, float cell_size, ismhip_cloud** out);
+int  ismhip_cloud_destroy(ismhip_ctx* ctx, ismhip_cloud* cloud);
+/* per-object centroid (features_shot.cpp:45-51) -> centroid_out[n_obj*3] */
+int  ismhip_cloud_centroids(ismhip_ctx* ctx, const ismhip_cloud* cloud, float* centroid_out);
+
+/* ---- local reference frames: Features::computeSHOTReferenceFrames (features/features.cpp:238-252)
+ *      -> pcl::SHOTLocalReferenceFrameEstimationOMP (arithmetic as third_party/pcl_shot_na_lrf/shot_na_lrf.hpp:48-178
+ *      with upstream's v.z sign rule). lrf9_out[nkp*9] row-major [x;y;z]; all-NaN when <5 neighbours. */
+int  ismhip_shot_lrf(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
+                     const float* kpx, const float* kpy, const float* kpz,
+                     float radius, float* lrf9_out);
+
+/* ---- descriptors: FeaturesSHOT::iComputeDescriptors (features/features_shot.cpp:28-81) ------
+ * desc_out[nkp*352]; NaN row when LRF non-finite or <5 neighbours. neighbour_count_out may be NULL
+ * (else [nkp] number of radius neighbours, the M_k of the roofline model). */
+int  ismhip_shot352(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
+                    const float* kpx, const float* kpy, const float* kpz,
+                    const float* lrf9, float radius, float* desc_out, uint32_t* neighbour_count_out);
+/* FeaturesCSHOT::iComputeDescriptors (features/features_cshot.cpp:28-103); kp_rgba = keypoint colours */
+int  ismhip_cshot1344(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
+                      const float* kpx, const float* kpy, const float* kpz, const uint32_t* kp_rgba,
+                      const float* lrf9, float radius, float* desc_out, uint32_t* neighbour_count_out);
+/* FeaturesFPFH::iComputeDescriptors (features/features_fpfh.cpp:27-72) */
+int  ismhip_fpfh33(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
+                   const float* kpx, const float* kpy, const float* kpz,
+                   float radius, float* desc_out, uint32_t* neighbour_count_out);
+/* ISMFeature::centerDist (features_shot.cpp:77): |keypoint - centroid(object)| -> out[nkp] */
+int  ismhip_center_dist(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
+                        const float* kpx, const float* kpy, const float* kpz, float* out);
+
+/* ---- feature filtering: Features::operator() drops non-finite LRFs (features.cpp:66-76),
+ *      ImplicitShapeModel::removeNaNFeatures drops NaN descriptors (implicit_shape_model.cpp:1276-1308).
+ *      Stable stream compaction of rows; keep_offsets_h_out[n_obj+1] (host) receives the new per-object
+ *      ranges; src_index_out[nkp] (device) the source row of every kept row. The call synchronises. */
+int  ismhip_compact_features(ismhip_ctx* ctx, int n_obj, const uint32_t* kp_offsets_h, int dim,
+                             const float* desc, const float* lrf9,
+                             const float* kpx, const float* kpy, const float* kpz,
+                             float* desc_out, float* lrf9_out,
+                             float* kpx_out, float* kpy_out, float* kpz_out,
+                             uint32_t* src_index_out, uint32_t* keep_offsets_h_out);
+
+/* ---- codebook: FlannHelper dataset (utils/flann_helper.cpp:21-70) + CodewordDistribution vote
+ *      tables (codebook/codeword_distribution.cpp:73-144) + classSigmas (codebook.cpp:107,159-193).
+ *      Rows of words_h are in getCodewords() order (ascending codeword id, codebook.cpp:856-859).
+ *      Votes are CSR over words. All inputs are host arrays, copied once; the codebook stays resident. */
+int  ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* words_h,
+                            const float* word_weight_h,          /* [n_words] Codeword::getWeight, may be NULL (=1) */
+                            const uint32_t* vote_offsets_h,      /* [n_words+1] */
+                            const float* vote_xyz_h,             /* [n_votes*3] vote in LRF coordinates */
+                            const float* vote_weight_h,          /* [n_votes] learned centre weight, NULL = 1 */
+                            const float* vote_class_weight_h,    /* [n_votes] statistical weight of the vote's class, NULL = 1 */
+                            const uint32_t* vote_class_h,        /* [n_votes] */
+                            const uint32_t* vote_instance_h,     /* [n_votes] */
+                            const float* vote_bbox_quat_h,       /* [n_votes*4] (w,x,y,z), NULL = identity */
+                            const float* vote_bbox_size_h,       /* [n_votes*3], NULL = 0 */
+                            int n_classes, const float* class_sigma_h, /* [n_classes] variance per class id */
+                            ismhip_codebook** out);
+int  ismhip_codebook_destroy(ismhip_ctx* ctx, ismhip_codebook* cb);
+int  ismhip_codebook_max_votes_per_word(const ismhip_codebook* cb);
+
+/* ---- activation: ActivationStrategyKNN::activateKNN (activation_strategy/activation_strategy_knn.h:41-126)
+ *      with FLANNExactMatch semantics (SearchParams(-1)): exact k nearest codewords, ascending distance,
+ *      ties -> lowest row. idx_out[nq*k] (row in words, -1 when n_words < k), dist_out[nq*k] = the FLANN
+ *      functor value (utils/distance.cpp:33-52), recomputed by direct summation for the winners. */
+int  ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q,
+                int k, int32_t* idx_out, float* dist_out);
+/* distance-ratio test of activateKNN (:74-85), k must be 1: needs the 2-NN; idx -> -1 when d1/d2 > threshold */
+int  ismhip_knn_ratio(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q,
+                      float ratio_threshold, int32_t* idx_out, float* dist_out);
+
+/* ---- vote casting: Codebook::castVotes second loop + CodewordDistribution::castVotes/castVote
+ *      (codebook.cpp:541-554, codeword_distribution.cpp:73-167), sink = Voting::vote (voting/voting.cpp:58-77).
+ *      Vote slot of (feature f, activation j, stored vote v) = (f*k + j)*maxv + v with
+ *      maxv = ismhip_codebook_max_votes_per_word; a slot that casts no vote has class = -1.
+ *      All outputs are SoA of n_slots = nq*k*maxv entries. */
+int  ismhip_cast_votes(ismhip_ctx* ctx, const ismhip_codebook* cb, uint32_t weight_flags,
+                       int nq, const float* lrf9, const float* kpx, const float* kpy, const float* kpz,
+                       int k, const int32_t* idx, const float* dist,
+                       float* vote_pos_out,      /* [n_slots*3] */
+                       float* vote_weight_out,   /* [n_slots] */
+                       int32_t* vote_class_out,  /* [n_slots], -1 = no vote */
+                       int32_t* vote_instance_out,
+                       int32_t* vote_codeword_out,
+                       float* vote_bbox_quat_out,/* [n_slots*4], may be NULL */
+                       float* vote_bbox_size_out /* [n_slots*3], may be NULL */);
+
+/* ---- maxima: Voting::findMaxima + VotingMeanShift::iFindMaxima + MaximaHandler
+ *      (voting/voting.cpp:79-328,436-462; voting_mean_shift.cpp:39-177,201-481; maxima_handler.cpp:51-157) */
+typedef struct ismhip_maxima_params {
+    int   n_classes;
+    const float* class_bandwidth_h; /* [n_classes] MaximaHandler::getSearchDistForClass; NULL -> bandwidth for all */
+    float bandwidth;                /* Voting.Bandwidth */
+    float threshold;                /* Voting.Threshold */
+    int   max_iter;                 /* Voting.MaxIter */
+    int   kernel;                   /* ISMHIP_KERNEL_* */
+    int   suppression;              /* ISMHIP_SUPPRESS_* */
+    int   min_votes_threshold;      /* Voting.MinVotesThreshold */
+    float min_threshold;            /* Voting.MinThreshold (negative = relative to best) */
+    int   best_k;                   /* Voting.BestK (<=0: all) */
+    int   max_maxima;               /* capacity of the output per object */
+} ismhip_maxima_params;
+
+/* slot_offsets_h[n_obj+1]: vote-slot range of each object. Outputs per object o, maximum m (sorted by
+ * weight, descending): index o*max_maxima + m. n_maxima_out[n_obj]. class_score_out[n_obj*n_classes] =
+ * best normalised weight per class (0 when the class has no maximum) — the record the multi-GPU
+ * all-gather exchanges. */
+int  ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* slot_offsets_h,
+                        const float* vote_pos, const float* vote_weight, const int32_t* vote_class,
+                        const int32_t* vote_instance, const float* vote_bbox_size /* may be NULL */,
+                        const ismhip_maxima_params* params,
+                        int32_t* n_maxima_out, float* max_pos_out, float* max_weight_out,
+                        int32_t* max_class_out, int32_t* max_instance_out, float* max_instance_weight_out,
+                        float* max_bbox_size_out /* may be NULL */, int32_t* max_n_votes_out,
+                        float* class_score_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISMHIP_H_ */

@@ -1,0 +1,119 @@
+/*
+ * ism_oracle.h — CPU restatement (oracle) of the implicit_shape_model recognition hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / timed CPU baseline. The product path (libismhip.so) never links or calls it.
+ *
+ * PARITY UNPINNED by the reference: vseib/point-cloud-donkey ships no tests, golden vectors or
+ * fixtures and its hot loops live in PCL 1.10 / FLANN 1.9.1 / Eigen 3.3, none of
+ * which is present here, so the reference cannot be built (oracle/README.md). The arithmetic below
+ * restates the published PCL/FLANN algorithms in the reference's own operation order and is pinned
+ * by hand-derived known-answer vectors (tests/golden/, generator committed).
+ *
+ * All pointers are HOST pointers; signatures mirror include/ismhip.h with the ctx / handles removed.
+ */
+#ifndef ISM_ORACLE_H_
+#define ISM_ORACLE_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ismref_maxima_params {
+    int   n_classes;
+    const float* class_bandwidth; /* may be NULL */
+    float bandwidth;
+    float threshold;
+    int   max_iter;
+    int   kernel;        /* 0 gaussian, 1 uniform */
+    int   suppression;   /* 0 average, 1 suppress, 2 none */
+    int   min_votes_threshold;
+    float min_threshold;
+    int   best_k;
+    int   max_maxima;
+} ismref_maxima_params;
+
+void ismref_set_num_threads(int n);
+int  ismref_get_num_threads(void);
+
+/* radius search used by every descriptor (pcl::search::KdTree::radiusSearch, sorted): returns the
+ * number of neighbours with d^2 < r^2; writes up to cap indices (into the object's points) and squared
+ * distances in ascending (d^2, index) order. */
+int  ismref_radius_search(int n, const float* x, const float* y, const float* z,
+                          float qx, float qy, float qz, float radius, int cap, int32_t* idx_out, float* d2_out);
+
+int  ismref_shot_lrf(int n_obj, const uint32_t* pt_offsets, const float* x, const float* y, const float* z,
+                     const uint32_t* kp_offsets, const float* kpx, const float* kpy, const float* kpz,
+                     float radius, float* lrf9_out);
+int  ismref_shot352(int n_obj, const uint32_t* pt_offsets, const float* x, const float* y, const float* z,
+                    const float* nx, const float* ny, const float* nz,
+                    const uint32_t* kp_offsets, const float* kpx, const float* kpy, const float* kpz,
+                    const float* lrf9, float radius, float* desc_out, uint32_t* neighbour_count_out);
+int  ismref_cshot1344(int n_obj, const uint32_t* pt_offsets, const float* x, const float* y, const float* z,
+                      const float* nx, const float* ny, const float* nz, const uint32_t* rgba,
+                      const uint32_t* kp_offsets, const float* kpx, const float* kpy, const float* kpz,
+                      const uint32_t* kp_rgba, const float* lrf9, float radius, float* desc_out,
+                      uint32_t* neighbour_count_out);
+int  ismref_fpfh33(int n_obj, const uint32_t* pt_offsets, const float* x, const float* y, const float* z,
+                   const float* nx, const float* ny, const float* nz,
+                   const uint32_t* kp_offsets, const float* kpx, const float* kpy, const float* kpz,
+                   float radius, float* desc_out, uint32_t* neighbour_count_out);
+int  ismref_centroids(int n_obj, const uint32_t* pt_offsets, const float* x, const float* y, const float* z,
+                      float* centroid_out);
+int  ismref_center_dist(int n_obj, const uint32_t* pt_offsets, const float* x, const float* y, const float* z,
+                        const uint32_t* kp_offsets, const float* kpx, const float* kpy, const float* kpz, float* out);
+void ismref_rgb2lab(uint32_t rgba, float* L, float* a, float* b);
+/* single pair feature of FPFH (pcl::computePairFeatures); returns 1 when valid */
+int  ismref_pair_features(const float* p1, const float* n1, const float* p2, const float* n2, float* f4_out);
+
+float ismref_distance(int metric, int dim, const float* a, const float* b);
+int  ismref_knn(int metric, int n_words, int dim, const float* words, int nq, const float* q, int k,
+                int32_t* idx_out, float* dist_out);
+int  ismref_knn_ratio(int metric, int n_words, int dim, const float* words, int nq, const float* q,
+                      float ratio_threshold, int32_t* idx_out, float* dist_out);
+
+/* Utils::rotateInto / rotateBack / getRotQuaternion (utils/utils.cpp:136-178) */
+void ismref_rot_quaternion(const float* lrf9, float* quat_wxyz_out);
+void ismref_rotate_into(const float* lrf9, const float* v, float* out);
+void ismref_rotate_back(const float* lrf9, const float* v, float* out);
+
+int  ismref_cast_votes(int n_words, int dim, const float* word_weight,
+                       const uint32_t* vote_offsets, const float* vote_xyz, const float* vote_weight,
+                       const float* vote_class_weight, const uint32_t* vote_class, const uint32_t* vote_instance,
+                       const float* vote_bbox_quat, const float* vote_bbox_size,
+                       int n_classes, const float* class_sigma, uint32_t weight_flags,
+                       int nq, const float* lrf9, const float* kpx, const float* kpy, const float* kpz,
+                       int k, const int32_t* idx, const float* dist,
+                       float* vote_pos_out, float* vote_weight_out, int32_t* vote_class_out,
+                       int32_t* vote_instance_out, int32_t* vote_codeword_out,
+                       float* vote_bbox_quat_out, float* vote_bbox_size_out);
+
+int  ismref_find_maxima(int n_obj, const uint32_t* slot_offsets,
+                        const float* vote_pos, const float* vote_weight, const int32_t* vote_class,
+                        const int32_t* vote_instance, const float* vote_bbox_size,
+                        const ismref_maxima_params* params,
+                        int32_t* n_maxima_out, float* max_pos_out, float* max_weight_out,
+                        int32_t* max_class_out, int32_t* max_instance_out, float* max_instance_weight_out,
+                        float* max_bbox_size_out, int32_t* max_n_votes_out, float* class_score_out);
+
+/* mean-shift building blocks exposed for known-answer tests (voting_mean_shift.cpp:431-481, 331-376) */
+int  ismref_create_seeds(int n, const float* pos, const float* w, float bin_size, int cap,
+                         float* seed_pos_out, float* seed_w_out);
+
+/* pcl::VoxelGrid centroids (keypoints/keypoints_voxel_grid.cpp:30-46): returns number of keypoints */
+int  ismref_voxel_grid(int n, const float* x, const float* y, const float* z, const uint32_t* rgba,
+                       float leaf, int cap, float* kx, float* ky, float* kz, uint32_t* krgba);
+
+/* training-side helper used to build synthetic codebooks the way the reference's train() does with
+ * Clustering "None" and KNN K=1 (implicit_shape_model.cpp:437-490, codebook.cpp:64-224):
+ * class sigma = sample variance of distances between the first <=sqrt(n) features of the class and the
+ * first <=sqrt(n) activated codewords (codebook.cpp:94-193). feat_class[n] ascending by class is NOT required. */
+int  ismref_class_sigmas(int metric, int dim, int n_feat, const float* feats, const uint32_t* feat_class,
+                         const uint32_t* feat_model, const int32_t* activated_word, int n_words, const float* words,
+                         int n_classes, float* sigma_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

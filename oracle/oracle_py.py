@@ -1,0 +1,254 @@
+"""ctypes/numpy binding of the CPU oracle (oracle/libism_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by
+the product package. See oracle/ism_oracle.h for the parity statement (parity unpinned by the reference).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libism_oracle.so")
+_lib = None
+
+
+class MaximaParams(C.Structure):
+    _fields_ = [("n_classes", C.c_int), ("class_bandwidth", C.c_void_p), ("bandwidth", C.c_float),
+                ("threshold", C.c_float), ("max_iter", C.c_int), ("kernel", C.c_int), ("suppression", C.c_int),
+                ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int),
+                ("max_maxima", C.c_int)]
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.ismref_distance.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _u(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.uint32))
+
+
+def _i(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _p(a):
+    return C.c_void_p(0) if a is None else C.c_void_p(a.ctypes.data)
+
+
+def set_num_threads(n):
+    lib().ismref_set_num_threads(C.c_int(n))
+
+
+def get_num_threads():
+    return lib().ismref_get_num_threads()
+
+
+def radius_search(x, y, z, q, radius):
+    x, y, z = _f(x), _f(y), _f(z)
+    n = len(x)
+    idx = np.empty(n, np.int32)
+    d2 = np.empty(n, np.float32)
+    m = lib().ismref_radius_search(C.c_int(n), _p(x), _p(y), _p(z), C.c_float(q[0]), C.c_float(q[1]), C.c_float(q[2]),
+                                   C.c_float(radius), C.c_int(n), _p(idx), _p(d2))
+    return idx[:m].copy(), d2[:m].copy()
+
+
+def shot_lrf(pt_off, x, y, z, kp_off, kx, ky, kz, radius):
+    po, ko = _u(pt_off), _u(kp_off)
+    x, y, z, kx, ky, kz = map(_f, (x, y, z, kx, ky, kz))
+    out = np.empty((int(ko[-1]), 9), np.float32)
+    lib().ismref_shot_lrf(C.c_int(len(po) - 1), _p(po), _p(x), _p(y), _p(z), _p(ko), _p(kx), _p(ky), _p(kz), C.c_float(radius), _p(out))
+    return out
+
+
+def shot352(pt_off, x, y, z, nx, ny, nz, kp_off, kx, ky, kz, lrf, radius):
+    po, ko = _u(pt_off), _u(kp_off)
+    x, y, z, nx, ny, nz, kx, ky, kz, lrf = map(_f, (x, y, z, nx, ny, nz, kx, ky, kz, lrf))
+    n = int(ko[-1])
+    out = np.empty((n, 352), np.float32)
+    cnt = np.empty(n, np.uint32)
+    lib().ismref_shot352(C.c_int(len(po) - 1), _p(po), _p(x), _p(y), _p(z), _p(nx), _p(ny), _p(nz), _p(ko), _p(kx), _p(ky), _p(kz),
+                         _p(lrf), C.c_float(radius), _p(out), _p(cnt))
+    return out, cnt
+
+
+def cshot1344(pt_off, x, y, z, nx, ny, nz, rgba, kp_off, kx, ky, kz, kp_rgba, lrf, radius):
+    po, ko = _u(pt_off), _u(kp_off)
+    x, y, z, nx, ny, nz, kx, ky, kz, lrf = map(_f, (x, y, z, nx, ny, nz, kx, ky, kz, lrf))
+    rgba, kp_rgba = _u(rgba), _u(kp_rgba)
+    n = int(ko[-1])
+    out = np.empty((n, 1344), np.float32)
+    cnt = np.empty(n, np.uint32)
+    rc = lib().ismref_cshot1344(C.c_int(len(po) - 1), _p(po), _p(x), _p(y), _p(z), _p(nx), _p(ny), _p(nz), _p(rgba), _p(ko), _p(kx),
+                                _p(ky), _p(kz), _p(kp_rgba), _p(lrf), C.c_float(radius), _p(out), _p(cnt))
+    assert rc == 0
+    return out, cnt
+
+
+def fpfh33(pt_off, x, y, z, nx, ny, nz, kp_off, kx, ky, kz, radius):
+    po, ko = _u(pt_off), _u(kp_off)
+    x, y, z, nx, ny, nz, kx, ky, kz = map(_f, (x, y, z, nx, ny, nz, kx, ky, kz))
+    n = int(ko[-1])
+    out = np.empty((n, 33), np.float32)
+    cnt = np.empty(n, np.uint32)
+    lib().ismref_fpfh33(C.c_int(len(po) - 1), _p(po), _p(x), _p(y), _p(z), _p(nx), _p(ny), _p(nz), _p(ko), _p(kx), _p(ky), _p(kz),
+                        C.c_float(radius), _p(out), _p(cnt))
+    return out, cnt
+
+
+def centroids(pt_off, x, y, z):
+    po = _u(pt_off)
+    x, y, z = map(_f, (x, y, z))
+    out = np.empty((len(po) - 1, 3), np.float32)
+    lib().ismref_centroids(C.c_int(len(po) - 1), _p(po), _p(x), _p(y), _p(z), _p(out))
+    return out
+
+
+def center_dist(pt_off, x, y, z, kp_off, kx, ky, kz):
+    po, ko = _u(pt_off), _u(kp_off)
+    x, y, z, kx, ky, kz = map(_f, (x, y, z, kx, ky, kz))
+    out = np.empty(int(ko[-1]), np.float32)
+    lib().ismref_center_dist(C.c_int(len(po) - 1), _p(po), _p(x), _p(y), _p(z), _p(ko), _p(kx), _p(ky), _p(kz), _p(out))
+    return out
+
+
+def rgb2lab(rgba):
+    L, a, b = C.c_float(), C.c_float(), C.c_float()
+    lib().ismref_rgb2lab(C.c_uint32(int(rgba)), C.byref(L), C.byref(a), C.byref(b))
+    return L.value, a.value, b.value
+
+
+def pair_features(p1, n1, p2, n2):
+    p1, n1, p2, n2 = map(_f, (p1, n1, p2, n2))
+    out = np.zeros(4, np.float32)
+    ok = lib().ismref_pair_features(_p(p1), _p(n1), _p(p2), _p(n2), _p(out))
+    return bool(ok), out
+
+
+def distance(metric, a, b):
+    a, b = _f(a), _f(b)
+    return float(lib().ismref_distance(C.c_int(metric), C.c_int(len(a)), _p(a), _p(b)))
+
+
+def knn(metric, words, q, k=1):
+    words, q = _f(words), _f(q)
+    nq = q.shape[0]
+    idx = np.empty((nq, k), np.int32)
+    dist = np.empty((nq, k), np.float32)
+    lib().ismref_knn(C.c_int(metric), C.c_int(words.shape[0]), C.c_int(words.shape[1]), _p(words), C.c_int(nq), _p(q), C.c_int(k),
+                     _p(idx), _p(dist))
+    return idx, dist
+
+
+def knn_ratio(metric, words, q, thr):
+    words, q = _f(words), _f(q)
+    nq = q.shape[0]
+    idx = np.empty((nq, 1), np.int32)
+    dist = np.empty((nq, 1), np.float32)
+    lib().ismref_knn_ratio(C.c_int(metric), C.c_int(words.shape[0]), C.c_int(words.shape[1]), _p(words), C.c_int(nq), _p(q), C.c_float(thr),
+                           _p(idx), _p(dist))
+    return idx, dist
+
+
+def rot_quaternion(lrf9):
+    l = _f(lrf9).reshape(9)
+    out = np.empty(4, np.float32)
+    lib().ismref_rot_quaternion(_p(l), _p(out))
+    return out
+
+
+def rotate_into(lrf9, v):
+    l, v = _f(lrf9).reshape(9), _f(v)
+    out = np.empty(3, np.float32)
+    lib().ismref_rotate_into(_p(l), _p(v), _p(out))
+    return out
+
+
+def rotate_back(lrf9, v):
+    l, v = _f(lrf9).reshape(9), _f(v)
+    out = np.empty(3, np.float32)
+    lib().ismref_rotate_back(_p(l), _p(v), _p(out))
+    return out
+
+
+def cast_votes(cb, weight_flags, lrf, kx, ky, kz, idx, dist):
+    """cb: dict with words, vote_offsets, vote_xyz, vote_class, vote_instance, class_sigma (+ optional weights/bbox)"""
+    words = _f(cb["words"])
+    vo = _u(cb["vote_offsets"])
+    idx, dist = _i(idx), _f(dist)
+    nq, k = idx.shape
+    maxv = int(np.max(np.diff(vo))) if len(vo) > 1 else 0
+    ns = nq * k * maxv
+    pos = np.empty((ns, 3), np.float32); w = np.empty(ns, np.float32)
+    cls = np.empty(ns, np.int32); inst = np.empty(ns, np.int32); cw = np.empty(ns, np.int32)
+    bq = np.empty((ns, 4), np.float32); bs = np.empty((ns, 3), np.float32)
+    sig = _f(cb["class_sigma"])
+    args = [_f(cb.get("word_weight")), vo, _f(cb["vote_xyz"]), _f(cb.get("vote_weight")), _f(cb.get("vote_class_weight")),
+            _u(cb["vote_class"]), _u(cb["vote_instance"]), _f(cb.get("vote_bbox_quat")), _f(cb.get("vote_bbox_size"))]
+    lrf, kx, ky, kz = map(_f, (lrf, kx, ky, kz))
+    lib().ismref_cast_votes(C.c_int(words.shape[0]), C.c_int(words.shape[1]), *[_p(a) for a in args], C.c_int(len(sig)), _p(sig),
+                            C.c_uint32(weight_flags), C.c_int(nq), _p(lrf), _p(kx), _p(ky), _p(kz), C.c_int(k), _p(idx), _p(dist),
+                            _p(pos), _p(w), _p(cls), _p(inst), _p(cw), _p(bq), _p(bs))
+    return dict(pos=pos, weight=w, cls=cls, inst=inst, codeword=cw, bbox_quat=bq, bbox_size=bs)
+
+
+def find_maxima(slot_offsets, votes, n_classes, bandwidth, threshold=1e-3, max_iter=1000, kernel=0, suppression=0,
+                min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16, class_bandwidth=None):
+    so = _u(slot_offsets)
+    n_obj = len(so) - 1
+    cbw = _f(class_bandwidth)
+    P = MaximaParams(n_classes, cbw.ctypes.data if cbw is not None else None, bandwidth, threshold, max_iter, kernel, suppression,
+                     min_votes_threshold, min_threshold, best_k, max_maxima)
+    out = dict(n=np.empty(n_obj, np.int32), pos=np.empty((n_obj, max_maxima, 3), np.float32),
+               weight=np.empty((n_obj, max_maxima), np.float32), cls=np.empty((n_obj, max_maxima), np.int32),
+               inst=np.empty((n_obj, max_maxima), np.int32), inst_weight=np.empty((n_obj, max_maxima), np.float32),
+               bbox_size=np.empty((n_obj, max_maxima, 3), np.float32), n_votes=np.empty((n_obj, max_maxima), np.int32),
+               class_score=np.empty((n_obj, n_classes), np.float32))
+    pos, w, cls, inst = _f(votes["pos"]), _f(votes["weight"]), _i(votes["cls"]), _i(votes["inst"])
+    bs = _f(votes.get("bbox_size"))
+    lib().ismref_find_maxima(C.c_int(n_obj), _p(so), _p(pos), _p(w), _p(cls), _p(inst), _p(bs), C.byref(P), _p(out["n"]), _p(out["pos"]),
+                             _p(out["weight"]), _p(out["cls"]), _p(out["inst"]), _p(out["inst_weight"]), _p(out["bbox_size"]),
+                             _p(out["n_votes"]), _p(out["class_score"]))
+    return out
+
+
+def create_seeds(pos, w, bin_size):
+    pos, w = _f(pos), _f(w)
+    n = len(w)
+    sp = np.empty((max(n, 1), 3), np.float32); sw = np.empty(max(n, 1), np.float32)
+    m = lib().ismref_create_seeds(C.c_int(n), _p(pos), _p(w), C.c_float(bin_size), C.c_int(n), _p(sp), _p(sw))
+    return sp[:m].copy(), sw[:m].copy()
+
+
+def voxel_grid(x, y, z, leaf, rgba=None):
+    x, y, z = map(_f, (x, y, z))
+    rgba = _u(rgba)
+    n = len(x)
+    kx = np.empty(n, np.float32); ky = np.empty(n, np.float32); kz = np.empty(n, np.float32); kc = np.empty(n, np.uint32)
+    m = lib().ismref_voxel_grid(C.c_int(n), _p(x), _p(y), _p(z), _p(rgba), C.c_float(leaf), C.c_int(n), _p(kx), _p(ky), _p(kz), _p(kc))
+    return kx[:m].copy(), ky[:m].copy(), kz[:m].copy(), kc[:m].copy()
+
+
+def class_sigmas(metric, feats, feat_class, feat_model, activated_word, words, n_classes):
+    feats, words = _f(feats), _f(words)
+    out = np.empty(n_classes, np.float32)
+    lib().ismref_class_sigmas(C.c_int(metric), C.c_int(feats.shape[1]), C.c_int(feats.shape[0]), _p(feats), _p(_u(feat_class)),
+                              _p(_u(feat_model)), _p(_i(activated_word)), C.c_int(words.shape[0]), _p(words), C.c_int(n_classes), _p(out))
+    return out

@@ -1,0 +1,310 @@
+"""ctypes binding of libismhip.so (include/ismhip.h) for the Python test / bench harness.
+
+The product is the shared library; this module only marshals pointers. torch is used for device memory
+(tensor.data_ptr()) and streams; no torch type crosses the C ABI. There is no CPU fallback: if the
+library or a gfx950 device is missing, loading / ctx creation raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libismhip.so")
+
+METRIC_L2SQ, METRIC_CHI2 = 0, 1
+W_CLASS, W_VOTE, W_MATCHING, W_CODEWORD = 1, 2, 4, 8
+KERNEL_GAUSSIAN, KERNEL_UNIFORM = 0, 1
+SUPPRESS_AVERAGE, SUPPRESS_SUPPRESS, SUPPRESS_NONE = 0, 1, 2
+ERR_NODEVICE = -5
+
+EXPORTS = [
+    "ismhip_abi_version", "ismhip_ctx_create", "ismhip_ctx_destroy", "ismhip_sync", "ismhip_last_error",
+    "ismhip_timers_enable", "ismhip_timers_reset", "ismhip_timer_get",
+    "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids",
+    "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
+    "ismhip_compact_features",
+    "ismhip_codebook_create", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word",
+    "ismhip_knn", "ismhip_knn_ratio", "ismhip_cast_votes", "ismhip_find_maxima",
+]
+
+
+class MaximaParams(C.Structure):
+    _fields_ = [("n_classes", C.c_int), ("class_bandwidth_h", C.c_void_p), ("bandwidth", C.c_float),
+                ("threshold", C.c_float), ("max_iter", C.c_int), ("kernel", C.c_int), ("suppression", C.c_int),
+                ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int),
+                ("max_maxima", C.c_int)]
+
+
+class IsmHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libismhip.so (once). Raises if it has not been built — the hot path has no other back end."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IsmHipError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C point-cloud-donkey_amd/csrc)")
+        L = C.CDLL(LIB_PATH)
+        L.ismhip_last_error.restype = C.c_char_p
+        L.ismhip_last_error.argtypes = [C.c_void_p]
+        for name in EXPORTS:
+            fn = getattr(L, name)
+            if name != "ismhip_last_error":
+                fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(t):
+    """device pointer of a torch tensor / host pointer of a numpy array / None"""
+    if t is None:
+        return C.c_void_p(0)
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"]
+        return C.c_void_p(t.ctypes.data)
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def _u32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint32))
+
+
+class Ctx:
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        rc = lib().ismhip_ctx_create(C.c_int(device), C.c_void_p(stream or 0), C.byref(self._h))
+        if rc != 0:
+            raise IsmHipError(f"ismhip_ctx_create failed ({rc}); a gfx950 device is required, there is no CPU fallback")
+        self.device = device
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise IsmHipError(f"{what} failed ({rc}): {lib().ismhip_last_error(self._h).decode()}")
+
+    def sync(self):
+        self.check(lib().ismhip_sync(self._h), "ismhip_sync")
+
+    def timers_enable(self, on=True):
+        self.check(lib().ismhip_timers_enable(self._h, C.c_int(1 if on else 0)), "timers_enable")
+
+    def timers_reset(self):
+        self.check(lib().ismhip_timers_reset(self._h), "timers_reset")
+
+    def timer(self, name):
+        ms, n = C.c_double(), C.c_int64()
+        self.check(lib().ismhip_timer_get(self._h, name.encode(), C.byref(ms), C.byref(n)), "timer_get")
+        return ms.value, n.value
+
+    def close(self):
+        if self._h:
+            lib().ismhip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Cloud:
+    """ismhip_cloud: search surface of a batch of objects (device SoA tensors are borrowed, keep them alive)."""
+
+    def __init__(self, ctx, pt_offsets, x, y, z, nx, ny, nz, cell_size, rgba=None):
+        self.ctx = ctx
+        self.pt_offsets = _u32(pt_offsets)
+        self.n_obj = len(self.pt_offsets) - 1
+        self._keep = (x, y, z, nx, ny, nz, rgba)
+        self._h = C.c_void_p()
+        rc = lib().ismhip_cloud_create(ctx._h, C.c_int(self.n_obj), _p(self.pt_offsets), _p(x), _p(y), _p(z), _p(nx), _p(ny),
+                                       _p(nz), _p(rgba), C.c_float(cell_size), C.byref(self._h))
+        ctx.check(rc, "ismhip_cloud_create")
+
+    def close(self):
+        if self._h:
+            lib().ismhip_cloud_destroy(self.ctx._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Codebook:
+    def __init__(self, ctx, words, vote_offsets, vote_xyz, vote_class, vote_instance, n_classes, class_sigma,
+                 word_weight=None, vote_weight=None, vote_class_weight=None, vote_bbox_quat=None, vote_bbox_size=None):
+        f32 = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        self.ctx = ctx
+        words = f32(words)
+        self.n_words, self.dim = words.shape
+        self.n_classes = int(n_classes)
+        self._h = C.c_void_p()
+        rc = lib().ismhip_codebook_create(ctx._h, C.c_int(self.n_words), C.c_int(self.dim), _p(words), _p(f32(word_weight)),
+                                          _p(_u32(vote_offsets)), _p(f32(vote_xyz)), _p(f32(vote_weight)),
+                                          _p(f32(vote_class_weight)), _p(_u32(vote_class)), _p(_u32(vote_instance)),
+                                          _p(f32(vote_bbox_quat)), _p(f32(vote_bbox_size)), C.c_int(self.n_classes),
+                                          _p(f32(class_sigma)), C.byref(self._h))
+        ctx.check(rc, "ismhip_codebook_create")
+        self.max_votes = lib().ismhip_codebook_max_votes_per_word(self._h)
+
+    def close(self):
+        if self._h:
+            lib().ismhip_codebook_destroy(self.ctx._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def shot_lrf(ctx, cloud, kp_offsets, kpx, kpy, kpz, radius):
+    torch = _torch()
+    ko = _u32(kp_offsets)
+    out = torch.empty((int(ko[-1]), 9), dtype=torch.float32, device=kpx.device)
+    ctx.check(lib().ismhip_shot_lrf(ctx._h, cloud._h, _p(ko), _p(kpx), _p(kpy), _p(kpz), C.c_float(radius), _p(out)), "ismhip_shot_lrf")
+    return out
+
+
+def shot352(ctx, cloud, kp_offsets, kpx, kpy, kpz, lrf, radius, want_counts=False):
+    torch = _torch()
+    ko = _u32(kp_offsets)
+    n = int(ko[-1])
+    out = torch.empty((n, 352), dtype=torch.float32, device=kpx.device)
+    cnt = torch.empty((n,), dtype=torch.int32, device=kpx.device) if want_counts else None
+    ctx.check(lib().ismhip_shot352(ctx._h, cloud._h, _p(ko), _p(kpx), _p(kpy), _p(kpz), _p(lrf), C.c_float(radius), _p(out), _p(cnt)),
+              "ismhip_shot352")
+    return (out, cnt) if want_counts else out
+
+
+def cshot1344(ctx, cloud, kp_offsets, kpx, kpy, kpz, kp_rgba, lrf, radius, want_counts=False):
+    torch = _torch()
+    ko = _u32(kp_offsets)
+    n = int(ko[-1])
+    out = torch.empty((n, 1344), dtype=torch.float32, device=kpx.device)
+    cnt = torch.empty((n,), dtype=torch.int32, device=kpx.device) if want_counts else None
+    ctx.check(lib().ismhip_cshot1344(ctx._h, cloud._h, _p(ko), _p(kpx), _p(kpy), _p(kpz), _p(kp_rgba), _p(lrf), C.c_float(radius),
+                                     _p(out), _p(cnt)), "ismhip_cshot1344")
+    return (out, cnt) if want_counts else out
+
+
+def fpfh33(ctx, cloud, kp_offsets, kpx, kpy, kpz, radius, want_counts=False):
+    torch = _torch()
+    ko = _u32(kp_offsets)
+    n = int(ko[-1])
+    out = torch.empty((n, 33), dtype=torch.float32, device=kpx.device)
+    cnt = torch.empty((n,), dtype=torch.int32, device=kpx.device) if want_counts else None
+    ctx.check(lib().ismhip_fpfh33(ctx._h, cloud._h, _p(ko), _p(kpx), _p(kpy), _p(kpz), C.c_float(radius), _p(out), _p(cnt)),
+              "ismhip_fpfh33")
+    return (out, cnt) if want_counts else out
+
+
+def cloud_centroids(ctx, cloud, device):
+    torch = _torch()
+    out = torch.empty((cloud.n_obj, 3), dtype=torch.float32, device=device)
+    ctx.check(lib().ismhip_cloud_centroids(ctx._h, cloud._h, _p(out)), "ismhip_cloud_centroids")
+    return out
+
+
+def center_dist(ctx, cloud, kp_offsets, kpx, kpy, kpz):
+    torch = _torch()
+    ko = _u32(kp_offsets)
+    out = torch.empty((int(ko[-1]),), dtype=torch.float32, device=kpx.device)
+    ctx.check(lib().ismhip_center_dist(ctx._h, cloud._h, _p(ko), _p(kpx), _p(kpy), _p(kpz), _p(out)), "ismhip_center_dist")
+    return out
+
+
+def compact_features(ctx, kp_offsets, desc, lrf, kpx, kpy, kpz):
+    """returns (keep_offsets, desc, lrf, kpx, kpy, kpz, src_index) with NaN rows removed (order preserved)"""
+    torch = _torch()
+    ko = _u32(kp_offsets)
+    n_obj = len(ko) - 1
+    n, dim = desc.shape
+    d_o = torch.empty_like(desc)
+    l_o = torch.empty_like(lrf) if lrf is not None else None
+    x_o, y_o, z_o = torch.empty_like(kpx), torch.empty_like(kpy), torch.empty_like(kpz)
+    src = torch.empty((n,), dtype=torch.int32, device=desc.device)
+    keep = np.zeros(n_obj + 1, dtype=np.uint32)
+    ctx.check(lib().ismhip_compact_features(ctx._h, C.c_int(n_obj), _p(ko), C.c_int(dim), _p(desc), _p(lrf), _p(kpx), _p(kpy), _p(kpz),
+                                            _p(d_o), _p(l_o), _p(x_o), _p(y_o), _p(z_o), _p(src), _p(keep)), "ismhip_compact_features")
+    m = int(keep[-1])
+    return keep, d_o[:m], (l_o[:m] if l_o is not None else None), x_o[:m], y_o[:m], z_o[:m], src[:m]
+
+
+def knn(ctx, cb, metric, q, k=1):
+    torch = _torch()
+    nq = q.shape[0]
+    idx = torch.empty((nq, k), dtype=torch.int32, device=q.device)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+    ctx.check(lib().ismhip_knn(ctx._h, cb._h, C.c_int(metric), C.c_int(nq), _p(q), C.c_int(k), _p(idx), _p(dist)), "ismhip_knn")
+    return idx, dist
+
+
+def knn_ratio(ctx, cb, metric, q, ratio_threshold):
+    torch = _torch()
+    nq = q.shape[0]
+    idx = torch.empty((nq, 1), dtype=torch.int32, device=q.device)
+    dist = torch.empty((nq, 1), dtype=torch.float32, device=q.device)
+    ctx.check(lib().ismhip_knn_ratio(ctx._h, cb._h, C.c_int(metric), C.c_int(nq), _p(q), C.c_float(ratio_threshold), _p(idx), _p(dist)),
+              "ismhip_knn_ratio")
+    return idx, dist
+
+
+def cast_votes(ctx, cb, weight_flags, lrf, kpx, kpy, kpz, idx, dist, want_bbox=False):
+    torch = _torch()
+    nq, k = idx.shape
+    ns = nq * k * max(cb.max_votes, 0)
+    dev = idx.device
+    pos = torch.empty((ns, 3), dtype=torch.float32, device=dev)
+    w = torch.empty((ns,), dtype=torch.float32, device=dev)
+    cls = torch.empty((ns,), dtype=torch.int32, device=dev)
+    inst = torch.empty((ns,), dtype=torch.int32, device=dev)
+    cw = torch.empty((ns,), dtype=torch.int32, device=dev)
+    bq = torch.empty((ns, 4), dtype=torch.float32, device=dev) if want_bbox else None
+    bs = torch.empty((ns, 3), dtype=torch.float32, device=dev) if want_bbox else None
+    ctx.check(lib().ismhip_cast_votes(ctx._h, cb._h, C.c_uint32(weight_flags), C.c_int(nq), _p(lrf), _p(kpx), _p(kpy), _p(kpz), C.c_int(k),
+                                      _p(idx), _p(dist), _p(pos), _p(w), _p(cls), _p(inst), _p(cw), _p(bq), _p(bs)), "ismhip_cast_votes")
+    return dict(pos=pos, weight=w, cls=cls, inst=inst, codeword=cw, bbox_quat=bq, bbox_size=bs)
+
+
+def find_maxima(ctx, slot_offsets, votes, n_classes, bandwidth, threshold=1e-3, max_iter=1000, kernel=KERNEL_GAUSSIAN,
+                suppression=SUPPRESS_AVERAGE, min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16,
+                class_bandwidth=None):
+    torch = _torch()
+    so = _u32(slot_offsets)
+    n_obj = len(so) - 1
+    dev = votes["pos"].device
+    cbw = None if class_bandwidth is None else np.ascontiguousarray(np.asarray(class_bandwidth, dtype=np.float32))
+    P = MaximaParams(n_classes, cbw.ctypes.data if cbw is not None else None, bandwidth, threshold, max_iter, kernel, suppression,
+                     min_votes_threshold, min_threshold, best_k, max_maxima)
+    out = dict(
+        n=torch.empty((n_obj,), dtype=torch.int32, device=dev),
+        pos=torch.empty((n_obj, max_maxima, 3), dtype=torch.float32, device=dev),
+        weight=torch.empty((n_obj, max_maxima), dtype=torch.float32, device=dev),
+        cls=torch.empty((n_obj, max_maxima), dtype=torch.int32, device=dev),
+        inst=torch.empty((n_obj, max_maxima), dtype=torch.int32, device=dev),
+        inst_weight=torch.empty((n_obj, max_maxima), dtype=torch.float32, device=dev),
+        bbox_size=torch.empty((n_obj, max_maxima, 3), dtype=torch.float32, device=dev),
+        n_votes=torch.empty((n_obj, max_maxima), dtype=torch.int32, device=dev),
+        class_score=torch.empty((n_obj, n_classes), dtype=torch.float32, device=dev),
+    )
+    ctx.check(lib().ismhip_find_maxima(ctx._h, C.c_int(n_obj), _p(so), _p(votes["pos"]), _p(votes["weight"]), _p(votes["cls"]),
+                                       _p(votes["inst"]), _p(votes.get("bbox_size")), C.byref(P), _p(out["n"]), _p(out["pos"]),
+                                       _p(out["weight"]), _p(out["cls"]), _p(out["inst"]), _p(out["inst_weight"]), _p(out["bbox_size"]),
+                                       _p(out["n_votes"]), _p(out["class_score"])), "ismhip_find_maxima")
+    return out

@@ -1,0 +1,216 @@
+// codebook.hip — device-resident codebook (FlannHelper dataset + CodewordDistribution vote tables) and vote casting.
+// Reference: utils/flann_helper.cpp:21-70 (row-major Nc x D dataset in getCodewords() order),
+// codebook/codeword_distribution.cpp:73-167 (castVotes / castVote), codebook/codebook.cpp:541-554 (second loop of
+// Codebook::castVotes), utils/utils.cpp:136-178, 342-394, 560-574 (LRF -> quaternion, rotateBack), voting/voting.cpp:58-77.
+//
+// HBM layout: words [n_words_pad x dim_pad] zero-padded so the kNN tiles never branch on bounds (n_words_pad multiple
+// of 128, dim_pad multiple of 32); votes as CSR over words with SoA payloads. Vote casting is HBM-bound
+// (V*(12+4+4+4) read + V*32 written) and tiny next to kNN.
+#include "common.h"
+#include <cmath>
+#include <limits>
+
+namespace {
+
+__global__ void k_word_norms(const float* __restrict__ words, int n_words, int n_words_pad, int dim_pad, float* __restrict__ norm) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_words_pad) return;
+    const int lane = lane_id();
+    float s = 0.f;
+    for (int c = lane; c < dim_pad; c += 64) { const float v = words[(size_t)row * dim_pad + c]; s += v * v; }
+    s = wave_sum_f(s);
+    if (lane == 0) norm[row] = row < n_words ? s : __builtin_inff();   // padding rows can never win
+}
+
+struct Quat { float w, x, y, z; };
+__device__ __forceinline__ Quat qmul(const Quat& a, const Quat& b) {     // boost::math::quaternion operator*
+    Quat r;
+    r.w = +a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = +a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = +a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    r.z = +a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return r;
+}
+__device__ __forceinline__ Quat qconj(const Quat& q) { return Quat{q.w, -q.x, -q.y, -q.z}; }
+
+// Utils::getRotQuaternion + matrix2Quat: rows of the matrix are the LRF axes
+__device__ __forceinline__ Quat rot_quaternion(const float* l) {
+    const float m[3][3] = {{l[0], l[1], l[2]}, {l[3], l[4], l[5]}, {l[6], l[7], l[8]}};
+    float q[4] = {0.f, 0.f, 0.f, 1.f};   // x,y,z,w
+    const float trace = m[0][0] + m[1][1] + m[2][2];
+    float root;
+    if (trace > 0.0f) {
+        root = sqrtf(trace + 1.0f);
+        q[3] = 0.5f * root;
+        root = 0.5f / root;
+        q[0] = (m[2][1] - m[1][2]) * root;
+        q[1] = (m[0][2] - m[2][0]) * root;
+        q[2] = (m[1][0] - m[0][1]) * root;
+    } else {
+        int i = 0;
+        if (m[1][1] > m[0][0]) i = 1;
+        if (m[2][2] > m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        root = sqrtf((float)((double)(m[i][i] - m[j][j] - m[k][k]) + 1.0));
+        q[i] = 0.5f * root;
+        root = 0.5f / root;
+        q[3] = (m[k][j] - m[j][k]) * root;
+        q[j] = (m[j][i] + m[i][j]) * root;
+        q[k] = (m[k][i] + m[i][k]) * root;
+    }
+    return Quat{q[3], q[0], q[1], q[2]};
+}
+
+struct VoteArgs {
+    const float* word_weight; const uint32_t* vote_off; const float* vote_xyz; const float* vote_weight;
+    const float* vote_class_weight; const uint32_t* vote_class; const uint32_t* vote_instance;
+    const float* vote_bbox_quat; const float* vote_bbox_size; const float* class_sigma;
+    int n_words, n_classes, maxv; uint32_t flags;
+    int nq, k; const float* lrf; const float *kx, *ky, *kz; const int32_t* idx; const float* dist;
+    float* pos; float* w; int32_t* cls; int32_t* inst; int32_t* cw; float* bq; float* bs;
+};
+
+__global__ __launch_bounds__(256) void k_cast_votes(VoteArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.nq * a.k) return;
+    const int f = t / a.k;
+    const size_t slot0 = (size_t)t * a.maxv;
+    for (int v = 0; v < a.maxv; ++v) {
+        const size_t s = slot0 + v;
+        a.cls[s] = -1; a.inst[s] = -1; a.cw[s] = -1; a.w[s] = 0.f;
+        a.pos[s * 3] = 0.f; a.pos[s * 3 + 1] = 0.f; a.pos[s * 3 + 2] = 0.f;
+        if (a.bq) { a.bq[s * 4] = 1.f; a.bq[s * 4 + 1] = 0.f; a.bq[s * 4 + 2] = 0.f; a.bq[s * 4 + 3] = 0.f; }
+        if (a.bs) { a.bs[s * 3] = 0.f; a.bs[s * 3 + 1] = 0.f; a.bs[s * 3 + 2] = 0.f; }
+    }
+    const int c = a.idx[t];
+    if (c < 0 || c >= a.n_words) return;
+    const float d = a.dist[t];                                               // codeword_distribution.cpp:87
+    const Quat rq = rot_quaternion(a.lrf + (size_t)f * 9);
+    const Quat rqc = qconj(rq);
+    const uint32_t v0 = a.vote_off[c], v1 = a.vote_off[c + 1];
+    for (uint32_t v = v0; v < v1; ++v) {
+        const size_t s = slot0 + (v - v0);
+        const uint32_t classId = a.vote_class[v];
+        const float classWeight = a.vote_class_weight ? a.vote_class_weight[v] : 1.0f;
+        const float classSigma = ((int)classId < a.n_classes) ? a.class_sigma[classId] : 1.0f;   // :108-117
+        float weight = 1.0f;
+        if (a.flags & ISMHIP_W_CLASS) weight = weight * classWeight;
+        if (a.flags & ISMHIP_W_VOTE) weight = weight * (a.vote_weight ? a.vote_weight[v] : 1.0f);
+        if (a.flags & ISMHIP_W_MATCHING) {
+            // gaussDist (:23-26), evaluated in double like the reference
+            const double sg = (double)classSigma, dd = (double)d;
+            const float matching = (float)((1.0 / sqrt(2.0 * 3.14159265358979323846 * sg)) * exp(-(dd * dd) / (2.0 * sg)));
+            weight = weight * matching;
+        }
+        if (a.flags & ISMHIP_W_CODEWORD) weight = weight * (a.word_weight ? a.word_weight[c] : 1.0f);
+        if (fabsf(d) > 2 * classSigma) continue;                              // :131
+        if (weight < 1.1920928955078125e-07f) continue;                       // :137 FLT_EPSILON
+        // rotateBack: conj(q) * p * q  (utils.cpp:167-178, 560-566)
+        const Quat p{0.f, a.vote_xyz[v * 3], a.vote_xyz[v * 3 + 1], a.vote_xyz[v * 3 + 2]};
+        const Quat rb = qmul(qmul(rqc, p), rq);
+        a.pos[s * 3 + 0] = a.kx[f] + rb.x; a.pos[s * 3 + 1] = a.ky[f] + rb.y; a.pos[s * 3 + 2] = a.kz[f] + rb.z;
+        a.w[s] = weight; a.cls[s] = (int32_t)classId; a.inst[s] = (int32_t)a.vote_instance[v]; a.cw[s] = c;
+        if (a.bq) {
+            const Quat b = a.vote_bbox_quat ? Quat{a.vote_bbox_quat[v * 4], a.vote_bbox_quat[v * 4 + 1], a.vote_bbox_quat[v * 4 + 2], a.vote_bbox_quat[v * 4 + 3]}
+                                            : Quat{1.f, 0.f, 0.f, 0.f};
+            const Quat r = qmul(b, rq);                                       // :162
+            a.bq[s * 4] = r.w; a.bq[s * 4 + 1] = r.x; a.bq[s * 4 + 2] = r.y; a.bq[s * 4 + 3] = r.z;
+        }
+        if (a.bs && a.vote_bbox_size) { a.bs[s * 3] = a.vote_bbox_size[v * 3]; a.bs[s * 3 + 1] = a.vote_bbox_size[v * 3 + 1]; a.bs[s * 3 + 2] = a.vote_bbox_size[v * 3 + 2]; }
+    }
+}
+
+template <typename Tt>
+bool upload(Tt** dst, const Tt* src_h, size_t n) {
+    if (n == 0) n = 1;
+    if (hipMalloc((void**)dst, n * sizeof(Tt)) != hipSuccess) return false;
+    if (src_h && hipMemcpy(*dst, src_h, n * sizeof(Tt), hipMemcpyHostToDevice) != hipSuccess) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* words_h, const float* word_weight_h,
+                           const uint32_t* vote_offsets_h, const float* vote_xyz_h, const float* vote_weight_h,
+                           const float* vote_class_weight_h, const uint32_t* vote_class_h, const uint32_t* vote_instance_h,
+                           const float* vote_bbox_quat_h, const float* vote_bbox_size_h,
+                           int n_classes, const float* class_sigma_h, ismhip_codebook** out) {
+    if (!ctx || !out || n_words <= 0 || dim <= 0 || !words_h || !vote_offsets_h || !vote_xyz_h || !vote_class_h ||
+        !vote_instance_h || n_classes <= 0 || !class_sigma_h)
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "codebook_create: bad argument");
+    *out = nullptr;
+    if (vote_offsets_h[0] != 0) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "codebook_create: vote offsets must start at 0");
+    int maxv = 0;
+    for (int c = 0; c < n_words; ++c) {
+        if (vote_offsets_h[c + 1] < vote_offsets_h[c]) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "codebook_create: vote offsets not monotone");
+        maxv = std::max(maxv, (int)(vote_offsets_h[c + 1] - vote_offsets_h[c]));
+    }
+    ISM_HIP(ctx, hipSetDevice(ctx->device));
+    ismhip_codebook* cb = new ismhip_codebook();
+    cb->n_words = n_words; cb->dim = dim; cb->n_classes = n_classes;
+    cb->dim_pad = (dim + 31) / 32 * 32;
+    cb->n_words_pad = (n_words + 127) / 128 * 128;
+    cb->n_votes = (int)vote_offsets_h[n_words]; cb->max_votes = maxv;
+    auto fail = [&](int code, const char* msg) { ismhip_codebook_destroy(ctx, cb); return ism_set_err(ctx, code, msg); };
+    const size_t wbytes = (size_t)cb->n_words_pad * cb->dim_pad * sizeof(float);
+    if (hipMalloc((void**)&cb->words, wbytes) != hipSuccess) return fail(ISMHIP_ERR_NOMEM, "codebook_create: words");
+    if (hipMemset(cb->words, 0, wbytes) != hipSuccess) return fail(ISMHIP_ERR_HIP, "codebook_create: memset");
+    if (hipMemcpy2D(cb->words, (size_t)cb->dim_pad * 4, words_h, (size_t)dim * 4, (size_t)dim * 4, n_words, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(ISMHIP_ERR_HIP, "codebook_create: words copy");
+    if (hipMalloc((void**)&cb->word_norm, (size_t)cb->n_words_pad * 4) != hipSuccess) return fail(ISMHIP_ERR_NOMEM, "codebook_create: norms");
+    const size_t nv = cb->n_votes;
+    bool ok = upload(&cb->vote_off, vote_offsets_h, (size_t)n_words + 1) && upload(&cb->vote_xyz, vote_xyz_h, nv * 3) &&
+              upload(&cb->vote_class, vote_class_h, nv) && upload(&cb->vote_instance, vote_instance_h, nv) &&
+              upload(&cb->class_sigma, class_sigma_h, (size_t)n_classes);
+    if (ok && word_weight_h) ok = upload(&cb->word_weight, word_weight_h, (size_t)n_words);
+    if (ok && vote_weight_h) ok = upload(&cb->vote_weight, vote_weight_h, nv);
+    if (ok && vote_class_weight_h) ok = upload(&cb->vote_class_weight, vote_class_weight_h, nv);
+    if (ok && vote_bbox_quat_h) ok = upload(&cb->vote_bbox_quat, vote_bbox_quat_h, nv * 4);
+    if (ok && vote_bbox_size_h) ok = upload(&cb->vote_bbox_size, vote_bbox_size_h, nv * 3);
+    if (!ok) return fail(ISMHIP_ERR_NOMEM, "codebook_create: vote tables");
+    hipLaunchKernelGGL(k_word_norms, dim3((cb->n_words_pad + 3) / 4), dim3(256), 0, ctx->stream, cb->words, n_words, cb->n_words_pad, cb->dim_pad, cb->word_norm);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ISMHIP_ERR_HIP, "codebook_create: norms kernel");
+    *out = cb;
+    return ISMHIP_OK;
+}
+
+int ismhip_codebook_destroy(ismhip_ctx* ctx, ismhip_codebook* cb) {
+    if (!cb) return ISMHIP_ERR_INVALID;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    void* ptrs[] = {cb->words, cb->word_norm, cb->word_weight, cb->vote_off, cb->vote_xyz, cb->vote_weight, cb->vote_class_weight,
+                    cb->vote_class, cb->vote_instance, cb->vote_bbox_quat, cb->vote_bbox_size, cb->class_sigma};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete cb;
+    return ISMHIP_OK;
+}
+
+int ismhip_codebook_max_votes_per_word(const ismhip_codebook* cb) { return cb ? cb->max_votes : ISMHIP_ERR_INVALID; }
+
+int ismhip_cast_votes(ismhip_ctx* ctx, const ismhip_codebook* cb, uint32_t weight_flags,
+                      int nq, const float* lrf9, const float* kpx, const float* kpy, const float* kpz,
+                      int k, const int32_t* idx, const float* dist,
+                      float* vote_pos_out, float* vote_weight_out, int32_t* vote_class_out,
+                      int32_t* vote_instance_out, int32_t* vote_codeword_out,
+                      float* vote_bbox_quat_out, float* vote_bbox_size_out) {
+    if (!ctx || !cb || nq < 0 || k <= 0 || !lrf9 || !kpx || !kpy || !kpz || !idx || !dist || !vote_pos_out || !vote_weight_out ||
+        !vote_class_out || !vote_instance_out || !vote_codeword_out)
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "cast_votes: bad argument");
+    if (nq == 0 || cb->max_votes == 0) return ISMHIP_OK;
+    VoteArgs a;
+    a.word_weight = cb->word_weight; a.vote_off = cb->vote_off; a.vote_xyz = cb->vote_xyz; a.vote_weight = cb->vote_weight;
+    a.vote_class_weight = cb->vote_class_weight; a.vote_class = cb->vote_class; a.vote_instance = cb->vote_instance;
+    a.vote_bbox_quat = cb->vote_bbox_quat; a.vote_bbox_size = cb->vote_bbox_size; a.class_sigma = cb->class_sigma;
+    a.n_words = cb->n_words; a.n_classes = cb->n_classes; a.maxv = cb->max_votes; a.flags = weight_flags;
+    a.nq = nq; a.k = k; a.lrf = lrf9; a.kx = kpx; a.ky = kpy; a.kz = kpz; a.idx = idx; a.dist = dist;
+    a.pos = vote_pos_out; a.w = vote_weight_out; a.cls = vote_class_out; a.inst = vote_instance_out; a.cw = vote_codeword_out;
+    a.bq = vote_bbox_quat_out; a.bs = vote_bbox_size_out;
+    TimerScope ts(ctx, "cast_votes");
+    const int n = nq * k;
+    hipLaunchKernelGGL(k_cast_votes, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
+    ISM_CHECK_LAUNCH(ctx, "k_cast_votes");
+    return ISMHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+// common.h — internal definitions shared by the HIP translation units of libismhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/ismhip.h"
+
+#define ISM_WAVE 64
+
+// ---- per-object uniform grid (device-resident) ------------------------------------------------
+#define ISM_GRID_MAXDIM 32                      // cells per axis (cell edge doubles until the object fits)
+#define ISM_GRID_MAXCELLS (ISM_GRID_MAXDIM * ISM_GRID_MAXDIM * ISM_GRID_MAXDIM)
+#define ISM_GRID_STRIDE (ISM_GRID_MAXCELLS + 1) // cell_start entries reserved per object
+
+struct GridMeta {
+    float minv[3];
+    float cell;       // edge actually used (>= requested)
+    float inv_cell;
+    int   dim[3];
+    float centroid[3];
+    uint32_t n_finite;
+};
+
+struct ismhip_cloud {
+    int n_obj = 0;
+    uint32_t n_pts = 0;
+    uint32_t max_pts = 0;                 // largest object
+    std::vector<uint32_t> pt_off_h;
+    uint32_t* pt_off = nullptr;           // [n_obj+1]
+    // caller's arrays (borrowed, original order)
+    const float *x = nullptr, *y = nullptr, *z = nullptr, *nx = nullptr, *ny = nullptr, *nz = nullptr;
+    const uint32_t* rgba = nullptr;
+    // cell-sorted SoA copies (owned)
+    float *sx = nullptr, *sy = nullptr, *sz = nullptr, *snx = nullptr, *sny = nullptr, *snz = nullptr;
+    float *sL = nullptr, *sa = nullptr, *sb = nullptr;   // normalised CIELab (only with rgba)
+    uint32_t* sorig = nullptr;            // object-local original index of every sorted point
+    uint32_t* cell_of_pt = nullptr;       // scratch: cell id per original point
+    uint32_t* rank_of_pt = nullptr;       // scratch: arrival rank inside the cell
+    GridMeta* meta = nullptr;             // [n_obj]
+    uint32_t* cell_start = nullptr;       // [n_obj * ISM_GRID_STRIDE]
+    float requested_cell = 0.f;
+};
+
+struct ismhip_codebook {
+    int n_words = 0, dim = 0, dim_pad = 0, n_votes = 0, max_votes = 0, n_classes = 0;
+    float* words = nullptr;          // [n_words_pad * dim_pad] row-major, zero padded (MFMA tile friendly)
+    int n_words_pad = 0;
+    float* word_norm = nullptr;      // [n_words_pad] squared L2 norm (+inf for padding rows)
+    float* word_weight = nullptr;    // [n_words]
+    uint32_t* vote_off = nullptr;    // [n_words+1]
+    float* vote_xyz = nullptr;       // [n_votes*3]
+    float* vote_weight = nullptr;    // [n_votes]
+    float* vote_class_weight = nullptr;
+    uint32_t* vote_class = nullptr;
+    uint32_t* vote_instance = nullptr;
+    float* vote_bbox_quat = nullptr; // [n_votes*4]
+    float* vote_bbox_size = nullptr; // [n_votes*3]
+    float* class_sigma = nullptr;    // [n_classes]
+};
+
+struct TimerAcc {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct ismhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    bool timers_on = false;
+    std::map<std::string, TimerAcc> timers;
+    std::vector<hipEvent_t> event_pool;
+    // grow-only scratch slots
+    struct Slot { void* p = nullptr; size_t bytes = 0; };
+    std::map<int, Slot> scratch;
+    // LUTs for RGB->Lab (device)
+    float* lut_srgb = nullptr;   // [256]
+    float* lut_sxyz = nullptr;   // [4000]
+};
+
+enum ScratchSlot {
+    SCR_KP_OFF = 1, SCR_TIE_LIST, SCR_TIE_REC, SCR_TIE_KEYS, SCR_COUNTERS, SCR_KNN_CAND_IDX, SCR_KNN_CAND_VAL,
+    SCR_QNORM, SCR_FPFH_FLAG, SCR_FPFH_LIST, SCR_FPFH_SPFH, SCR_FPFH_LOOKUP, SCR_SLOT_OFF, SCR_CLASS_BW,
+    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD
+};
+
+int  ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg);
+void* ism_scratch(ismhip_ctx* ctx, int slot, size_t bytes);   // nullptr on failure (error recorded)
+
+#define ISM_HIP(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e__ = (call);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return ism_set_err((ctx), ISMHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+#define ISM_CHECK_LAUNCH(ctx, name)                                                                 \
+    do {                                                                                            \
+        hipError_t e__ = hipGetLastError();                                                         \
+        if (e__ != hipSuccess)                                                                      \
+            return ism_set_err((ctx), ISMHIP_ERR_HIP, std::string("launch ") + name + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// RAII-ish timer scope: records events around a group of launches on the ctx stream
+struct TimerScope {
+    ismhip_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    TimerScope(ismhip_ctx* c, const char* n);
+    ~TimerScope();
+};
+
+// ---- device helpers ---------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// squared distance exactly as FLANN L2_Simple<float> / the oracle: sequential float accumulate.
+// The library is compiled with -ffp-contract=off, so no FMA is formed here.
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    float r = 0.f, d;
+    d = ax - bx; r += d * d;
+    d = ay - by; r += d * d;
+    d = az - bz; r += d * d;
+    return r;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// cell coordinate of a value along one axis, clamped (monotone in v)
+__device__ __forceinline__ int cell_coord(float v, float minv, float inv_cell, int dim) {
+    int c = (int)floorf((v - minv) * inv_cell);
+    return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+}
+
+// Conservative cell range of the ball (q, r) along every axis. Returns false when the ball misses the grid.
+struct CellRange { int lo[3], hi[3]; };
+__device__ __forceinline__ bool ball_cells(const GridMeta& m, float qx, float qy, float qz, float r, CellRange& cr) {
+    const float q[3] = {qx, qy, qz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float pad = r * 1e-5f + fabsf(q[a]) * 4e-7f + 1e-30f;   // absorbs the rounding of q±r and of the binning
+        const float lo = (q[a] - r - pad - m.minv[a]) * m.inv_cell;
+        const float hi = (q[a] + r + pad - m.minv[a]) * m.inv_cell;
+        int l = (int)floorf(lo), h = (int)floorf(hi);
+        if (h < 0 || l > m.dim[a] - 1) return false;
+        cr.lo[a] = l < 0 ? 0 : l;
+        cr.hi[a] = h > m.dim[a] - 1 ? m.dim[a] - 1 : h;
+    }
+    return true;
+}
+#endif

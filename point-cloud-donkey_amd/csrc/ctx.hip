@@ -1,0 +1,136 @@
+// ctx.hip — context, scratch arena, device timers of libismhip.so
+#include "common.h"
+#include <cmath>
+#include <cstring>
+
+int ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+void* ism_scratch(ismhip_ctx* ctx, int slot, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    auto& s = ctx->scratch[slot];
+    if (s.bytes >= bytes) return s.p;
+    if (s.p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(s.p); s.p = nullptr; s.bytes = 0; }
+    size_t want = bytes + bytes / 4;   // grow-only with headroom so steady state never reallocates
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) { ism_set_err(ctx, ISMHIP_ERR_NOMEM, "scratch hipMalloc failed"); return nullptr; }
+    s.p = p; s.bytes = want;
+    return p;
+}
+
+TimerScope::TimerScope(ismhip_ctx* c, const char* n) : ctx(c), name(n) {
+    if (!ctx->timers_on) return;
+    auto get = [&]() {
+        hipEvent_t e = nullptr;
+        if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    a = get(); b = get();
+    (void)hipEventRecord(a, ctx->stream);
+}
+TimerScope::~TimerScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->timers[name].pending.emplace_back(a, b);
+}
+
+extern "C" {
+
+int ismhip_abi_version(void) { return ISMHIP_ABI_VERSION; }
+
+int ismhip_ctx_create(int device, void* stream, ismhip_ctx** out) {
+    if (!out) return ISMHIP_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ISMHIP_ERR_NODEVICE;
+    if (device < 0 || device >= n) return ISMHIP_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return ISMHIP_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ISMHIP_ERR_HIP;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ISMHIP_ERR_NODEVICE;   // code objects are gfx950 only
+    ismhip_ctx* ctx = new ismhip_ctx();
+    ctx->device = device;
+    if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ISMHIP_ERR_HIP; }
+        ctx->own_stream = true;
+    }
+    // RGB->CIELab look-up tables, reference: features/features_cshot.cpp:52-70
+    std::vector<float> srgb(256), sxyz(4000);
+    for (int i = 0; i < 256; i++) {
+        float f = static_cast<float>(i) / 255.0f;
+        srgb[i] = (f > 0.04045) ? powf((f + 0.055f) / 1.055f, 2.4f) : f / 12.92f;
+    }
+    for (int i = 0; i < 4000; i++) {
+        float f = static_cast<float>(i) / 4000.0f;
+        sxyz[i] = (f > 0.008856) ? static_cast<float>(powf(f, 0.3333f)) : static_cast<float>((7.787 * f) + (16.0 / 116.0));
+    }
+    if (hipMalloc((void**)&ctx->lut_srgb, 256 * 4) != hipSuccess || hipMalloc((void**)&ctx->lut_sxyz, 4000 * 4) != hipSuccess) {
+        delete ctx; return ISMHIP_ERR_NOMEM;
+    }
+    (void)hipMemcpy(ctx->lut_srgb, srgb.data(), 256 * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(ctx->lut_sxyz, sxyz.data(), 4000 * 4, hipMemcpyHostToDevice);
+    *out = ctx;
+    return ISMHIP_OK;
+}
+
+int ismhip_ctx_destroy(ismhip_ctx* ctx) {
+    if (!ctx) return ISMHIP_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->scratch) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : ctx->timers) for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->lut_srgb) (void)hipFree(ctx->lut_srgb);
+    if (ctx->lut_sxyz) (void)hipFree(ctx->lut_sxyz);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return ISMHIP_OK;
+}
+
+int ismhip_sync(ismhip_ctx* ctx) {
+    if (!ctx) return ISMHIP_ERR_INVALID;
+    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ISMHIP_OK;
+}
+
+const char* ismhip_last_error(const ismhip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int ismhip_timers_enable(ismhip_ctx* ctx, int on) {
+    if (!ctx) return ISMHIP_ERR_INVALID;
+    ctx->timers_on = on != 0;
+    return ISMHIP_OK;
+}
+
+static void resolve_timers(ismhip_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->timers) {
+        for (auto& pr : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { kv.second.ms += ms; kv.second.launches++; }
+            ctx->event_pool.push_back(pr.first); ctx->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+int ismhip_timers_reset(ismhip_ctx* ctx) {
+    if (!ctx) return ISMHIP_ERR_INVALID;
+    resolve_timers(ctx);
+    for (auto& kv : ctx->timers) { kv.second.ms = 0; kv.second.launches = 0; }
+    return ISMHIP_OK;
+}
+
+int ismhip_timer_get(ismhip_ctx* ctx, const char* name, double* ms_out, int64_t* launches_out) {
+    if (!ctx || !name) return ISMHIP_ERR_INVALID;
+    resolve_timers(ctx);
+    auto it = ctx->timers.find(name);
+    if (ms_out) *ms_out = it == ctx->timers.end() ? 0.0 : it->second.ms;
+    if (launches_out) *launches_out = it == ctx->timers.end() ? 0 : it->second.launches;
+    return ISMHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// fpfh.hip — FPFH-33 descriptors. Reference seam: FeaturesFPFH::iComputeDescriptors
+// (features/features_fpfh.cpp:27-72) -> pcl::FPFHEstimationOMP<..., FPFHSignature33>; arithmetic restated from
+// PCL 1.10 computePairFeatures / computePointSPFHSignature / weightPointSPFHSignature.
+//
+// Three launches, one wavefront per unit of work:
+//   k_fpfh_mark : per keypoint, flag every surface point inside its ball (the union U of A.4) and count M_k
+//   k_spfh      : per flagged surface point p, SPFH(p) = 3x11 histogram of Darboux angles to its neighbours
+//   k_fpfh_sum  : per keypoint, FPFH = sum_nb SPFH(nb)/d^2, every 11-bin block rescaled to 100
+// Roofline (HBM gather model): sum_{p in U} M_p*24 + |U|*132 + sum_k M_k*136 + K*132 bytes.
+#include "common.h"
+
+uint32_t* ism_upload_offsets(ismhip_ctx* ctx, int slot, const uint32_t* off_h, int n);
+
+namespace {
+
+struct FpfhArgs {
+    const uint32_t* pt_off; const GridMeta* meta; const uint32_t* cell_start;
+    const float *sx, *sy, *sz, *snx, *sny, *snz;
+    const uint32_t* kp_off; const float *kx, *ky, *kz;
+    float radius, r2;
+    uint8_t* flag;      // [n_pts] sorted index space
+    float* spfh;        // [n_pts*33]
+    float* desc; uint32_t* count;
+    uint32_t max_pts;
+};
+
+__global__ __launch_bounds__(256) void k_fpfh_mark(FpfhArgs a) {
+    const int o = blockIdx.y;
+    const uint32_t k = a.kp_off[o] + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= a.kp_off[o + 1]) return;
+    const int lane = lane_id();
+    const float cx = a.kx[k], cy = a.ky[k], cz = a.kz[k];
+    const GridMeta m = a.meta[o];
+    CellRange cr;
+    uint32_t total = 0;
+    if (isfinite(cx) && isfinite(cy) && isfinite(cz) && ball_cells(m, cx, cy, cz, a.radius, cr)) {
+        const uint32_t* cs = a.cell_start + (size_t)o * ISM_GRID_STRIDE;
+        const uint32_t base = a.pt_off[o];
+        for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
+            for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+                const int rb = (gz * m.dim[1] + gy) * m.dim[0];
+                const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+                for (uint32_t t = s + lane; t < e; t += 64) {
+                    const float d2 = sqdist3(a.sx[base + t], a.sy[base + t], a.sz[base + t], cx, cy, cz);
+                    if (d2 < a.r2) { a.flag[base + t] = 1; total++; }
+                }
+            }
+    }
+    total = (uint32_t)wave_sum_i((int)total);
+    if (a.count && lane == 0) a.count[k] = total;
+}
+
+// pcl::computePairFeatures in float; returns false when the pair is skipped
+__device__ __forceinline__ bool pair_features(float px, float py, float pz, float pnx, float pny, float pnz,
+                                              float qx, float qy, float qz, float qnx, float qny, float qnz,
+                                              float& f1, float& f2, float& f3) {
+    float dx = qx - px, dy = qy - py, dz = qz - pz;
+    const float f4 = sqrtf((dx * dx + dy * dy) + dz * dz);
+    if (f4 == 0.0f) return false;
+    float ax = pnx, ay = pny, az = pnz, bx = qnx, by = qny, bz = qnz;
+    const float angle1 = ((ax * dx + ay * dy) + az * dz) / f4;
+    const float angle2 = ((bx * dx + by * dy) + bz * dz) / f4;
+    if (acosf(fabsf(angle1)) > acosf(fabsf(angle2))) {
+        float t;
+        t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; t = az; az = bz; bz = t;
+        dx = -dx; dy = -dy; dz = -dz;
+        f3 = -angle2;
+    } else f3 = angle1;
+    float vx = dy * az - dz * ay, vy = dz * ax - dx * az, vz = dx * ay - dy * ax;
+    const float vn = sqrtf((vx * vx + vy * vy) + vz * vz);
+    if (vn == 0.0f) return false;
+    vx /= vn; vy /= vn; vz /= vn;
+    const float wx = ay * vz - az * vy, wy = az * vx - ax * vz, wz = ax * vy - ay * vx;
+    f2 = (vx * bx + vy * by) + vz * bz;
+    f1 = atan2f((wx * bx + wy * by) + wz * bz, (ax * bx + ay * by) + az * bz);
+    return true;
+}
+
+__device__ __forceinline__ int clamp_bin(int h) { return h < 0 ? 0 : (h > 10 ? 10 : h); }
+
+__global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
+    __shared__ unsigned int s_hist[4][36];
+    const int o = blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t base = a.pt_off[o];
+    const uint32_t n = a.pt_off[o + 1] - base;
+    const uint32_t p = blockIdx.x * 4 + wv;
+    if (p >= n || !a.flag[base + p]) return;
+    unsigned int* hist = s_hist[wv];
+    if (lane < 36) hist[lane] = 0u;
+    const float px = a.sx[base + p], py = a.sy[base + p], pz = a.sz[base + p];
+    const float pnx = a.snx[base + p], pny = a.sny[base + p], pnz = a.snz[base + p];
+    const GridMeta m = a.meta[o];
+    CellRange cr;
+    ball_cells(m, px, py, pz, a.radius, cr);
+    const uint32_t* cs = a.cell_start + (size_t)o * ISM_GRID_STRIDE;
+    const float d_pi = 1.0f / (2.0f * 3.14159265358979323846f);
+    uint32_t total = 0;
+    for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
+        for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+            const int rb = (gz * m.dim[1] + gy) * m.dim[0];
+            const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+            for (uint32_t t = s + lane; t < e; t += 64) {
+                const float qx = a.sx[base + t], qy = a.sy[base + t], qz = a.sz[base + t];
+                const float d2 = sqdist3(qx, qy, qz, px, py, pz);
+                if (!(d2 < a.r2)) continue;
+                total++;
+                if (t == p) continue;
+                float f1, f2, f3;
+                if (!pair_features(px, py, pz, pnx, pny, pnz, qx, qy, qz, a.snx[base + t], a.sny[base + t], a.snz[base + t], f1, f2, f3)) continue;
+                // the three bin formulas are evaluated in double as in PCL (float operands, double constants)
+                const int h1 = clamp_bin((int)floor(11 * (((double)f1 + 3.14159265358979323846) * (double)d_pi)));
+                const int h2 = clamp_bin((int)floor(11 * (((double)f2 + 1.0) * 0.5)));
+                const int h3 = clamp_bin((int)floor(11 * (((double)f3 + 1.0) * 0.5)));
+                atomicAdd(&hist[h1], 1u); atomicAdd(&hist[11 + h2], 1u); atomicAdd(&hist[22 + h3], 1u);
+            }
+        }
+    total = (uint32_t)wave_sum_i((int)total);
+    const float hist_incr = 100.0f / (float)(total - 1u);
+    if (lane < 33) a.spfh[(size_t)(base + p) * 33 + lane] = (float)hist[lane] * hist_incr;
+}
+
+__global__ __launch_bounds__(256) void k_fpfh_sum(FpfhArgs a) {
+    __shared__ uint32_t s_qi[4][64];
+    __shared__ float s_qw[4][64];
+    const int o = blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t k = a.kp_off[o] + blockIdx.x * 4 + wv;
+    if (k >= a.kp_off[o + 1]) return;
+    float* out = a.desc + (size_t)k * 33;
+    const float cx = a.kx[k], cy = a.ky[k], cz = a.kz[k];
+    const GridMeta m = a.meta[o];
+    CellRange cr;
+    if (!(isfinite(cx) && isfinite(cy) && isfinite(cz)) || !ball_cells(m, cx, cy, cz, a.radius, cr)) {
+        if (lane < 33) out[lane] = __builtin_nanf("");
+        return;
+    }
+    const uint32_t* cs = a.cell_start + (size_t)o * ISM_GRID_STRIDE;
+    const uint32_t base = a.pt_off[o];
+    float acc = 0.f;          // lane b < 33 owns bin b
+    uint32_t total = 0;
+    for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
+        for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+            const int rb = (gz * m.dim[1] + gy) * m.dim[0];
+            const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+            for (uint32_t t0 = s; t0 < e; t0 += 64) {
+                const uint32_t i = t0 + lane;
+                bool pass = false; float d2 = 0.f;
+                if (i < e) { d2 = sqdist3(a.sx[base + i], a.sy[base + i], a.sz[base + i], cx, cy, cz); pass = d2 < a.r2; }
+                const unsigned long long mask = __ballot(pass);
+                total += __popcll(mask);
+                const bool use = pass && d2 != 0.f;                      // "minus the query point itself"
+                const unsigned long long umask = __ballot(use);
+                if (use) {
+                    const uint32_t pos = __popcll(umask & ((1ull << lane) - 1ull));
+                    s_qi[wv][pos] = base + i; s_qw[wv][pos] = 1.0f / d2;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int cnt = __popcll(umask);
+                if (lane < 33)
+                    for (int j = 0; j < cnt; ++j) acc += a.spfh[(size_t)s_qi[wv][j] * 33 + lane] * s_qw[wv][j];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    if (total == 0) {                 // searchForNeighbors == 0 -> NaN histogram
+        if (lane < 33) out[lane] = __builtin_nanf("");
+        return;
+    }
+    // per 11-bin block: scale to sum 100 (sum over the block's lanes)
+    float sum = 0.f;
+    const int blk = lane / 11;
+    for (int j = 0; j < 11; ++j) {
+        const float v = __shfl(acc, blk * 11 + j, 64);
+        sum += v;
+    }
+    if (sum != 0.f) sum = 100.0f / sum;
+    if (lane < 33) out[lane] = acc * sum;
+}
+
+}  // namespace
+
+extern "C" int ismhip_fpfh33(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
+                             const float* kpx, const float* kpy, const float* kpz,
+                             float radius, float* desc_out, uint32_t* neighbour_count_out) {
+    if (!ctx || !cloud || !kp_offsets_h || !kpx || !kpy || !kpz || !desc_out || !(radius > 0.f))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "fpfh33: bad argument");
+    const int n_obj = cloud->n_obj;
+    uint32_t maxk = 0;
+    for (int o = 0; o < n_obj; ++o) {
+        if (kp_offsets_h[o + 1] < kp_offsets_h[o]) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "fpfh33: offsets not monotone");
+        maxk = std::max(maxk, kp_offsets_h[o + 1] - kp_offsets_h[o]);
+    }
+    if (maxk == 0) return ISMHIP_OK;
+    uint32_t* ko = ism_upload_offsets(ctx, SCR_KP_OFF, kp_offsets_h, n_obj + 1);
+    if (!ko) return ISMHIP_ERR_HIP;
+    const size_t np = cloud->n_pts ? cloud->n_pts : 1;
+    uint8_t* flag = (uint8_t*)ism_scratch(ctx, SCR_FPFH_FLAG, np);
+    float* spfh = (float*)ism_scratch(ctx, SCR_FPFH_SPFH, np * 33 * sizeof(float));
+    if (!flag || !spfh) return ISMHIP_ERR_NOMEM;
+    FpfhArgs a;
+    a.pt_off = cloud->pt_off; a.meta = cloud->meta; a.cell_start = cloud->cell_start;
+    a.sx = cloud->sx; a.sy = cloud->sy; a.sz = cloud->sz; a.snx = cloud->snx; a.sny = cloud->sny; a.snz = cloud->snz;
+    a.kp_off = ko; a.kx = kpx; a.ky = kpy; a.kz = kpz;
+    a.radius = radius; a.r2 = (float)((double)radius * (double)radius);
+    a.flag = flag; a.spfh = spfh; a.desc = desc_out; a.count = neighbour_count_out; a.max_pts = cloud->max_pts;
+    TimerScope ts(ctx, "fpfh33");
+    ISM_HIP(ctx, hipMemsetAsync(flag, 0, np, ctx->stream));
+    hipLaunchKernelGGL(k_fpfh_mark, dim3((maxk + 3) / 4, n_obj), dim3(256), 0, ctx->stream, a);
+    ISM_CHECK_LAUNCH(ctx, "k_fpfh_mark");
+    hipLaunchKernelGGL(k_spfh, dim3((cloud->max_pts + 3) / 4, n_obj), dim3(256), 0, ctx->stream, a);
+    ISM_CHECK_LAUNCH(ctx, "k_spfh");
+    hipLaunchKernelGGL(k_fpfh_sum, dim3((maxk + 3) / 4, n_obj), dim3(256), 0, ctx->stream, a);
+    ISM_CHECK_LAUNCH(ctx, "k_fpfh_sum");
+    return ISMHIP_OK;
+}

@@ -1,0 +1,293 @@
+// grid.hip — search surface: per-object uniform grid + cell-sorted SoA copy of the cloud.
+// Replaces the pcl::search::KdTree the reference builds per object (implicit_shape_model.cpp:823-831):
+// an exact fixed-radius search over a grid is equivalent up to neighbour order.
+//
+// HBM layout: points of all objects are concatenated SoA (x|y|z|nx|ny|nz, 4-byte floats). The sorted copy
+// orders every object's points by cell id (x fastest), so the 2r-wide x-run of cells a query ball touches
+// in one (y,z) row is ONE contiguous, coalesced span of each array.
+#include "common.h"
+#include <cfloat>
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_bbox_meta(const uint32_t* __restrict__ pt_off,
+                                                   const float* __restrict__ x, const float* __restrict__ y,
+                                                   const float* __restrict__ z, float req_cell,
+                                                   GridMeta* __restrict__ meta, uint32_t* __restrict__ cell_start) {
+    const int o = blockIdx.x;
+    const uint32_t b = pt_off[o], e = pt_off[o + 1];
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    double s[3] = {0, 0, 0};
+    uint32_t cnt = 0;
+    for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+        const float px = x[i], py = y[i], pz = z[i];
+        if (!(isfinite(px) && isfinite(py) && isfinite(pz))) continue;
+        mn[0] = fminf(mn[0], px); mx[0] = fmaxf(mx[0], px);
+        mn[1] = fminf(mn[1], py); mx[1] = fmaxf(mx[1], py);
+        mn[2] = fminf(mn[2], pz); mx[2] = fmaxf(mx[2], pz);
+        s[0] += px; s[1] += py; s[2] += pz; cnt++;
+    }
+    __shared__ float s_mn[4][3], s_mx[4][3];
+    __shared__ double s_s[4][3];
+    __shared__ uint32_t s_c[4];
+    __shared__ int s_ncell;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+        }
+        s[a] = wave_sum_d(s[a]);
+    }
+    cnt = (uint32_t)wave_sum_i((int)cnt);
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+        for (int a = 0; a < 3; ++a) { s_mn[w][a] = mn[a]; s_mx[w][a] = mx[a]; s_s[w][a] = s[a]; }
+        s_c[w] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        GridMeta m;
+        uint32_t c = 0; double ss[3] = {0, 0, 0};
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int k = 0; k < 4; ++k) {
+            c += s_c[k];
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], s_mn[k][a]); hi[a] = fmaxf(hi[a], s_mx[k][a]); ss[a] += s_s[k][a]; }
+        }
+        if (c == 0) { for (int a = 0; a < 3; ++a) { lo[a] = 0.f; hi[a] = 0.f; } }
+        float cell = req_cell > 0.f ? req_cell : 1.f;
+        for (int it = 0; it < 64; ++it) {
+            bool ok = true;
+            for (int a = 0; a < 3; ++a) if ((hi[a] - lo[a]) / cell >= (float)(ISM_GRID_MAXDIM - 1)) ok = false;
+            if (ok) break;
+            cell *= 2.f;
+        }
+        m.cell = cell; m.inv_cell = 1.0f / cell;
+        int ncell = 1;
+        for (int a = 0; a < 3; ++a) {
+            m.minv[a] = lo[a];
+            int d = (int)floorf((hi[a] - lo[a]) * m.inv_cell) + 1;
+            d = d < 1 ? 1 : (d > ISM_GRID_MAXDIM ? ISM_GRID_MAXDIM : d);
+            m.dim[a] = d; ncell *= d;
+            m.centroid[a] = c ? (float)(ss[a] / (double)c) : 0.f;   // pcl::compute3DCentroid (double accumulate)
+        }
+        m.n_finite = c;
+        meta[o] = m;
+        s_ncell = ncell;
+    }
+    __syncthreads();
+    uint32_t* cs = cell_start + (size_t)o * ISM_GRID_STRIDE;
+    for (int i = threadIdx.x; i <= s_ncell; i += blockDim.x) cs[i] = 0u;
+}
+
+// counts points per cell; remembers each point's cell and its arrival rank inside the cell
+__global__ __launch_bounds__(256) void k_count(const uint32_t* __restrict__ pt_off, const float* __restrict__ x,
+                                               const float* __restrict__ y, const float* __restrict__ z,
+                                               const GridMeta* __restrict__ meta, uint32_t* __restrict__ cell_start,
+                                               uint32_t* __restrict__ cell_of_pt, uint32_t* __restrict__ rank_of_pt) {
+    const int o = blockIdx.y;
+    const uint32_t b = pt_off[o], e = pt_off[o + 1];
+    const uint32_t i = b + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e) return;
+    const GridMeta m = meta[o];
+    const float px = x[i], py = y[i], pz = z[i];
+    if (!(isfinite(px) && isfinite(py) && isfinite(pz))) { cell_of_pt[i] = 0xffffffffu; return; }
+    const int cx = cell_coord(px, m.minv[0], m.inv_cell, m.dim[0]);
+    const int cy = cell_coord(py, m.minv[1], m.inv_cell, m.dim[1]);
+    const int cz = cell_coord(pz, m.minv[2], m.inv_cell, m.dim[2]);
+    const uint32_t c = (uint32_t)((cz * m.dim[1] + cy) * m.dim[0] + cx);
+    cell_of_pt[i] = c;
+    rank_of_pt[i] = atomicAdd(&cell_start[(size_t)o * ISM_GRID_STRIDE + c], 1u);
+}
+
+// exclusive scan of the per-cell counts of one object (<= 32768 cells), in place; entry [ncell] = total
+__global__ __launch_bounds__(1024) void k_scan(const GridMeta* __restrict__ meta, uint32_t* __restrict__ cell_start) {
+    const int o = blockIdx.x;
+    const GridMeta m = meta[o];
+    const int ncell = m.dim[0] * m.dim[1] * m.dim[2];
+    uint32_t* cs = cell_start + (size_t)o * ISM_GRID_STRIDE;
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ncell; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < ncell ? cs[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(incl, off, 64);
+            if (lane_id() >= off) incl += t;
+        }
+        const int w = threadIdx.x >> 6;
+        if (lane_id() == 63) s_wave[w] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int k = 0; k < w; ++k) wave_off += s_wave[k];
+        const uint32_t carry = s_carry;
+        if (i < ncell) cs[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cs[ncell] = s_carry;
+}
+
+template <bool COLOR>
+__global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ pt_off,
+                                                 const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                 const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz,
+                                                 const uint32_t* __restrict__ rgba,
+                                                 const float* __restrict__ lut_srgb, const float* __restrict__ lut_sxyz,
+                                                 const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ cell_of_pt,
+                                                 const uint32_t* __restrict__ rank_of_pt,
+                                                 float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz,
+                                                 float* __restrict__ snx, float* __restrict__ sny, float* __restrict__ snz,
+                                                 float* __restrict__ sL, float* __restrict__ sa, float* __restrict__ sb,
+                                                 uint32_t* __restrict__ sorig) {
+    const int o = blockIdx.y;
+    const uint32_t b = pt_off[o], e = pt_off[o + 1];
+    const uint32_t i = b + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e) return;
+    const uint32_t c = cell_of_pt[i];
+    if (c == 0xffffffffu) return;
+    const uint32_t d = b + cell_start[(size_t)o * ISM_GRID_STRIDE + c] + rank_of_pt[i];
+    sx[d] = x[i]; sy[d] = y[i]; sz[d] = z[i];
+    snx[d] = nx[i]; sny[d] = ny[i]; snz[d] = nz[i];
+    sorig[d] = i - b;
+    if (COLOR) {
+        // RGB2CIELAB, reference: features/features_short_cshot.cpp:651-687 (PCL cshot.hpp); normalised L/100, a/120, b/120
+        const uint32_t c4 = rgba[i];
+        const float fr = lut_srgb[(c4 >> 16) & 0xff], fg = lut_srgb[(c4 >> 8) & 0xff], fb = lut_srgb[c4 & 0xff];
+        const float X = fr * 0.412453f + fg * 0.357580f + fb * 0.180423f;
+        const float Y = fr * 0.212671f + fg * 0.715160f + fb * 0.072169f;
+        const float Z = fr * 0.019334f + fg * 0.119193f + fb * 0.950227f;
+        float vx = X / 0.95047f, vy = Y, vz = Z / 1.08883f;
+        int ix = (int)(vx * 4000), iy = (int)(vy * 4000), iz = (int)(vz * 4000);
+        ix = ix < 0 ? 0 : (ix > 3999 ? 3999 : ix); iy = iy < 0 ? 0 : (iy > 3999 ? 3999 : iy); iz = iz < 0 ? 0 : (iz > 3999 ? 3999 : iz);
+        vx = lut_sxyz[ix]; vy = lut_sxyz[iy]; vz = lut_sxyz[iz];
+        float L = 116.0f * vy - 16.0f; if (L > 100) L = 100.0f;
+        float A = 500.0f * (vx - vy); if (A > 120) A = 120.0f; else if (A < -120) A = -120.0f;
+        float B = 200.0f * (vy - vz); if (B > 120) B = 120.0f; else if (B < -120) B = -120.0f;
+        sL[d] = L / 100.0f; sa[d] = A / 120.0f; sb[d] = B / 120.0f;
+    }
+}
+
+__global__ void k_centroids(const GridMeta* __restrict__ meta, int n_obj, float* __restrict__ out) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_obj) return;
+    out[o * 3 + 0] = meta[o].centroid[0]; out[o * 3 + 1] = meta[o].centroid[1]; out[o * 3 + 2] = meta[o].centroid[2];
+}
+
+__global__ __launch_bounds__(256) void k_center_dist(const GridMeta* __restrict__ meta, const uint32_t* __restrict__ kp_off,
+                                                     const float* __restrict__ kx, const float* __restrict__ ky,
+                                                     const float* __restrict__ kz, float* __restrict__ out) {
+    const int o = blockIdx.y;
+    const uint32_t k = kp_off[o] + blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= kp_off[o + 1]) return;
+    const float dx = kx[k] - meta[o].centroid[0], dy = ky[k] - meta[o].centroid[1], dz = kz[k] - meta[o].centroid[2];
+    out[k] = sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+}  // namespace
+
+// uploads a small host offsets array into a scratch slot; returns device pointer (nullptr on failure)
+uint32_t* ism_upload_offsets(ismhip_ctx* ctx, int slot, const uint32_t* off_h, int n) {
+    uint32_t* d = (uint32_t*)ism_scratch(ctx, slot, (size_t)n * sizeof(uint32_t));
+    if (!d) return nullptr;
+    if (hipMemcpyAsync(d, off_h, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        ism_set_err(ctx, ISMHIP_ERR_HIP, "offset upload failed");
+        return nullptr;
+    }
+    return d;
+}
+
+extern "C" {
+
+int ismhip_cloud_create(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_h,
+                        const float* x, const float* y, const float* z,
+                        const float* nx, const float* ny, const float* nz,
+                        const uint32_t* rgba, float cell_size, ismhip_cloud** out) {
+    if (!ctx || !out || n_obj <= 0 || !pt_offsets_h || !x || !y || !z || !nx || !ny || !nz || !(cell_size > 0.f))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "cloud_create: bad argument");
+    *out = nullptr;
+    for (int o = 0; o < n_obj; ++o)
+        if (pt_offsets_h[o + 1] < pt_offsets_h[o]) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "cloud_create: offsets not monotone");
+    if (pt_offsets_h[0] != 0) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "cloud_create: offsets must start at 0");
+    ISM_HIP(ctx, hipSetDevice(ctx->device));
+    ismhip_cloud* c = new ismhip_cloud();
+    c->n_obj = n_obj;
+    c->pt_off_h.assign(pt_offsets_h, pt_offsets_h + n_obj + 1);
+    c->n_pts = pt_offsets_h[n_obj];
+    for (int o = 0; o < n_obj; ++o) c->max_pts = std::max(c->max_pts, pt_offsets_h[o + 1] - pt_offsets_h[o]);
+    c->x = x; c->y = y; c->z = z; c->nx = nx; c->ny = ny; c->nz = nz; c->rgba = rgba;
+    c->requested_cell = cell_size;
+    const size_t np = c->n_pts ? c->n_pts : 1;
+    const int n_arr = rgba ? 9 : 6;
+    float* block = nullptr;
+    auto fail = [&](int code, const char* msg) { ismhip_cloud_destroy(ctx, c); return ism_set_err(ctx, code, msg); };
+    if (hipMalloc((void**)&block, np * sizeof(float) * n_arr) != hipSuccess) return fail(ISMHIP_ERR_NOMEM, "cloud_create: hipMalloc sorted arrays");
+    c->sx = block; c->sy = block + np; c->sz = block + 2 * np; c->snx = block + 3 * np; c->sny = block + 4 * np; c->snz = block + 5 * np;
+    if (rgba) { c->sL = block + 6 * np; c->sa = block + 7 * np; c->sb = block + 8 * np; }
+    if (hipMalloc((void**)&c->sorig, np * 4) != hipSuccess || hipMalloc((void**)&c->cell_of_pt, np * 4) != hipSuccess ||
+        hipMalloc((void**)&c->rank_of_pt, np * 4) != hipSuccess || hipMalloc((void**)&c->pt_off, (size_t)(n_obj + 1) * 4) != hipSuccess ||
+        hipMalloc((void**)&c->meta, (size_t)n_obj * sizeof(GridMeta)) != hipSuccess ||
+        hipMalloc((void**)&c->cell_start, (size_t)n_obj * ISM_GRID_STRIDE * 4) != hipSuccess)
+        return fail(ISMHIP_ERR_NOMEM, "cloud_create: hipMalloc grid");
+    if (hipMemcpyAsync(c->pt_off, c->pt_off_h.data(), (size_t)(n_obj + 1) * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(ISMHIP_ERR_HIP, "cloud_create: offsets copy");
+    {
+        TimerScope ts(ctx, "grid");
+        // non-finite points are dropped: an object's sorted span holds its n_finite points first, the tail is never read
+        hipLaunchKernelGGL(k_bbox_meta, dim3(n_obj), dim3(256), 0, ctx->stream, c->pt_off, x, y, z, cell_size, c->meta, c->cell_start);
+        const dim3 g((c->max_pts + 255) / 256 ? (c->max_pts + 255) / 256 : 1, n_obj);
+        hipLaunchKernelGGL(k_count, g, dim3(256), 0, ctx->stream, c->pt_off, x, y, z, c->meta, c->cell_start, c->cell_of_pt, c->rank_of_pt);
+        hipLaunchKernelGGL(k_scan, dim3(n_obj), dim3(1024), 0, ctx->stream, c->meta, c->cell_start);
+        if (rgba)
+            hipLaunchKernelGGL(k_scatter<true>, g, dim3(256), 0, ctx->stream, c->pt_off, x, y, z, nx, ny, nz, rgba, ctx->lut_srgb, ctx->lut_sxyz,
+                               c->cell_start, c->cell_of_pt, c->rank_of_pt, c->sx, c->sy, c->sz, c->snx, c->sny, c->snz, c->sL, c->sa, c->sb, c->sorig);
+        else
+            hipLaunchKernelGGL(k_scatter<false>, g, dim3(256), 0, ctx->stream, c->pt_off, x, y, z, nx, ny, nz, rgba, ctx->lut_srgb, ctx->lut_sxyz,
+                               c->cell_start, c->cell_of_pt, c->rank_of_pt, c->sx, c->sy, c->sz, c->snx, c->sny, c->snz, c->sL, c->sa, c->sb, c->sorig);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ISMHIP_ERR_HIP, hipGetErrorString(e));
+    *out = c;
+    return ISMHIP_OK;
+}
+
+int ismhip_cloud_destroy(ismhip_ctx* ctx, ismhip_cloud* c) {
+    if (!c) return ISMHIP_ERR_INVALID;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (c->sx) (void)hipFree(c->sx);
+    if (c->sorig) (void)hipFree(c->sorig);
+    if (c->cell_of_pt) (void)hipFree(c->cell_of_pt);
+    if (c->rank_of_pt) (void)hipFree(c->rank_of_pt);
+    if (c->pt_off) (void)hipFree(c->pt_off);
+    if (c->meta) (void)hipFree(c->meta);
+    if (c->cell_start) (void)hipFree(c->cell_start);
+    delete c;
+    return ISMHIP_OK;
+}
+
+int ismhip_cloud_centroids(ismhip_ctx* ctx, const ismhip_cloud* cloud, float* centroid_out) {
+    if (!ctx || !cloud || !centroid_out) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "cloud_centroids: bad argument");
+    hipLaunchKernelGGL(k_centroids, dim3((cloud->n_obj + 63) / 64), dim3(64), 0, ctx->stream, cloud->meta, cloud->n_obj, centroid_out);
+    ISM_CHECK_LAUNCH(ctx, "k_centroids");
+    return ISMHIP_OK;
+}
+
+int ismhip_center_dist(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
+                       const float* kpx, const float* kpy, const float* kpz, float* out) {
+    if (!ctx || !cloud || !kp_offsets_h || !kpx || !kpy || !kpz || !out) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "center_dist: bad argument");
+    uint32_t* ko = ism_upload_offsets(ctx, SCR_KP_OFF, kp_offsets_h, cloud->n_obj + 1);
+    if (!ko) return ISMHIP_ERR_HIP;
+    uint32_t maxk = 0;
+    for (int o = 0; o < cloud->n_obj; ++o) maxk = std::max(maxk, kp_offsets_h[o + 1] - kp_offsets_h[o]);
+    if (maxk == 0) return ISMHIP_OK;
+    hipLaunchKernelGGL(k_center_dist, dim3((maxk + 255) / 256, cloud->n_obj), dim3(256), 0, ctx->stream, cloud->meta, ko, kpx, kpy, kpz, out);
+    ISM_CHECK_LAUNCH(ctx, "k_center_dist");
+    return ISMHIP_OK;
+}
+
+}  // extern "C"

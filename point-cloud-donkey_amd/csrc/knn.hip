@@ -1,0 +1,432 @@
+// knn.hip — exact k-nearest-codeword search (codebook activation).
+// Reference seam: ActivationStrategyKNN::activateKNN (activation_strategy/activation_strategy_knn.h:41-126) with
+// FLANNExactMatch semantics (flann::SearchParams(-1)); distance functors utils/distance.h:45,65 (FLANN L2 = squared
+// Euclidean, ChiSquareDistance), SURVEY Appendix A.6.
+//
+// Two stages:
+//  1. candidate generation (the dominant kernel of the whole path)
+//     L2  : k_knn_l2_mfma — score(c,q) = |c|^2 - 2 c.q as a dense [codewords x queries] contraction on the FP32
+//           matrix cores (v_mfma_f32_32x32x2_f32, exact f32 fma chain). 128x128 output tile per 4-wave workgroup,
+//           each wave 64x64 = 2x2 MFMA tiles, K staged through LDS in 32-wide slices (register-prefetched, double
+//           buffered). Codewords are the MFMA ROWS and queries the COLUMNS, so that a lane holds 16 codeword scores
+//           of ONE query per accumulator tile: the running top-T per query is kept in registers with no cross-lane
+//           traffic and the Nq x Nc matrix is never materialised. Roofline: 2*Nq*Nc*D flop vs 157.3 TFLOP/s.
+//     chi2: k_knn_chi2 — not a contraction (sum (a-b)^2/(a+b)); 64x64 VALU tile, 4x4 pairs per thread, v_rcp_f32.
+//     Both keep T candidates per lane/thread with T >= k, so the true k nearest are always among the candidates.
+//  2. k_knn_rerank — one wave per query: every candidate's distance is recomputed with the FLANN functor's own
+//     summation order (bit-identical to the CPU functor) and the k smallest (distance, row) pairs are selected;
+//     ties go to the lowest row.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define KNN_BM 128       // codeword rows per tile
+#define KNN_BN 128       // queries per tile
+#define KNN_BK 32
+#define KNN_LDK 36       // padded row stride (floats) of the LDS tiles: 144 B keeps 16-B alignment, spreads banks
+
+template <int T>
+struct TopT {
+    float v[T]; int i[T];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int t = 0; t < T; ++t) { v[t] = __builtin_inff(); i[t] = -1; }
+    }
+    // insert keeping ascending order; strict < keeps the earlier (lower row) on ties
+    __device__ __forceinline__ void push(float x, int idx) {
+        if (!(x < v[T - 1])) return;
+        v[T - 1] = x; i[T - 1] = idx;
+#pragma unroll
+        for (int t = T - 1; t > 0; --t) {
+            if (v[t] < v[t - 1]) {
+                float tv = v[t]; v[t] = v[t - 1]; v[t - 1] = tv;
+                int ti = i[t]; i[t] = i[t - 1]; i[t - 1] = ti;
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// L2 candidates on the FP32 matrix cores
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict__ words, const float* __restrict__ word_norm,
+                                                        int n_tiles_m, int dim_pad,
+                                                        const float* __restrict__ q, int nq, int ldq,
+                                                        int tiles_per_split, int n_splits,
+                                                        float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride) {
+    __shared__ __attribute__((aligned(16))) float sA[2][KNN_BM * KNN_LDK];
+    __shared__ __attribute__((aligned(16))) float sB[2][KNN_BN * KNN_LDK];
+    __shared__ float sCn[KNN_BM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int qtile = blockIdx.x, split = blockIdx.y;
+    const int mt0 = split * tiles_per_split;
+    const int mt1 = min(n_tiles_m, mt0 + tiles_per_split);
+    const int nk = dim_pad / KNN_BK;
+
+    // staging map: thread -> (row = tid/8 + 32*i, float4 column = tid%8)
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const float* qbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int qr = qtile * KNN_BN + srow + 32 * i;
+        qr = qr < nq ? qr : nq - 1;                       // clamp: duplicates are never written back
+        qbase[i] = q + (size_t)qr * ldq + scol;
+    }
+
+    TopT<T> top[2];
+    top[0].init(); top[1].init();
+
+    for (int mt = mt0; mt < mt1; ++mt) {
+        const float* abase[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) abase[i] = words + (size_t)(mt * KNN_BM + srow + 32 * i) * dim_pad + scol;
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+        float4 ga[4], gb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ga[i] = *(const float4*)(abase[i]); gb[i] = *(const float4*)(qbase[i]); }
+        __syncthreads();                                   // previous tile's epilogue has finished reading sCn / LDS
+        if (tid < KNN_BM) sCn[tid] = word_norm[mt * KNN_BM + tid];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(float4*)(&sA[0][(srow + 32 * i) * KNN_LDK + scol]) = ga[i];
+            *(float4*)(&sB[0][(srow + 32 * i) * KNN_LDK + scol]) = gb[i];
+        }
+        __syncthreads();
+
+        for (int kc = 0; kc < nk; ++kc) {
+            const int cur = kc & 1;
+            if (kc + 1 < nk) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ga[i] = *(const float4*)(abase[i] + (kc + 1) * KNN_BK);
+                    gb[i] = *(const float4*)(qbase[i] + (kc + 1) * KNN_BK);
+                }
+            }
+            // operand fragments: lane half h owns k = 16h .. 16h+15 of the slice (any pairing of k is valid as long as
+            // A and B agree); step s of the 32x32x2 MFMA consumes element s of both halves.
+            float fa[2][16], fb[2][16];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const float* p = &sA[cur][(wr * 64 + mi * 32 + r) * KNN_LDK + h * 16];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float4 t4 = *(const float4*)(p + v * 4);
+                    fa[mi][v * 4 + 0] = t4.x; fa[mi][v * 4 + 1] = t4.y; fa[mi][v * 4 + 2] = t4.z; fa[mi][v * 4 + 3] = t4.w;
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const float* p = &sB[cur][(wc * 64 + ni * 32 + r) * KNN_LDK + h * 16];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float4 t4 = *(const float4*)(p + v * 4);
+                    fb[ni][v * 4 + 0] = t4.x; fb[ni][v * 4 + 1] = t4.y; fb[ni][v * 4 + 2] = t4.z; fb[ni][v * 4 + 3] = t4.w;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][s], fb[ni][s], acc[mi][ni], 0, 0, 0);
+            if (kc + 1 < nk) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    *(float4*)(&sA[cur ^ 1][(srow + 32 * i) * KNN_LDK + scol]) = ga[i];
+                    *(float4*)(&sB[cur ^ 1][(srow + 32 * i) * KNN_LDK + scol]) = gb[i];
+                }
+            }
+            __syncthreads();
+        }
+        // epilogue: C/D layout of the 32x32 tile: col = lane&31 (query), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (codeword)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row_l = wr * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float cn = sCn[row_l];
+                const int idx = mt * KNN_BM + row_l;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) top[ni].push(cn - 2.0f * acc[mi][ni][e], idx);
+            }
+    }
+    // candidates: slot = split*(4T) + (wr*2 + h)*T + t
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int qi = qtile * KNN_BN + wc * 64 + ni * 32 + r;
+        if (qi < nq) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const size_t o = (size_t)qi * cand_stride + split * (4 * T) + (wr * 2 + h) * T + t;
+                cand_val[o] = top[ni].v[t]; cand_idx[o] = top[ni].i[t];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// chi-square candidates on the vector ALUs
+// ---------------------------------------------------------------------------------------------
+#define CHI_B 64
+#define CHI_LDK 33
+template <int T>
+__global__ __launch_bounds__(256) void k_knn_chi2(const float* __restrict__ words, int n_words_pad, int dim_pad,
+                                                  const float* __restrict__ q, int nq, int ldq,
+                                                  int tiles_per_split,
+                                                  float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride) {
+    __shared__ float sC[CHI_B * CHI_LDK];
+    __shared__ float sQ[CHI_B * CHI_LDK];
+    __shared__ float sMv[CHI_B][16][T];
+    __shared__ int sMi[CHI_B][16][T];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;       // tx -> 4 query columns, ty -> 4 codeword rows
+    const int qtile = blockIdx.x, split = blockIdx.y;
+    const int n_tiles = n_words_pad / CHI_B;
+    const int mt0 = split * tiles_per_split, mt1 = min(n_tiles, mt0 + tiles_per_split);
+    const int nk = dim_pad / 32;
+    TopT<T> top[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) top[j].init();
+    // staging: 64 rows x 32 floats = 2048 floats, 8 per thread: row = tid/4, cols (tid%4)*8 .. +7
+    const int srow = tid >> 2, scol = (tid & 3) * 8;
+    int qr = qtile * CHI_B + srow; qr = qr < nq ? qr : nq - 1;
+    const float* qp = q + (size_t)qr * ldq + scol;
+    for (int mt = mt0; mt < mt1; ++mt) {
+        const float* cp = words + (size_t)(mt * CHI_B + srow) * dim_pad + scol;
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (int kc = 0; kc < nk; ++kc) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sC[srow * CHI_LDK + scol + e] = cp[kc * 32 + e];
+                sQ[srow * CHI_LDK + scol + e] = qp[kc * 32 + e];
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int kk = 0; kk < 32; ++kk) {
+                float cv[4], qv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cv[i] = sC[(ty * 4 + i) * CHI_LDK + kk];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qv[j] = sQ[(tx * 4 + j) * CHI_LDK + kk];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float s = cv[i] + qv[j], d = cv[i] - qv[j];
+                        const float t = d * d * __builtin_amdgcn_rcpf(s);
+                        acc[i][j] += s > 0.f ? t : 0.f;
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) top[j].push(acc[i][j], mt * CHI_B + ty * 4 + i);
+    }
+    // merge the 16 row-threads of every query column, keep the best T
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < T; ++t) { sMv[tx * 4 + j][ty][t] = top[j].v[t]; sMi[tx * 4 + j][ty][t] = top[j].i[t]; }
+    __syncthreads();
+    if (tid < CHI_B) {
+        const int qi = qtile * CHI_B + tid;
+        if (qi < nq) {
+            TopT<T> best; best.init();
+            for (int y = 0; y < 16; ++y)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    // order by (value, row): rows from different threads interleave, so compare rows on equal values
+                    const float v = sMv[tid][y][t]; const int id = sMi[tid][y][t];
+                    if (id < 0) continue;
+                    if (v < best.v[T - 1] || (v == best.v[T - 1] && id < best.i[T - 1])) {
+                        best.v[T - 1] = v; best.i[T - 1] = id;
+#pragma unroll
+                        for (int u = T - 1; u > 0; --u)
+                            if (best.v[u] < best.v[u - 1] || (best.v[u] == best.v[u - 1] && best.i[u] < best.i[u - 1])) {
+                                float tv = best.v[u]; best.v[u] = best.v[u - 1]; best.v[u - 1] = tv;
+                                int ti = best.i[u]; best.i[u] = best.i[u - 1]; best.i[u - 1] = ti;
+                            }
+                    }
+                }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const size_t o = (size_t)qi * cand_stride + split * T + t;
+                cand_val[o] = best.v[t]; cand_idx[o] = best.i[t];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact re-rank with the FLANN functors' summation order
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float flann_l2(const float* a, const float* b, int size) {
+    float result = 0.f;
+    int i = 0;
+    for (; i + 3 < size; i += 4) {
+        const float d0 = a[i] - b[i], d1 = a[i + 1] - b[i + 1], d2 = a[i + 2] - b[i + 2], d3 = a[i + 3] - b[i + 3];
+        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    for (; i < size; ++i) { const float d0 = a[i] - b[i]; result += d0 * d0; }
+    return result;
+}
+__device__ __forceinline__ float flann_chi2(const float* a, const float* b, int size) {
+    float result = 0.f;
+    for (int i = 0; i < size; ++i) {
+        const float sum = a[i] + b[i];
+        if (sum > 0) { const float diff = a[i] - b[i]; result += diff * diff / sum; }
+    }
+    return result;
+}
+
+__global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ words, int dim, int dim_pad, int n_words,
+                                                    const float* __restrict__ q, int nq, int ldq, int metric,
+                                                    const int* __restrict__ cand_idx, int cand_stride, int n_cand,
+                                                    int k, int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const int lane = lane_id();
+    const float* qp = q + (size_t)qi * ldq;
+    // n_cand <= 64 by construction (host): one candidate per lane
+    unsigned long long key = ~0ull;
+    if (lane < n_cand) {
+        const int id = cand_idx[(size_t)qi * cand_stride + lane];
+        if (id >= 0 && id < n_words) {
+            const float* wp = words + (size_t)id * dim_pad;
+            const float d = metric == ISMHIP_METRIC_CHI2 ? flann_chi2(qp, wp, dim) : flann_l2(qp, wp, dim);
+            // distances are >= 0 (or NaN); positive float bit patterns order like unsigned integers
+            key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;
+        }
+    }
+    for (int j = 0; j < k; ++j) {
+        unsigned long long mn = key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(mn, o, 64); mn = t < mn ? t : mn; }
+        if (lane == 0) {
+            if (mn == ~0ull) { idx_out[(size_t)qi * k + j] = -1; dist_out[(size_t)qi * k + j] = __builtin_nanf(""); }
+            else { idx_out[(size_t)qi * k + j] = (int)(mn & 0xffffffffull); dist_out[(size_t)qi * k + j] = __uint_as_float((unsigned)(mn >> 32)); }
+        }
+        if (key == mn) key = ~0ull;     // rows are unique among candidates, so exactly one lane retires
+    }
+}
+
+__global__ void k_pad_rows(const float* __restrict__ src, int n, int dim, float* __restrict__ dst, int dim_pad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * dim_pad) return;
+    const int row = (int)(i / dim_pad), col = (int)(i % dim_pad);
+    dst[i] = col < dim ? src[(size_t)row * dim + col] : 0.f;
+}
+
+__global__ void k_ratio(int nq, float thr, const int32_t* __restrict__ idx2, const float* __restrict__ d2,
+                        int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int id = idx2[i * 2]; const float a = d2[i * 2], b = d2[i * 2 + 1];
+    if (idx2[i * 2 + 1] >= 0 && a / b > thr) id = -1;        // activation_strategy_knn.h:77-84
+    idx_out[i] = id; dist_out[i] = a;
+}
+
+template <int T>
+int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q, int k,
+            int32_t* idx_out, float* dist_out) {
+    const float* qq = q; int ldq = cb->dim;
+    if (cb->dim_pad != cb->dim) {
+        float* qpad = (float*)ism_scratch(ctx, SCR_QPAD, (size_t)nq * cb->dim_pad * sizeof(float));
+        if (!qpad) return ISMHIP_ERR_NOMEM;
+        const size_t tot = (size_t)nq * cb->dim_pad;
+        hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, q, nq, cb->dim, qpad, cb->dim_pad);
+        ISM_CHECK_LAUNCH(ctx, "k_pad_rows");
+        qq = qpad; ldq = cb->dim_pad;
+    }
+    int n_splits, cand_per_split, n_cand, tiles_per_split;
+    if (metric == ISMHIP_METRIC_L2SQ) {
+        const int n_qt = (nq + KNN_BN - 1) / KNN_BN, n_mt = cb->n_words_pad / KNN_BM;
+        const int max_s = 64 / (4 * T);
+        n_splits = std::max(1, std::min(std::min(max_s, n_mt), (1024 + n_qt - 1) / n_qt));
+        tiles_per_split = (n_mt + n_splits - 1) / n_splits;
+        n_splits = (n_mt + tiles_per_split - 1) / tiles_per_split;
+        cand_per_split = 4 * T;
+    } else {
+        const int n_qt = (nq + CHI_B - 1) / CHI_B, n_mt = cb->n_words_pad / CHI_B;
+        const int max_s = 64 / T;
+        n_splits = std::max(1, std::min(std::min(max_s, n_mt), (2048 + n_qt - 1) / n_qt));
+        tiles_per_split = (n_mt + n_splits - 1) / n_splits;
+        n_splits = (n_mt + tiles_per_split - 1) / tiles_per_split;
+        cand_per_split = T;
+    }
+    n_cand = n_splits * cand_per_split;
+    float* cand_val = (float*)ism_scratch(ctx, SCR_KNN_CAND_VAL, (size_t)nq * n_cand * sizeof(float));
+    int* cand_idx = (int*)ism_scratch(ctx, SCR_KNN_CAND_IDX, (size_t)nq * n_cand * sizeof(int));
+    if (!cand_val || !cand_idx) return ISMHIP_ERR_NOMEM;
+    {
+        TimerScope ts(ctx, metric == ISMHIP_METRIC_L2SQ ? "knn_l2_mfma" : "knn_chi2");
+        if (metric == ISMHIP_METRIC_L2SQ) {
+            const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
+            hipLaunchKernelGGL(k_knn_l2_mfma<T>, dim3(n_qt, n_splits), dim3(256), 0, ctx->stream, cb->words, cb->word_norm,
+                               cb->n_words_pad / KNN_BM, cb->dim_pad, qq, nq, ldq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand);
+            ISM_CHECK_LAUNCH(ctx, "k_knn_l2_mfma");
+        } else {
+            const int n_qt = (nq + CHI_B - 1) / CHI_B;
+            hipLaunchKernelGGL(k_knn_chi2<T>, dim3(n_qt, n_splits), dim3(256), 0, ctx->stream, cb->words, cb->n_words_pad, cb->dim_pad,
+                               qq, nq, ldq, tiles_per_split, cand_val, cand_idx, n_cand);
+            ISM_CHECK_LAUNCH(ctx, "k_knn_chi2");
+        }
+    }
+    hipLaunchKernelGGL(k_knn_rerank, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
+                       qq, nq, ldq, metric, cand_idx, n_cand, n_cand, k, idx_out, dist_out);
+    ISM_CHECK_LAUNCH(ctx, "k_knn_rerank");
+    return ISMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q, int k,
+               int32_t* idx_out, float* dist_out) {
+    if (!ctx || !cb || !q || !idx_out || !dist_out || nq < 0 || k <= 0 || (metric != ISMHIP_METRIC_L2SQ && metric != ISMHIP_METRIC_CHI2))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "knn: bad argument");
+    if (k > 4) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: k > 4 not built");
+    if (nq == 0) return ISMHIP_OK;
+    TimerScope ts(ctx, "knn");
+    return k <= 2 ? run_knn<2>(ctx, cb, metric, nq, q, k, idx_out, dist_out) : run_knn<4>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
+}
+
+int ismhip_knn_ratio(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q,
+                     float ratio_threshold, int32_t* idx_out, float* dist_out) {
+    if (!ctx || !cb || !q || !idx_out || !dist_out || nq < 0) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "knn_ratio: bad argument");
+    if (nq == 0) return ISMHIP_OK;
+    int32_t* idx2 = (int32_t*)ism_scratch(ctx, SCR_QNORM, (size_t)nq * 2 * (sizeof(int32_t) + sizeof(float)));
+    if (!idx2) return ISMHIP_ERR_NOMEM;
+    float* d2 = (float*)(idx2 + (size_t)nq * 2);
+    int rc = ismhip_knn(ctx, cb, metric, nq, q, 2, idx2, d2);
+    if (rc != ISMHIP_OK) return rc;
+    hipLaunchKernelGGL(k_ratio, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, nq, ratio_threshold, idx2, d2, idx_out, dist_out);
+    ISM_CHECK_LAUNCH(ctx, "k_ratio");
+    return ISMHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+// lrf.hip — SHOT local reference frames, one 64-lane wavefront per keypoint.
+// Reference seam: Features::computeSHOTReferenceFrames (features/features.cpp:238-252) ->
+// pcl::SHOTLocalReferenceFrameEstimationOMP; arithmetic as third_party/pcl_shot_na_lrf/shot_na_lrf.hpp:48-178
+// with upstream's z-sign rule (vij . v3 >= 0), SURVEY Appendix A.1.
+//
+// Roofline: HBM-bound gather, algorithmic bytes = sum_k M'_k * 12 + K * 48.
+// Pass 1 streams the candidate x-runs of the query ball (coalesced SoA loads of the cell-sorted cloud),
+// accumulates the weighted covariance per lane in FP64 and wave-reduces it; every lane then runs the same
+// 3x3 Jacobi solve; pass 2 re-streams the runs and counts the sign votes with ballots. Keypoints whose sign
+// vote ties (needs the 5 median neighbours BY DISTANCE, shot_na_lrf.hpp:139-151) are queued for k_lrf_tie.
+#include "common.h"
+#include "eigen3.h"
+
+uint32_t* ism_upload_offsets(ismhip_ctx* ctx, int slot, const uint32_t* off_h, int n);
+
+namespace {
+
+struct TieRec {
+    double v1[3], v3[3];
+    uint32_t kp, obj;
+    int valid;
+    int tie_x, tie_z;     // 1 = undecided
+};
+
+struct CloudView {
+    const uint32_t* pt_off; const GridMeta* meta; const uint32_t* cell_start;
+    const float *sx, *sy, *sz; const uint32_t* sorig;
+    const float *x, *y, *z;   // original order (tie kernel)
+};
+
+__device__ __forceinline__ void write_lrf(float* out, const double v1[3], const double v3[3]) {
+    const float xf[3] = {(float)v1[0], (float)v1[1], (float)v1[2]};
+    const float zf[3] = {(float)v3[0], (float)v3[1], (float)v3[2]};
+    out[0] = xf[0]; out[1] = xf[1]; out[2] = xf[2];
+    out[3] = zf[1] * xf[2] - zf[2] * xf[1];     // y = z x x, in float (shot_na_lrf.hpp:170)
+    out[4] = zf[2] * xf[0] - zf[0] * xf[2];
+    out[5] = zf[0] * xf[1] - zf[1] * xf[0];
+    out[6] = zf[0]; out[7] = zf[1]; out[8] = zf[2];
+}
+
+__global__ __launch_bounds__(256) void k_lrf(CloudView cv, const uint32_t* __restrict__ kp_off,
+                                             const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ kz,
+                                             float radius, float r2, float* __restrict__ lrf_out,
+                                             uint32_t* __restrict__ tie_count, TieRec* __restrict__ tie_rec) {
+    const int o = blockIdx.y;
+    const uint32_t k = kp_off[o] + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= kp_off[o + 1]) return;
+    const int lane = lane_id();
+    float* out = lrf_out + (size_t)k * 9;
+    const float cx = kx[k], cy = ky[k], cz = kz[k];
+    const GridMeta m = cv.meta[o];
+    const uint32_t* cs = cv.cell_start + (size_t)o * ISM_GRID_STRIDE;
+    const uint32_t base = cv.pt_off[o];
+    CellRange cr;
+    const bool finite_q = isfinite(cx) && isfinite(cy) && isfinite(cz);
+    if (!finite_q || !ball_cells(m, cx, cy, cz, radius, cr)) {
+        if (lane < 9) out[lane] = __builtin_nanf("");
+        return;
+    }
+    double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, sum = 0;
+    int valid = 0;
+    const double rd = (double)radius;
+    for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
+        for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+            const int rb = (gz * m.dim[1] + gy) * m.dim[0];
+            const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+            for (uint32_t t = s + lane; t < e; t += 64) {
+                const float px = cv.sx[base + t], py = cv.sy[base + t], pz = cv.sz[base + t];
+                const float d2 = sqdist3(px, py, pz, cx, cy, cz);
+                if (d2 < r2 && !(px == cx && py == cy && pz == cz)) {
+                    const double vx = (double)(px - cx), vy = (double)(py - cy), vz = (double)(pz - cz);
+                    const double w = rd - sqrt((double)d2);
+                    c00 += w * (vx * vx); c01 += w * (vx * vy); c02 += w * (vx * vz);
+                    c11 += w * (vy * vy); c12 += w * (vy * vz); c22 += w * (vz * vz);
+                    sum += w; valid++;
+                }
+            }
+        }
+    c00 = wave_sum_d(c00); c01 = wave_sum_d(c01); c02 = wave_sum_d(c02);
+    c11 = wave_sum_d(c11); c12 = wave_sum_d(c12); c22 = wave_sum_d(c22);
+    sum = wave_sum_d(sum); valid = wave_sum_i(valid);
+    if (valid < 5) {
+        if (lane < 9) out[lane] = __builtin_nanf("");
+        return;
+    }
+    double A[3][3] = {{c00 / sum, c01 / sum, c02 / sum}, {c01 / sum, c11 / sum, c12 / sum}, {c02 / sum, c12 / sum, c22 / sum}};
+    double w[3], V[3][3];
+    eigen_sym3(A, w, V);
+    if (!(isfinite(w[0]) && isfinite(w[1]) && isfinite(w[2]))) {
+        if (lane < 9) out[lane] = __builtin_nanf("");
+        return;
+    }
+    double v1[3] = {V[0][2], V[1][2], V[2][2]};
+    double v3[3] = {V[0][0], V[1][0], V[2][0]};
+    int plusT = 0, plusN = 0;
+    for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
+        for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+            const int rb = (gz * m.dim[1] + gy) * m.dim[0];
+            const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+            for (uint32_t t = s + lane; t < e; t += 64) {
+                const float px = cv.sx[base + t], py = cv.sy[base + t], pz = cv.sz[base + t];
+                const float d2 = sqdist3(px, py, pz, cx, cy, cz);
+                if (d2 < r2 && !(px == cx && py == cy && pz == cz)) {
+                    const double vx = (double)(px - cx), vy = (double)(py - cy), vz = (double)(pz - cz);
+                    if (vx * v1[0] + vy * v1[1] + vz * v1[2] >= 0) plusT++;
+                    if (vx * v3[0] + vy * v3[1] + vz * v3[2] >= 0) plusN++;
+                }
+            }
+        }
+    plusT = 2 * wave_sum_i(plusT) - valid;
+    plusN = 2 * wave_sum_i(plusN) - valid;
+    if (plusT < 0) { v1[0] = -v1[0]; v1[1] = -v1[1]; v1[2] = -v1[2]; }
+    if (plusN < 0) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
+    if (plusT == 0 || plusN == 0) {
+        if (lane == 0) {
+            const uint32_t slot = atomicAdd(tie_count, 1u);
+            TieRec r;
+            for (int i = 0; i < 3; ++i) { r.v1[i] = v1[i]; r.v3[i] = v3[i]; }
+            r.kp = k; r.obj = (uint32_t)o; r.valid = valid; r.tie_x = plusT == 0; r.tie_z = plusN == 0;
+            tie_rec[slot] = r;
+        }
+        return;   // finished by k_lrf_tie
+    }
+    if (lane == 0) write_lrf(out, v1, v3);
+}
+
+// Sign ties: the 5 neighbours around the median BY DISTANCE decide (ascending (d^2, index) order).
+// One wave per queued keypoint; keys = (d2 bits << 32 | original index) in a per-wave global scratch.
+__global__ __launch_bounds__(256) void k_lrf_tie(CloudView cv, const float* __restrict__ kx, const float* __restrict__ ky,
+                                                 const float* __restrict__ kz, float radius, float r2,
+                                                 float* __restrict__ lrf_out, const uint32_t* __restrict__ tie_count,
+                                                 const TieRec* __restrict__ tie_rec, unsigned long long* __restrict__ keys,
+                                                 uint32_t key_cap) {
+    const int lane = lane_id();
+    const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t nw = gridDim.x * 4;
+    const uint32_t n_tie = *tie_count;
+    unsigned long long* mykeys = keys + (size_t)gw * key_cap;
+    for (uint32_t t = gw; t < n_tie; t += nw) {
+        const TieRec r = tie_rec[t];
+        const int o = (int)r.obj;
+        const uint32_t k = r.kp;
+        const float cx = kx[k], cy = ky[k], cz = kz[k];
+        const GridMeta m = cv.meta[o];
+        const uint32_t* cs = cv.cell_start + (size_t)o * ISM_GRID_STRIDE;
+        const uint32_t base = cv.pt_off[o];
+        CellRange cr;
+        ball_cells(m, cx, cy, cz, radius, cr);
+        uint32_t n = 0;
+        for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
+            for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+                const int rb = (gz * m.dim[1] + gy) * m.dim[0];
+                const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+                for (uint32_t t0 = s; t0 < e; t0 += 64) {
+                    const uint32_t i = t0 + lane;
+                    bool pass = false; float d2 = 0.f; uint32_t orig = 0;
+                    if (i < e) {
+                        const float px = cv.sx[base + i], py = cv.sy[base + i], pz = cv.sz[base + i];
+                        d2 = sqdist3(px, py, pz, cx, cy, cz);
+                        pass = d2 < r2 && !(px == cx && py == cy && pz == cz);
+                        orig = cv.sorig[base + i];
+                    }
+                    const unsigned long long mask = __ballot(pass);
+                    if (pass) {
+                        const uint32_t pos = n + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (pos < key_cap) mykeys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | orig;
+                    }
+                    n += __popcll(mask);
+                }
+            }
+        __threadfence_block();
+        if (n > key_cap) n = key_cap;   // cannot happen: key_cap = largest object
+        const int median = (int)n / 2;
+        int cntx = 0, cntz = 0;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const unsigned long long ki = mykeys[i];
+            int rank = 0;
+            for (uint32_t j = 0; j < n; ++j) rank += mykeys[j] < ki;
+            if (rank >= median - 2 && rank <= median + 2) {
+                const uint32_t orig = (uint32_t)(ki & 0xffffffffull);
+                const double vx = (double)(cv.x[base + orig] - cx), vy = (double)(cv.y[base + orig] - cy), vz = (double)(cv.z[base + orig] - cz);
+                if (vx * r.v1[0] + vy * r.v1[1] + vz * r.v1[2] > 0) cntx++;
+                if (vx * r.v3[0] + vy * r.v3[1] + vz * r.v3[2] > 0) cntz++;
+            }
+        }
+        cntx = wave_sum_i(cntx); cntz = wave_sum_i(cntz);
+        double v1[3] = {r.v1[0], r.v1[1], r.v1[2]}, v3[3] = {r.v3[0], r.v3[1], r.v3[2]};
+        if (r.tie_x && cntx < 3) { v1[0] = -v1[0]; v1[1] = -v1[1]; v1[2] = -v1[2]; }
+        if (r.tie_z && cntz < 3) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
+        if (lane == 0) write_lrf(lrf_out + (size_t)k * 9, v1, v3);
+    }
+}
+
+}  // namespace
+
+extern "C" int ismhip_shot_lrf(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
+                               const float* kpx, const float* kpy, const float* kpz, float radius, float* lrf9_out) {
+    if (!ctx || !cloud || !kp_offsets_h || !kpx || !kpy || !kpz || !lrf9_out || !(radius > 0.f))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "shot_lrf: bad argument");
+    const int n_obj = cloud->n_obj;
+    uint32_t maxk = 0;
+    for (int o = 0; o < n_obj; ++o) {
+        if (kp_offsets_h[o + 1] < kp_offsets_h[o]) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "shot_lrf: offsets not monotone");
+        maxk = std::max(maxk, kp_offsets_h[o + 1] - kp_offsets_h[o]);
+    }
+    const uint32_t nkp = kp_offsets_h[n_obj] - kp_offsets_h[0];
+    if (nkp == 0 || maxk == 0) return ISMHIP_OK;
+    uint32_t* ko = ism_upload_offsets(ctx, SCR_KP_OFF, kp_offsets_h, n_obj + 1);
+    if (!ko) return ISMHIP_ERR_HIP;
+    uint32_t* tie_count = (uint32_t*)ism_scratch(ctx, SCR_COUNTERS, 64);
+    TieRec* tie_rec = (TieRec*)ism_scratch(ctx, SCR_TIE_REC, (size_t)nkp * sizeof(TieRec));
+    const int tie_blocks = 128;   // 512 waves
+    const uint32_t key_cap = cloud->max_pts ? cloud->max_pts : 1;
+    unsigned long long* keys = (unsigned long long*)ism_scratch(ctx, SCR_TIE_KEYS, (size_t)tie_blocks * 4 * key_cap * 8);
+    if (!tie_count || !tie_rec || !keys) return ISMHIP_ERR_NOMEM;
+    CloudView cv{cloud->pt_off, cloud->meta, cloud->cell_start, cloud->sx, cloud->sy, cloud->sz, cloud->sorig, cloud->x, cloud->y, cloud->z};
+    const float r2 = (float)((double)radius * (double)radius);   // PCL: static_cast<float>(radius*radius) with double radius
+    TimerScope ts(ctx, "lrf");
+    ISM_HIP(ctx, hipMemsetAsync(tie_count, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_lrf, dim3((maxk + 3) / 4, n_obj), dim3(256), 0, ctx->stream, cv, ko, kpx, kpy, kpz, radius, r2, lrf9_out, tie_count, tie_rec);
+    ISM_CHECK_LAUNCH(ctx, "k_lrf");
+    hipLaunchKernelGGL(k_lrf_tie, dim3(tie_blocks), dim3(256), 0, ctx->stream, cv, kpx, kpy, kpz, radius, r2, lrf9_out, tie_count, tie_rec, keys, key_cap);
+    ISM_CHECK_LAUNCH(ctx, "k_lrf_tie");
+    return ISMHIP_OK;
+}

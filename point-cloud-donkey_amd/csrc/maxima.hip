@@ -1,0 +1,387 @@
+// maxima.hip — continuous Hough space: mean-shift mode search + maxima post-processing, one workgroup per object.
+// Reference seams: Voting::findMaxima (voting/voting.cpp:79-328, 436-462), VotingMeanShift::iFindMaxima and helpers
+// (voting/voting_mean_shift.cpp:33-37, 39-177, 201-481), MaximaHandler::averageNeighborMaxima / suppressNeighborMaxima
+// (voting/maxima_handler.cpp:51-157).
+//
+// Latency/LDS-bound and tiny (V <= a few thousand votes per object): all votes of the current class live in LDS,
+// seeds come from a 64-bit (z,y,x) cell-key bitonic sort (the reference's std::map order), every wave shifts one
+// seed at a time with its 64 lanes striding the votes, and the order-dependent greedy passes (average, suppress)
+// run on one lane exactly as the reference's loops do. Votes of a class are taken in slot order.
+// Not built (as in the oracle): RANSAC vote filter, global features, single-object max types, quaternion averaging.
+#include "common.h"
+
+namespace {
+
+#define MX_MAXC 256        // classes
+#define MX_MAXM 256        // maxima kept per object before sort/normalise
+#define MX_BIAS (1 << 20)
+
+struct MaxArgs {
+    const uint32_t* slot_off; const float* vpos; const float* vw; const int32_t* vcls; const int32_t* vinst; const float* vbs;
+    int n_classes; const float* class_bw; float bandwidth, threshold; int max_iter, kernel, suppression, min_votes;
+    float min_threshold; int best_k, max_maxima, cap;
+    int32_t* n_max; float* mpos; float* mw; int32_t* mcls; int32_t* minst; float* miw; float* mbs; int32_t* mnv; float* class_score;
+};
+
+__device__ __forceinline__ float ms_kernel(int kernel, float u) {          // voting_mean_shift.cpp:378-417
+    if (kernel == ISMHIP_KERNEL_GAUSSIAN) return (float)exp(-0.5 * (double)u);
+    if (kernel == ISMHIP_KERNEL_UNIFORM) return 1.f;
+    return 0.f;
+}
+__device__ __forceinline__ float ms_neg_kernel_derivative(int kernel, float u) {
+    if (kernel == ISMHIP_KERNEL_GAUSSIAN) { const float profile = (float)exp(-0.5 * (double)u); return -(-0.5f * profile); }
+    if (kernel == ISMHIP_KERNEL_UNIFORM) return -1.f;
+    return 0.f;
+}
+__device__ __forceinline__ float dist3(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+__device__ __forceinline__ float block_sum_f(float v, float* s_red) {   // 256 threads
+    v = wave_sum_f(v);
+    __syncthreads();
+    if (lane_id() == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+__device__ __forceinline__ int block_sum_i(int v, int* s_red) {
+    v = wave_sum_i(v);
+    __syncthreads();
+    if (lane_id() == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+__global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int cap = a.cap;                                   // power of two >= max votes of one object
+    float* vx = (float*)smem;               float* vy = vx + cap; float* vz = vy + cap; float* vw = vz + cap;
+    int* vinst = (int*)(vw + cap);          int* vslot = vinst + cap;
+    unsigned long long* keys = (unsigned long long*)(vslot + cap);
+    float4* ctr = (float4*)(keys + cap);    float4* ctr2 = ctr + cap;
+    unsigned char* member = (unsigned char*)(ctr2 + cap);
+    __shared__ int s_clscount[MX_MAXC];
+    __shared__ float s_mpos[MX_MAXM][3], s_mw[MX_MAXM], s_miw[MX_MAXM], s_mbs[MX_MAXM][3];
+    __shared__ int s_mcls[MX_MAXM], s_minst[MX_MAXM], s_mnv[MX_MAXM];
+    __shared__ int s_nmax, s_n, s_ns, s_nc, s_np;
+    __shared__ int s_wcnt[4];
+    __shared__ float s_redf[4];
+    __shared__ int s_redi[4];
+    __shared__ float s_bv[4]; __shared__ int s_bi[4];
+
+    const int o = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t s0 = a.slot_off[o], s1 = a.slot_off[o + 1];
+    const int C = a.n_classes;
+    for (int i = tid; i < C; i += 256) s_clscount[i] = 0;
+    if (tid == 0) s_nmax = 0;
+    __syncthreads();
+    for (uint32_t s = s0 + tid; s < s1; s += 256) { const int c = a.vcls[s]; if (c >= 0 && c < C) atomicAdd(&s_clscount[c], 1); }
+    __syncthreads();
+
+    for (int c = 0; c < C; ++c) {
+        if (s_clscount[c] == 0) continue;                    // class absent from m_votes
+        const float h = a.class_bw ? a.class_bw[c] : a.bandwidth;          // voting_mean_shift.cpp:48-49
+        const float h2 = (float)((double)h * (double)h);
+        const float hh = h * h;
+        // ---- ordered compaction of the class's votes into LDS
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (uint32_t base = s0; base < s1; base += 256) {
+            const uint32_t s = base + tid;
+            const bool f = s < s1 && a.vcls[s] == c;
+            const unsigned long long mask = __ballot(f);
+            if (lane == 0) s_wcnt[wv] = __popcll(mask);
+            __syncthreads();
+            int off = s_n;
+            for (int k = 0; k < wv; ++k) off += s_wcnt[k];
+            if (f) {
+                const int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < cap) {
+                    vx[pos] = a.vpos[(size_t)s * 3]; vy[pos] = a.vpos[(size_t)s * 3 + 1]; vz[pos] = a.vpos[(size_t)s * 3 + 2];
+                    vw[pos] = a.vw[s]; vinst[pos] = a.vinst[s]; vslot[pos] = (int)s;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_n += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            __syncthreads();
+        }
+        const int n = min(s_n, cap);
+        // ---- seeds: unique cells of edge 2h/sqrt(2), key floor(x/edge + 0.5), (z,y,x) order (:431-481)
+        const float bin = (h * 2.0f) / sqrtf(2.0f);
+        int P = 1; while (P < n) P <<= 1;
+        for (int i = tid; i < P; i += 256) {
+            unsigned long long key = ~0ull;
+            if (i < n) {
+                int kx = (int)floor((double)(vx[i] / bin) + 0.5), ky = (int)floor((double)(vy[i] / bin) + 0.5), kz = (int)floor((double)(vz[i] / bin) + 0.5);
+                kx = max(-(MX_BIAS - 1), min(MX_BIAS - 1, kx)); ky = max(-(MX_BIAS - 1), min(MX_BIAS - 1, ky)); kz = max(-(MX_BIAS - 1), min(MX_BIAS - 1, kz));
+                key = ((unsigned long long)(kz + MX_BIAS) << 42) | ((unsigned long long)(ky + MX_BIAS) << 21) | (unsigned long long)(kx + MX_BIAS);
+            }
+            keys[i] = key;
+        }
+        __syncthreads();
+        for (int k2 = 2; k2 <= P; k2 <<= 1)
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < P; i += 256) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long ka = keys[i], kb = keys[ixj];
+                        const bool up = (i & k2) == 0;
+                        if ((ka > kb) == up) { keys[i] = kb; keys[ixj] = ka; }
+                    }
+                }
+                __syncthreads();
+            }
+        if (tid == 0) {
+            int ns = 0;
+            for (int i = 0; i < n; ++i) if (i == 0 || keys[i] != keys[i - 1]) keys[ns++] = keys[i];
+            s_ns = ns;
+        }
+        __syncthreads();
+        const int ns = s_ns;
+        // ---- mean shift, one wave per seed (:201-244, 331-376)
+        for (int si = wv; si < ns; si += 4) {
+            const unsigned long long key = keys[si];
+            float cx = (float)((int)(key & 0x1fffff) - MX_BIAS) * bin;
+            float cy = (float)((int)((key >> 21) & 0x1fffff) - MX_BIAS) * bin;
+            float cz = (float)((int)((key >> 42) & 0x1fffff) - MX_BIAS) * bin;
+            int iter = 0; float diff = 0.f; bool skip = false;
+            do {
+                float sx = 0.f, sy = 0.f, sz = 0.f; double tw = 0.0; int cnt = 0;
+                for (int i = lane; i < n; i += 64) {
+                    const float d2 = sqdist3(vx[i], vy[i], vz[i], cx, cy, cz);
+                    if (d2 < h2) {
+                        const float g = ms_neg_kernel_derivative(a.kernel, d2 / hh) * vw[i];
+                        sx += g * vx[i]; sy += g * vy[i]; sz += g * vz[i]; tw += (double)g; cnt++;
+                    }
+                }
+                cnt = wave_sum_i(cnt);
+                if (cnt == 0) { skip = true; break; }
+                sx = wave_sum_f(sx); sy = wave_sum_f(sy); sz = wave_sum_f(sz); tw = wave_sum_d(tw);
+                if (tw != 0.0) { const float twf = (float)tw; sx /= twf; sy /= twf; sz /= twf; }
+                diff = dist3(cx, cy, cz, sx, sy, sz);
+                cx = sx; cy = sy; cz = sz;
+                iter++;
+            } while (diff > a.threshold && iter <= a.max_iter);
+            if (lane == 0) ctr[si] = make_float4(cx, cy, cz, skip ? -1.f : 1.f);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int nc = 0;
+            for (int i = 0; i < ns; ++i) if (ctr[i].w > 0.f) ctr[nc++] = ctr[i];
+            s_nc = nc;
+        }
+        __syncthreads();
+        int nc = s_nc;
+        // ---- densities (:247-285), one wave per centre
+        for (int ci = wv; ci < nc; ci += 4) {
+            const float4 p = ctr[ci];
+            float dsum = 0.f;
+            for (int i = lane; i < n; i += 64) {
+                const float d2 = sqdist3(vx[i], vy[i], vz[i], p.x, p.y, p.z);
+                if (d2 < h2) dsum += ms_kernel(a.kernel, d2 / hh) * vw[i];
+            }
+            dsum = wave_sum_f(dsum);
+            if (lane == 0) ctr[ci].w = dsum;
+        }
+        __syncthreads();
+        if (a.suppression == ISMHIP_SUPPRESS_AVERAGE) {
+            // averageNeighborMaxima (maxima_handler.cpp:94-157): greedy, order dependent; duplicates stay in the list
+            if (tid == 0) {
+                for (int i = 0; i < nc; ++i) member[i] = 0;
+                for (int k = 0; k < nc; ++k) {
+                    if (member[k]) { ctr2[k] = ctr[k]; continue; }
+                    const float4 pa = ctr[k];
+                    float ax = 0.f, ay = 0.f, az = 0.f, sd = 0.f; int cnt = 1;
+                    ax = pa.x * pa.w; ay = pa.y * pa.w; az = pa.z * pa.w; sd = pa.w;
+                    for (int j = k + 1; j < nc; ++j) {
+                        if (member[j]) continue;
+                        const float4 pb = ctr[j];
+                        if (dist3(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z) < h) {
+                            member[j] = 1; cnt++;
+                            ax += pb.x * pb.w; ay += pb.y * pb.w; az += pb.z * pb.w; sd += pb.w;
+                        }
+                    }
+                    if (cnt == 1) ctr2[k] = pa;
+                    else {
+                        // the reference accumulates from zero: (0 + c_k*d_k) + c_j*d_j ...; adding to 0 first is exact
+                        ctr2[k] = make_float4(ax / sd, ay / sd, az / sd, 0.f);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int ci = wv; ci < nc; ci += 4) {
+                const float4 p = ctr2[ci];
+                float dsum = 0.f;
+                for (int i = lane; i < n; i += 64) {
+                    const float d2 = sqdist3(vx[i], vy[i], vz[i], p.x, p.y, p.z);
+                    if (d2 < h2) dsum += ms_kernel(a.kernel, d2 / hh) * vw[i];
+                }
+                dsum = wave_sum_f(dsum);
+                if (lane == 0) ctr[ci] = make_float4(p.x, p.y, p.z, dsum);
+            }
+            __syncthreads();
+        }
+        // ---- suppressNeighborMaxima (maxima_handler.cpp:51-92): greedy NMS by density
+        if (tid == 0) {
+            int np = 0;
+            if (a.suppression == ISMHIP_SUPPRESS_AVERAGE || a.suppression == ISMHIP_SUPPRESS_SUPPRESS) {
+                float* work = (float*)keys;
+                for (int i = 0; i < nc; ++i) work[i] = ctr[i].w;
+                for (;;) {
+                    float mx = -1.f; int mi = -1;
+                    for (int i = 0; i < nc; ++i) if (mi < 0 || work[i] > mx) { mx = work[i]; mi = i; }   // std::max_element: first largest
+                    if (mi < 0 || mx == -1.f) break;
+                    const float4 cpt = ctr[mi];
+                    ctr2[np++] = cpt;
+                    work[mi] = -1.f;
+                    for (int i = 0; i < nc; ++i)
+                        if (dist3(cpt.x, cpt.y, cpt.z, ctr[i].x, ctr[i].y, ctr[i].z) < h) work[i] = -1.f;
+                }
+            }
+            s_np = np;
+        }
+        __syncthreads();
+        const int np = s_np;
+        // ---- per maximum: density + in-place reweighting (:289-328) and the Voting::findMaxima block (voting.cpp:131-236)
+        for (int pi = 0; pi < np; ++pi) {
+            const float4 p = ctr2[pi];
+            int cnt = 0; float sw = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            for (int i = tid; i < n; i += 256) {
+                const float d2 = sqdist3(vx[i], vy[i], vz[i], p.x, p.y, p.z);
+                const bool in = d2 < h2;
+                member[i] = in ? 1 : 0;
+                if (in) {
+                    const float w = ms_kernel(a.kernel, d2 / hh) * vw[i];
+                    vw[i] = w;
+                    cnt++; sw += w;
+                    if (a.vbs) { const size_t s = (size_t)vslot[i] * 3; b0 += w * a.vbs[s]; b1 += w * a.vbs[s + 1]; b2 += w * a.vbs[s + 2]; }
+                }
+            }
+            cnt = block_sum_i(cnt, s_redi);
+            if (cnt < a.min_votes || cnt == 0) continue;      // uniform across the block
+            sw = block_sum_f(sw, s_redf);
+            b0 = block_sum_f(b0, s_redf); b1 = block_sum_f(b1, s_redf); b2 = block_sum_f(b2, s_redf);
+            __syncthreads();
+            // instance id with the largest summed weight; ties -> smallest id; weights <= 0 never win (voting.cpp:139-165)
+            float bestS = 0.f; int bestI = 0x7fffffff;
+            for (int i = tid; i < n; i += 256) {
+                if (!member[i]) continue;
+                const int id = vinst[i];
+                float S = 0.f;
+                for (int j = 0; j < n; ++j) if (member[j] && vinst[j] == id) S += vw[j];
+                if (S > bestS || (S == bestS && S > 0.f && (unsigned)id < (unsigned)bestI)) { bestS = S; bestI = id; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float oS = __shfl_xor(bestS, off, 64); const int oI = __shfl_xor(bestI, off, 64);
+                if (oS > bestS || (oS == bestS && oS > 0.f && (unsigned)oI < (unsigned)bestI)) { bestS = oS; bestI = oI; }
+            }
+            if (lane == 0) { s_bv[wv] = bestS; s_bi[wv] = bestI; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int k = 1; k < 4; ++k)
+                    if (s_bv[k] > bestS || (s_bv[k] == bestS && bestS > 0.f && (unsigned)s_bi[k] < (unsigned)bestI)) { bestS = s_bv[k]; bestI = s_bi[k]; }
+                const int m = s_nmax;
+                if (m < MX_MAXM) {
+                    s_mpos[m][0] = p.x; s_mpos[m][1] = p.y; s_mpos[m][2] = p.z;
+                    s_mw[m] = sw; s_mcls[m] = c; s_mnv[m] = cnt;
+                    s_minst[m] = bestS > 0.f ? bestI : -1; s_miw[m] = bestS > 0.f ? bestS : 0.f;
+                    s_mbs[m][0] = b0 / sw; s_mbs[m][1] = b1 / sw; s_mbs[m][2] = b2 / sw;
+                    s_nmax = m + 1;
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    // ---- sort (stable, descending weight), normalise, threshold, best-k (voting.cpp:272, 298-323, 441-462)
+    if (tid == 0) {
+        const int nm = s_nmax;
+        int* order = (int*)keys;
+        for (int i = 0; i < nm; ++i) order[i] = i;
+        for (int i = 1; i < nm; ++i) {
+            const int v = order[i]; int j = i - 1;
+            while (j >= 0 && s_mw[order[j]] < s_mw[v]) { order[j + 1] = order[j]; --j; }
+            order[j + 1] = v;
+        }
+        float sum = 0.f, sum_inst = 0.f;
+        for (int i = 0; i < nm; ++i) { sum += s_mw[order[i]]; sum_inst += s_miw[order[i]]; }
+        for (int i = 0; i < nm; ++i) {
+            s_mw[i] = sum != 0.f ? s_mw[i] / sum : 0.f;
+            s_miw[i] = sum_inst != 0.f ? s_miw[i] / sum_inst : 0.f;
+        }
+        float thr = a.min_threshold;
+        if (thr < 0.f) { const float mxw = nm > 0 ? s_mw[order[0]] : 0.0f; thr = -thr * mxw; }
+        int kept = 0;
+        for (int i = 0; i < nm; ++i) if (s_mw[order[i]] >= thr) order[kept++] = order[i];
+        if (a.best_k > 0 && kept >= a.best_k) kept = a.best_k;
+        for (int cc = 0; cc < C; ++cc) a.class_score[(size_t)o * C + cc] = 0.f;
+        for (int i = 0; i < kept; ++i) {
+            float* cs = &a.class_score[(size_t)o * C + s_mcls[order[i]]];
+            if (s_mw[order[i]] > *cs) *cs = s_mw[order[i]];
+        }
+        const int nout = min(kept, a.max_maxima);
+        a.n_max[o] = nout;
+        for (int i = 0; i < a.max_maxima; ++i) {
+            const size_t t = (size_t)o * a.max_maxima + i;
+            const bool ok = i < nout; const int m = ok ? order[i] : 0;
+            a.mpos[t * 3] = ok ? s_mpos[m][0] : 0.f; a.mpos[t * 3 + 1] = ok ? s_mpos[m][1] : 0.f; a.mpos[t * 3 + 2] = ok ? s_mpos[m][2] : 0.f;
+            a.mw[t] = ok ? s_mw[m] : 0.f; a.mcls[t] = ok ? s_mcls[m] : -1; a.minst[t] = ok ? s_minst[m] : -1;
+            a.miw[t] = ok ? s_miw[m] : 0.f; a.mnv[t] = ok ? s_mnv[m] : 0;
+            if (a.mbs) { a.mbs[t * 3] = ok ? s_mbs[m][0] : 0.f; a.mbs[t * 3 + 1] = ok ? s_mbs[m][1] : 0.f; a.mbs[t * 3 + 2] = ok ? s_mbs[m][2] : 0.f; }
+        }
+    }
+}
+
+}  // namespace
+
+uint32_t* ism_upload_offsets(ismhip_ctx* ctx, int slot, const uint32_t* off_h, int n);
+
+extern "C" int ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* slot_offsets_h,
+                                  const float* vote_pos, const float* vote_weight, const int32_t* vote_class,
+                                  const int32_t* vote_instance, const float* vote_bbox_size,
+                                  const ismhip_maxima_params* P,
+                                  int32_t* n_maxima_out, float* max_pos_out, float* max_weight_out,
+                                  int32_t* max_class_out, int32_t* max_instance_out, float* max_instance_weight_out,
+                                  float* max_bbox_size_out, int32_t* max_n_votes_out, float* class_score_out) {
+    if (!ctx || n_obj <= 0 || !slot_offsets_h || !vote_pos || !vote_weight || !vote_class || !vote_instance || !P ||
+        !n_maxima_out || !max_pos_out || !max_weight_out || !max_class_out || !max_instance_out || !max_instance_weight_out ||
+        !max_n_votes_out || !class_score_out || P->n_classes <= 0 || P->max_maxima <= 0 || !(P->bandwidth > 0.f || P->class_bandwidth_h))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "find_maxima: bad argument");
+    if (P->n_classes > MX_MAXC) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "find_maxima: more than 256 classes not built");
+    if (P->kernel != ISMHIP_KERNEL_GAUSSIAN && P->kernel != ISMHIP_KERNEL_UNIFORM) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "find_maxima: kernel");
+    uint32_t max_slots = 0;
+    for (int o = 0; o < n_obj; ++o) {
+        if (slot_offsets_h[o + 1] < slot_offsets_h[o]) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "find_maxima: offsets not monotone");
+        max_slots = std::max(max_slots, slot_offsets_h[o + 1] - slot_offsets_h[o]);
+    }
+    int cap = 64; while ((uint32_t)cap < max_slots) cap <<= 1;
+    if (cap > 2048) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "find_maxima: more than 2048 vote slots per object not built");
+    const size_t dyn = (size_t)cap * (4 * 4 + 2 * 4 + 8 + 16 + 16 + 1);
+    uint32_t* so = ism_upload_offsets(ctx, SCR_SLOT_OFF, slot_offsets_h, n_obj + 1);
+    if (!so) return ISMHIP_ERR_HIP;
+    float* bw = nullptr;
+    if (P->class_bandwidth_h) {
+        bw = (float*)ism_scratch(ctx, SCR_CLASS_BW, (size_t)P->n_classes * 4);
+        if (!bw) return ISMHIP_ERR_NOMEM;
+        ISM_HIP(ctx, hipMemcpyAsync(bw, P->class_bandwidth_h, (size_t)P->n_classes * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    MaxArgs a;
+    a.slot_off = so; a.vpos = vote_pos; a.vw = vote_weight; a.vcls = vote_class; a.vinst = vote_instance; a.vbs = vote_bbox_size;
+    a.n_classes = P->n_classes; a.class_bw = bw; a.bandwidth = P->bandwidth; a.threshold = P->threshold; a.max_iter = P->max_iter;
+    a.kernel = P->kernel; a.suppression = P->suppression; a.min_votes = P->min_votes_threshold; a.min_threshold = P->min_threshold;
+    a.best_k = P->best_k; a.max_maxima = P->max_maxima; a.cap = cap;
+    a.n_max = n_maxima_out; a.mpos = max_pos_out; a.mw = max_weight_out; a.mcls = max_class_out; a.minst = max_instance_out;
+    a.miw = max_instance_weight_out; a.mbs = max_bbox_size_out; a.mnv = max_n_votes_out; a.class_score = class_score_out;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ISM_HIP(ctx, hipFuncSetAttribute((const void*)k_find_maxima, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        attr_set = true;
+    }
+    TimerScope ts(ctx, "maxima");
+    hipLaunchKernelGGL(k_find_maxima, dim3(n_obj), dim3(256), dyn, ctx->stream, a);
+    ISM_CHECK_LAUNCH(ctx, "k_find_maxima");
+    return ISMHIP_OK;
+}

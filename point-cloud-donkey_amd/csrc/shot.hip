@@ -1,0 +1,284 @@
+// shot.hip — SHOT-352 and CSHOT-1344 descriptors, one 64-lane wavefront per keypoint.
+// Reference seams: FeaturesSHOT::iComputeDescriptors (features/features_shot.cpp:28-81) ->
+// pcl::SHOTEstimationOMP<..., SHOT352>; FeaturesCSHOT::iComputeDescriptors (features/features_cshot.cpp:28-103)
+// -> pcl::SHOTColorEstimationOMP<..., SHOT1344>. Arithmetic restated from PCL 1.10 computePointSHOT /
+// interpolateSingleChannel / interpolateDoubleChannel / normalizeHistogram.
+//
+// Roofline: HBM-bound gather. Algorithmic bytes per keypoint = M_k * 24 + 12 + 36 + 352*4 (SHOT) or
+// M_k * 28 + 12 + 36 + 4 + 1344*4 (CSHOT), M_k = radius neighbours.
+//
+// Structure per wave: stream the candidate x-runs of the query ball (coalesced SoA loads of the cell-sorted
+// cloud); lanes whose point is inside the ball are COMPACTED with a ballot + prefix popcount into a 128-entry
+// LDS queue; whenever 64 are queued, all 64 lanes run the per-neighbour math on a full wave (no divergence on
+// the radius test) and deposit into a per-wave LDS histogram with ds_add_f32. The wave then L2-normalises and
+// writes the row with coalesced stores.
+#include "common.h"
+
+uint32_t* ism_upload_offsets(ismhip_ctx* ctx, int slot, const uint32_t* off_h, int n);
+
+namespace {
+
+#define PST_RAD_45f   0.78539816339744830962f
+#define PST_RAD_90f   1.57079632679489661923f
+#define PST_RAD_135f  2.35619449019234492885f
+#define PST_RAD_PI_7_8f 2.7488935718910690836f
+
+struct ShotArgs {
+    const uint32_t* pt_off; const GridMeta* meta; const uint32_t* cell_start;
+    const float *sx, *sy, *sz, *snx, *sny, *snz, *sL, *sa, *sb;
+    const uint32_t* kp_off; const float *kx, *ky, *kz; const uint32_t* kp_rgba;
+    const float* lrf; float radius, r2;
+    const float *lut_srgb, *lut_sxyz;
+    float* desc; uint32_t* count;
+};
+
+template <bool COLOR>
+struct ShotSmem {
+    float hist[4][COLOR ? 1344 : 352];
+    float qd[4][128][3];     // dx, dy, dz of queued neighbours
+    float qd2[4][128];
+    uint32_t qi[4][128];     // sorted index of queued neighbours
+};
+
+// Per-neighbour SHOT update. All 64 lanes call it; 'act' marks lanes that hold a neighbour.
+template <bool COLOR>
+__device__ __forceinline__ void shot_neighbour(const ShotArgs& a, float* hist, bool act, uint32_t gi,
+                                               float dx, float dy, float dz, float d2,
+                                               const float fx[3], const float fy[3], const float fz[3],
+                                               float r12, float r14, float r34, float inv_r12,
+                                               float LRef, float aRef, float bRef) {
+    if (!act) return;
+    const float nxv = a.snx[gi], nyv = a.sny[gi], nzv = a.snz[gi];
+    if (!(isfinite(nxv) && isfinite(nyv) && isfinite(nzv))) return;              // createBinDistanceShape: NaN normal -> skipped
+    float cosd = (nxv * fz[0] + nyv * fz[1]) + nzv * fz[2];
+    cosd = fminf(1.0f, fmaxf(-1.0f, cosd));
+    float bd = ((1.0f + cosd) * 10.0f) * 0.5f;
+    const float dist = sqrtf(d2);
+    if (dist < 1e-15f) return;                                                    // areEquals(distance, 0)
+    float xl = (dx * fx[0] + dy * fx[1]) + dz * fx[2];
+    float yl = (dx * fy[0] + dy * fy[1]) + dz * fy[2];
+    float zl = (dx * fz[0] + dy * fz[1]) + dz * fz[2];
+    if (fabsf(yl) < 1e-30f) yl = 0.f;
+    if (fabsf(xl) < 1e-30f) xl = 0.f;
+    if (fabsf(zl) < 1e-30f) zl = 0.f;
+    const int bit4 = ((yl > 0.f) || ((yl == 0.f) && (xl < 0.f))) ? 1 : 0;
+    const int bit3 = ((xl > 0.f) || ((xl == 0.f) && (yl > 0.f))) ? !bit4 : bit4;
+    int di = ((bit4 << 3) + (bit3 << 2)) << 1;
+    const bool same_sign = (xl > 0.f && yl > 0.f) || (xl < 0.f && yl < 0.f);      // x*y > 0 without float underflow
+    if (same_sign || xl == 0.f) di += (fabsf(xl) >= fabsf(yl)) ? 0 : 4;
+    else di += (fabsf(xl) > fabsf(yl)) ? 4 : 0;
+    di += zl > 0.f ? 1 : 0;
+    const bool outer = dist > r12;
+    di += outer ? 2 : 0;
+
+    const int step = (int)floorf(bd + 0.5f);
+    const int vol = di * 11;
+    bd -= (float)step;
+    float w_shape = 1.f - fabsf(bd);
+    if (bd > 0.f) atomicAdd(&hist[vol + ((step + 1) % 10)], bd);
+    else atomicAdd(&hist[vol + ((step - 1 + 10) % 10)], -bd);
+
+    int step_c = 0, vol_c = 0; float w_col = 0.f;
+    if (COLOR) {
+        const float L = a.sL[gi], A = a.sa[gi], B = a.sb[gi];
+        float cd = (fabsf(LRef - L) + ((fabsf(aRef - A) + fabsf(bRef - B)) * 0.5f)) / 3.0f;
+        cd = fminf(1.0f, fmaxf(0.0f, cd));
+        float bc = cd * 30.0f;
+        step_c = (int)floorf(bc + 0.5f);
+        vol_c = 352 + di * 31;
+        bc -= (float)step_c;
+        w_col = 1.f - fabsf(bc);
+        if (bc > 0.f) atomicAdd(&hist[vol_c + ((step_c + 1) % 30)], bc);
+        else atomicAdd(&hist[vol_c + ((step_c - 1 + 30) % 30)], -bc);
+    }
+#define SHOT_DEP(sector, v)                                                          \
+    do {                                                                             \
+        atomicAdd(&hist[(sector) * 11 + step], (v));                                 \
+        if (COLOR) atomicAdd(&hist[352 + (sector) * 31 + step_c], (v));              \
+    } while (0)
+    float winc = 0.f;
+    // radial
+    if (outer) {
+        const float rd = (dist - r34) * inv_r12;
+        if (dist > r34) winc += 1.f - rd;
+        else { winc += 1.f + rd; SHOT_DEP(di - 2, -rd); }
+    } else {
+        const float rd = (dist - r14) * inv_r12;
+        if (dist < r14) winc += 1.f + rd;
+        else { winc += 1.f - rd; SHOT_DEP(di + 2, rd); }
+    }
+    // elevation
+    float ic = zl / dist;
+    ic = fminf(1.0f, fmaxf(-1.0f, ic));
+    const float inc = acosf(ic);
+    if (inc > PST_RAD_90f || (fabsf(inc - PST_RAD_90f) < 1e-30f && zl <= 0.f)) {
+        const float id = (inc - PST_RAD_135f) / PST_RAD_90f;
+        if (inc > PST_RAD_135f) winc += 1.f - id;
+        else { winc += 1.f + id; SHOT_DEP(di + 1, -id); }
+    } else {
+        const float id = (inc - PST_RAD_45f) / PST_RAD_90f;
+        if (inc < PST_RAD_45f) winc += 1.f + id;
+        else { winc += 1.f - id; SHOT_DEP(di - 1, id); }
+    }
+    // azimuth
+    if (yl != 0.f || xl != 0.f) {
+        const float az = atan2f(yl, xl);
+        const int sel = di >> 2;
+        float ad = (az - (-PST_RAD_PI_7_8f + PST_RAD_45f * (float)sel)) / PST_RAD_45f;
+        ad = fmaxf(-0.5f, fminf(ad, 0.5f));
+        if (ad > 0.f) { winc += 1.f - ad; SHOT_DEP((di + 4) % 32, ad); }
+        else { winc += 1.f + ad; SHOT_DEP((di - 4 + 32) % 32, -ad); }
+    }
+#undef SHOT_DEP
+    atomicAdd(&hist[vol + step], w_shape + winc);
+    if (COLOR) atomicAdd(&hist[vol_c + step_c], w_col + winc);
+}
+
+__device__ __forceinline__ void rgb2lab_norm(const float* lut_srgb, const float* lut_sxyz, uint32_t c4, float& L, float& A, float& B) {
+    const float fr = lut_srgb[(c4 >> 16) & 0xff], fg = lut_srgb[(c4 >> 8) & 0xff], fb = lut_srgb[c4 & 0xff];
+    const float X = fr * 0.412453f + fg * 0.357580f + fb * 0.180423f;
+    const float Y = fr * 0.212671f + fg * 0.715160f + fb * 0.072169f;
+    const float Z = fr * 0.019334f + fg * 0.119193f + fb * 0.950227f;
+    float vx = X / 0.95047f, vy = Y, vz = Z / 1.08883f;
+    int ix = (int)(vx * 4000), iy = (int)(vy * 4000), iz = (int)(vz * 4000);
+    ix = ix < 0 ? 0 : (ix > 3999 ? 3999 : ix); iy = iy < 0 ? 0 : (iy > 3999 ? 3999 : iy); iz = iz < 0 ? 0 : (iz > 3999 ? 3999 : iz);
+    vx = lut_sxyz[ix]; vy = lut_sxyz[iy]; vz = lut_sxyz[iz];
+    L = 116.0f * vy - 16.0f; if (L > 100) L = 100.0f;
+    A = 500.0f * (vx - vy); if (A > 120) A = 120.0f; else if (A < -120) A = -120.0f;
+    B = 200.0f * (vy - vz); if (B > 120) B = 120.0f; else if (B < -120) B = -120.0f;
+    L /= 100.0f; A /= 120.0f; B /= 120.0f;
+}
+
+template <bool COLOR>
+__global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
+    constexpr int D = COLOR ? 1344 : 352;
+    __shared__ ShotSmem<COLOR> sm;
+    const int o = blockIdx.y;
+    const int wv = threadIdx.x >> 6;
+    const int lane = lane_id();
+    const uint32_t k = a.kp_off[o] + blockIdx.x * 4 + wv;
+    if (k >= a.kp_off[o + 1]) return;          // wave-uniform; no block-level barrier below
+    float* hist = sm.hist[wv];
+    float* out = a.desc + (size_t)k * D;
+    const float cx = a.kx[k], cy = a.ky[k], cz = a.kz[k];
+    const float* f = a.lrf + (size_t)k * 9;
+    const float fx[3] = {f[0], f[1], f[2]}, fy[3] = {f[3], f[4], f[5]}, fz[3] = {f[6], f[7], f[8]};
+    const GridMeta m = a.meta[o];
+    CellRange cr;
+    const bool ok = isfinite(fx[0]) && isfinite(fy[0]) && isfinite(fz[0]) && isfinite(cx) && isfinite(cy) && isfinite(cz);
+    if (!ok || !ball_cells(m, cx, cy, cz, a.radius, cr)) {
+        for (int i = lane; i < D; i += 64) out[i] = __builtin_nanf("");
+        if (a.count && lane == 0) a.count[k] = 0;
+        return;
+    }
+    for (int i = lane; i < D; i += 64) hist[i] = 0.f;
+    float LRef = 0.f, aRef = 0.f, bRef = 0.f;
+    if (COLOR) rgb2lab_norm(a.lut_srgb, a.lut_sxyz, a.kp_rgba[k], LRef, aRef, bRef);
+    const float r12 = a.radius * 0.5f, r14 = a.radius * 0.25f, r34 = (a.radius * 3.0f) * 0.25f, inv_r12 = 1.0f / r12;
+    const uint32_t* cs = a.cell_start + (size_t)o * ISM_GRID_STRIDE;
+    const uint32_t base = a.pt_off[o];
+    uint32_t qn = 0, total = 0;
+    for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
+        for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+            const int rb = (gz * m.dim[1] + gy) * m.dim[0];
+            const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+            for (uint32_t t0 = s; t0 < e; t0 += 64) {
+                const uint32_t i = t0 + lane;
+                bool pass = false; float dx = 0, dy = 0, dz = 0, d2 = 0;
+                if (i < e) {
+                    const float px = a.sx[base + i], py = a.sy[base + i], pz = a.sz[base + i];
+                    d2 = sqdist3(px, py, pz, cx, cy, cz);
+                    dx = px - cx; dy = py - cy; dz = pz - cz;
+                    pass = d2 < a.r2;
+                }
+                const unsigned long long mask = __ballot(pass);
+                if (pass) {
+                    const uint32_t pos = qn + __popcll(mask & ((1ull << lane) - 1ull));
+                    sm.qd[wv][pos][0] = dx; sm.qd[wv][pos][1] = dy; sm.qd[wv][pos][2] = dz;
+                    sm.qd2[wv][pos] = d2; sm.qi[wv][pos] = base + i;
+                }
+                const uint32_t c = __popcll(mask);
+                qn += c; total += c;
+                if (qn >= 64) {
+                    // a full wave of neighbours (LDS traffic of one wave is ordered; no barrier needed)
+                    shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][lane], sm.qd[wv][lane][0], sm.qd[wv][lane][1], sm.qd[wv][lane][2],
+                                          sm.qd2[wv][lane], fx, fy, fz, r12, r14, r34, inv_r12, LRef, aRef, bRef);
+                    const uint32_t rem = qn - 64;
+                    float t0x = 0, t0y = 0, t0z = 0, t0d = 0; uint32_t t0i = 0;
+                    if ((uint32_t)lane < rem) {
+                        t0x = sm.qd[wv][64 + lane][0]; t0y = sm.qd[wv][64 + lane][1]; t0z = sm.qd[wv][64 + lane][2];
+                        t0d = sm.qd2[wv][64 + lane]; t0i = sm.qi[wv][64 + lane];
+                    }
+                    if ((uint32_t)lane < rem) {
+                        sm.qd[wv][lane][0] = t0x; sm.qd[wv][lane][1] = t0y; sm.qd[wv][lane][2] = t0z;
+                        sm.qd2[wv][lane] = t0d; sm.qi[wv][lane] = t0i;
+                    }
+                    qn = rem;
+                }
+            }
+        }
+    if (qn > 0) {
+        const bool act = (uint32_t)lane < qn;
+        shot_neighbour<COLOR>(a, hist, act, act ? sm.qi[wv][lane] : 0u, sm.qd[wv][lane][0], sm.qd[wv][lane][1], sm.qd[wv][lane][2],
+                              sm.qd2[wv][lane], fx, fy, fz, r12, r14, r34, inv_r12, LRef, aRef, bRef);
+    }
+    if (a.count && lane == 0) a.count[k] = total;
+    if (total < 5) {                                    // computePointSHOT: fewer than 5 neighbours -> NaN descriptor
+        for (int i = lane; i < D; i += 64) out[i] = __builtin_nanf("");
+        return;
+    }
+    // normalizeHistogram: double accumulate of float squares, divide by float(norm)
+    double acc = 0.0;
+    for (int i = lane; i < D; i += 64) { const float v = hist[i]; acc += (double)(v * v); }
+    acc = wave_sum_d(acc);
+    const float fn = (float)sqrt(acc);
+    for (int i = lane; i < D; i += 64) out[i] = hist[i] / fn;
+}
+
+template <bool COLOR>
+int launch_shot(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
+                const float* kpx, const float* kpy, const float* kpz, const uint32_t* kp_rgba,
+                const float* lrf9, float radius, float* desc_out, uint32_t* count_out, const char* name) {
+    if (!ctx || !cloud || !kp_offsets_h || !kpx || !kpy || !kpz || !lrf9 || !desc_out || !(radius > 0.f))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, std::string(name) + ": bad argument");
+    if (COLOR && (!cloud->rgba || !kp_rgba)) return ism_set_err(ctx, ISMHIP_ERR_INVALID, std::string(name) + ": colour arrays missing");
+    const int n_obj = cloud->n_obj;
+    uint32_t maxk = 0;
+    for (int o = 0; o < n_obj; ++o) {
+        if (kp_offsets_h[o + 1] < kp_offsets_h[o]) return ism_set_err(ctx, ISMHIP_ERR_INVALID, std::string(name) + ": offsets not monotone");
+        maxk = std::max(maxk, kp_offsets_h[o + 1] - kp_offsets_h[o]);
+    }
+    if (maxk == 0) return ISMHIP_OK;
+    uint32_t* ko = ism_upload_offsets(ctx, SCR_KP_OFF, kp_offsets_h, n_obj + 1);
+    if (!ko) return ISMHIP_ERR_HIP;
+    ShotArgs a;
+    a.pt_off = cloud->pt_off; a.meta = cloud->meta; a.cell_start = cloud->cell_start;
+    a.sx = cloud->sx; a.sy = cloud->sy; a.sz = cloud->sz; a.snx = cloud->snx; a.sny = cloud->sny; a.snz = cloud->snz;
+    a.sL = cloud->sL; a.sa = cloud->sa; a.sb = cloud->sb;
+    a.kp_off = ko; a.kx = kpx; a.ky = kpy; a.kz = kpz; a.kp_rgba = kp_rgba; a.lrf = lrf9;
+    a.radius = radius; a.r2 = (float)((double)radius * (double)radius);
+    a.lut_srgb = ctx->lut_srgb; a.lut_sxyz = ctx->lut_sxyz;
+    a.desc = desc_out; a.count = count_out;
+    TimerScope ts(ctx, name);
+    hipLaunchKernelGGL(k_shot<COLOR>, dim3((maxk + 3) / 4, n_obj), dim3(256), 0, ctx->stream, a);
+    ISM_CHECK_LAUNCH(ctx, name);
+    return ISMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ismhip_shot352(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
+                   const float* kpx, const float* kpy, const float* kpz,
+                   const float* lrf9, float radius, float* desc_out, uint32_t* neighbour_count_out) {
+    return launch_shot<false>(ctx, cloud, kp_offsets_h, kpx, kpy, kpz, nullptr, lrf9, radius, desc_out, neighbour_count_out, "shot352");
+}
+
+int ismhip_cshot1344(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
+                     const float* kpx, const float* kpy, const float* kpz, const uint32_t* kp_rgba,
+                     const float* lrf9, float radius, float* desc_out, uint32_t* neighbour_count_out) {
+    return launch_shot<true>(ctx, cloud, kp_offsets_h, kpx, kpy, kpz, kp_rgba, lrf9, radius, desc_out, neighbour_count_out, "cshot1344");
+}
+
+}  // extern "C"

@@ -1,0 +1,214 @@
+"""Batch recognition driver over the C ABI (include/ismhip.h): the Python twin of ImplicitShapeModel::train()/detect().
+
+Reference call stack mirrored here (paths relative to /root/reference/src/implicit_shape_model):
+  detect : implicit_shape_model.cpp:583-712  computeFeatures -> removeNaNFeatures -> castVotes -> findMaxima
+  train  : implicit_shape_model.cpp:252-500 with Clustering "None" (clustering_none.cpp:25-35), KNN K=1 activation
+           (codebook.cpp:64-224: activate, per-class sigma, k=1 clean-up) and Uniform feature ranking.
+All heavy work is inside libismhip.so; this file only sequences the calls and keeps every intermediate on the device
+(one host sync per batch, for the NaN-feature compaction counts). torch is device memory + streams, nothing else.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class IsmConfig:
+    feature: str = "SHOT"            # "SHOT" | "CSHOT" | "FPFH"   (Features.Type)
+    radius: float = 0.4              # Features.Radius
+    lrf_radius: float = 0.3          # Features.ReferenceFrameRadius
+    distance: str = "Euclidean"      # DistanceType: "Euclidean" (FLANN L2, squared) | "ChiSquared"
+    k: int = 1                       # ActivationStrategy.K
+    use_distance_ratio: bool = False
+    distance_ratio_threshold: float = 0.95
+    use_class_weight: bool = False
+    use_vote_weight: bool = False
+    use_matching_weight: bool = False
+    use_codeword_weight: bool = False
+    bandwidth: float = 0.6           # Voting.Bandwidth
+    threshold: float = 1e-3
+    max_iter: int = 1000
+    kernel: str = "Gaussian"
+    maxima_suppression: str = "Average"
+    min_votes_threshold: int = 1
+    min_threshold: float = 0.0
+    best_k: int = -1
+    max_maxima: int = 16
+    n_classes: int = 10
+    use_random_codebook: bool = False
+    random_codebook_size: int = 0    # fixed-size seeded subset (reference: UseRandomCodebook/RandomCodebookFactor, codebook.cpp:821-829)
+    random_codebook_seed: int = 0x5EED
+
+    @property
+    def dim(self):
+        return {"SHOT": 352, "CSHOT": 1344, "FPFH": 33}[self.feature]
+
+    @property
+    def metric(self):
+        return {"Euclidean": capi.METRIC_L2SQ, "ChiSquared": capi.METRIC_CHI2}[self.distance]
+
+    @property
+    def weight_flags(self):
+        return ((capi.W_CLASS if self.use_class_weight else 0) | (capi.W_VOTE if self.use_vote_weight else 0) |
+                (capi.W_MATCHING if self.use_matching_weight else 0) | (capi.W_CODEWORD if self.use_codeword_weight else 0))
+
+
+class DeviceBatch:
+    """A batch of objects resident in HBM as SoA float tensors (+ host offset arrays)."""
+
+    def __init__(self, np_batch, device):
+        import torch
+        t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device)
+        self.pt_off = np.asarray(np_batch["pt_off"], np.uint32)
+        self.kp_off = np.asarray(np_batch["kp_off"], np.uint32)
+        xyz, nrm, kp = np_batch["xyz"], np_batch["normals"], np_batch["kp"]
+        self.x, self.y, self.z = t(xyz[:, 0]), t(xyz[:, 1]), t(xyz[:, 2])
+        self.nx, self.ny, self.nz = t(nrm[:, 0]), t(nrm[:, 1]), t(nrm[:, 2])
+        self.kx, self.ky, self.kz = t(kp[:, 0]), t(kp[:, 1]), t(kp[:, 2])
+        self.rgba = t(np_batch["rgba"].astype(np.int64), torch.int32) if "rgba" in np_batch else None
+        self.kp_rgba = t(np_batch["kp_rgba"].astype(np.int64), torch.int32) if "kp_rgba" in np_batch else None
+        self.labels = np.asarray(np_batch.get("labels", np.zeros(len(self.pt_off) - 1)), np.int32)
+        self.n_obj = len(self.pt_off) - 1
+
+
+class Recognizer:
+    def __init__(self, ctx, cfg: IsmConfig):
+        self.ctx, self.cfg = ctx, cfg
+        self.codebook = None
+
+    # -- ImplicitShapeModel::computeFeatures step f + removeNaNFeatures -------------------------------------
+    def compute_features(self, b: DeviceBatch, want_counts=False):
+        c, ctx = self.cfg, self.ctx
+        cell = max(c.radius, c.lrf_radius if c.feature != "FPFH" else c.radius) * 0.5
+        cloud = capi.Cloud(ctx, b.pt_off, b.x, b.y, b.z, b.nx, b.ny, b.nz, cell, rgba=b.rgba if c.feature == "CSHOT" else None)
+        lrf = capi.shot_lrf(ctx, cloud, b.kp_off, b.kx, b.ky, b.kz, c.lrf_radius)   # Features::operator() always computes LRFs
+        if c.feature == "SHOT":
+            desc, cnt = capi.shot352(ctx, cloud, b.kp_off, b.kx, b.ky, b.kz, lrf, c.radius, want_counts=True)
+        elif c.feature == "CSHOT":
+            desc, cnt = capi.cshot1344(ctx, cloud, b.kp_off, b.kx, b.ky, b.kz, b.kp_rgba, lrf, c.radius, want_counts=True)
+        else:
+            # FPFH ignores the frames for description, but keypoints with an invalid frame are still dropped first
+            desc, cnt = capi.fpfh33(ctx, cloud, b.kp_off, b.kx, b.ky, b.kz, c.radius, want_counts=True)
+        keep, desc, lrf, kx, ky, kz, src = capi.compact_features(ctx, b.kp_off, desc, lrf, b.kx, b.ky, b.kz)
+        out = dict(off=keep, desc=desc, lrf=lrf, kx=kx, ky=ky, kz=kz, src=src, cloud=cloud)
+        if want_counts:
+            out["counts"] = cnt
+        return out
+
+    # -- ImplicitShapeModel::train() with Clustering None / KNN K=1 / Uniform ranking ---------------------------
+    def train(self, batches, instance_ids=None):
+        """batches: iterable of DeviceBatch whose objects are ordered class-major (the reference iterates std::map by class)."""
+        import torch
+        c, ctx = self.cfg, self.ctx
+        descs, lrfs, kps, cls, inst, model, centers = [], [], [], [], [], [], []
+        obj_base = 0
+        for b in batches:
+            f = self.compute_features(b)
+            # AABB centre per object (BoundingBoxType "AABB"; MVBB is not built)
+            for o in range(b.n_obj):
+                s, e = int(b.pt_off[o]), int(b.pt_off[o + 1])
+                mn = torch.stack([b.x[s:e].min(), b.y[s:e].min(), b.z[s:e].min()])
+                mx = torch.stack([b.x[s:e].max(), b.y[s:e].max(), b.z[s:e].max()])
+                n = int(f["off"][o + 1] - f["off"][o])
+                centers.append(((mn + mx) * 0.5).expand(n, 3))
+                cls.append(np.full(n, b.labels[o], np.uint32))
+                inst.append(np.full(n, (instance_ids[obj_base + o] if instance_ids is not None else obj_base + o), np.uint32))
+                model.append(np.full(n, obj_base + o, np.uint32))
+            obj_base += b.n_obj
+            descs.append(f["desc"]); lrfs.append(f["lrf"]); kps.append(torch.stack([f["kx"], f["ky"], f["kz"]], 1))
+            ctx.sync()
+        desc = torch.cat(descs); lrf = torch.cat(lrfs); kp = torch.cat(kps); center = torch.cat(centers)
+        cls = np.concatenate(cls); inst = np.concatenate(inst); model = np.concatenate(model)
+        n = desc.shape[0]
+        # one codeword per training feature (clustering_none.cpp), dataset rows in feature order
+        words_h = desc.cpu().numpy()
+        ones = np.arange(n + 1, dtype=np.uint32)
+        cb0 = capi.Codebook(ctx, words_h, ones, np.zeros((n, 3), np.float32), cls, inst, c.n_classes, np.ones(c.n_classes, np.float32))
+        act, _ = capi.knn(ctx, cb0, c.metric, desc, 1)                    # Codebook::activate, activateKNN per training feature
+        act = act[:, 0].cpu().numpy()
+        cb0.close()
+        # vote = rotateInto(center - keyPos, LRF): rows of the frame are the axes (utils.cpp:154-165)
+        votes = torch.einsum("nij,nj->ni", lrf.view(-1, 3, 3), center - kp).cpu().numpy()
+        sigma = class_sigmas_numpy(c.metric, words_h, cls, model, act, c.n_classes)
+        # k = 1 clean-up: keep distributions with exactly one vote (codebook.cpp:201-224)
+        n_votes = np.bincount(act, minlength=n)
+        keep_words = np.nonzero(n_votes == 1)[0]
+        owner = np.full(n, -1, np.int64)
+        owner[act] = np.arange(n)                     # the single feature that activated each kept word
+        src = owner[keep_words]
+        if c.use_random_codebook and 0 < c.random_codebook_size < len(keep_words):
+            rng = np.random.default_rng(c.random_codebook_seed)
+            sel = np.sort(rng.choice(len(keep_words), c.random_codebook_size, replace=False))
+            keep_words, src = keep_words[sel], src[sel]
+        m = len(keep_words)
+        per_class = np.bincount(cls[src], minlength=c.n_classes).astype(np.float32)
+        self.cb_host = dict(words=words_h[keep_words], vote_offsets=np.arange(m + 1, dtype=np.uint32), vote_xyz=votes[src],
+                            vote_class=cls[src], vote_instance=inst[src], class_sigma=sigma,
+                            vote_class_weight=(1.0 / np.maximum(per_class, 1))[cls[src]].astype(np.float32),
+                            vote_weight=np.ones(m, np.float32), word_weight=np.ones(m, np.float32))
+        self.load_codebook(self.cb_host)
+        return self.cb_host
+
+    def load_codebook(self, cb):
+        if self.codebook is not None:
+            self.codebook.close()
+        self.cb_host = cb
+        self.codebook = capi.Codebook(self.ctx, cb["words"], cb["vote_offsets"], cb["vote_xyz"], cb["vote_class"], cb["vote_instance"],
+                                      self.cfg.n_classes, cb["class_sigma"], word_weight=cb.get("word_weight"),
+                                      vote_weight=cb.get("vote_weight"), vote_class_weight=cb.get("vote_class_weight"),
+                                      vote_bbox_quat=cb.get("vote_bbox_quat"), vote_bbox_size=cb.get("vote_bbox_size"))
+
+    # -- ImplicitShapeModel::detect() over a batch --------------------------------------------------------------
+    def detect(self, b: DeviceBatch, keep_intermediates=False):
+        c, ctx, cb = self.cfg, self.ctx, self.codebook
+        f = self.compute_features(b)
+        if c.use_distance_ratio and c.k == 1:
+            idx, dist = capi.knn_ratio(ctx, cb, c.metric, f["desc"], c.distance_ratio_threshold)
+        else:
+            idx, dist = capi.knn(ctx, cb, c.metric, f["desc"], c.k)
+        votes = capi.cast_votes(ctx, cb, c.weight_flags, f["lrf"], f["kx"], f["ky"], f["kz"], idx, dist)
+        slot_off = f["off"].astype(np.uint64) * (c.k * cb.max_votes)
+        mx = capi.find_maxima(ctx, slot_off.astype(np.uint32), votes, c.n_classes, c.bandwidth, c.threshold, c.max_iter,
+                              capi.KERNEL_GAUSSIAN if c.kernel == "Gaussian" else capi.KERNEL_UNIFORM,
+                              {"Average": capi.SUPPRESS_AVERAGE, "Suppress": capi.SUPPRESS_SUPPRESS}.get(c.maxima_suppression, capi.SUPPRESS_NONE),
+                              c.min_votes_threshold, c.min_threshold, c.best_k, c.max_maxima)
+        if keep_intermediates:
+            mx.update(features=f, idx=idx, dist=dist, votes=votes, slot_off=slot_off.astype(np.uint32))
+        else:
+            mx["_keep"] = (f, idx, dist, votes)   # outputs are produced asynchronously: keep inputs alive until the caller syncs
+        return mx
+
+
+def class_sigmas_numpy(metric, feats, feat_class, feat_model, activated, n_classes):
+    """per-class sigma of Codebook::activate step 1 (codebook/codebook.cpp:94-193), float32 accumulation."""
+    out = np.full(n_classes, np.nan, np.float32)
+    for c in range(n_classes):
+        ids = np.nonzero(feat_class == c)[0]
+        if len(ids) == 0:
+            continue
+        ids = ids[np.argsort(feat_model[ids], kind="stable")]
+        max_elements = int(np.sqrt(float(len(ids))))
+        words = activated[ids][:max_elements]
+        words = words[words >= 0]
+        models = feat_model[ids]
+        allf = []
+        for m in np.unique(models):           # ascending = visiting order
+            if len(allf) >= max_elements:
+                break
+            allf.extend(ids[models == m].tolist())
+        A = feats[np.asarray(allf, np.int64)].astype(np.float32)
+        B = feats[words].astype(np.float32)
+        if metric == capi.METRIC_L2SQ:
+            d = ((A[:, None, :] - B[None, :, :]) ** 2).sum(-1, dtype=np.float32)
+        else:
+            s = A[:, None, :] + B[None, :, :]
+            diff = A[:, None, :] - B[None, :, :]
+            d = np.where(s > 0, diff * diff / np.where(s > 0, s, 1), 0).sum(-1, dtype=np.float32)
+        d = d.reshape(-1).astype(np.float32)
+        num = d.size
+        mean = np.float32(d.sum(dtype=np.float32) / np.float32(num))
+        var = np.float32(((d - mean) ** 2).sum(dtype=np.float32))
+        out[c] = var / np.float32(num - 1) if num > 1 else np.float32(np.nan)
+    return out
