@@ -65,6 +65,9 @@ typedef struct ismhip_codebook ismhip_codebook;
 int  ismhip_abi_version(void);
 /* stream: a hipStream_t (as void*) the caller owns, or NULL to let the ctx create its own. */
 int  ismhip_ctx_create(int device, void* stream, ismhip_ctx** out);
+/* same, but every value of stream is taken literally: NULL is the device's default (null) stream. This is how a host
+ * that already owns a stream (e.g. torch.cuda.current_stream()) orders its own work with the library's. */
+int  ismhip_ctx_create_on_stream(int device, void* stream, ismhip_ctx** out);
 int  ismhip_ctx_destroy(ismhip_ctx* ctx);
 int  ismhip_sync(ismhip_ctx* ctx);
 const char* ismhip_last_error(const ismhip_ctx* ctx);

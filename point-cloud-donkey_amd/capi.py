@@ -19,7 +19,7 @@ SUPPRESS_AVERAGE, SUPPRESS_SUPPRESS, SUPPRESS_NONE = 0, 1, 2
 ERR_NODEVICE = -5
 
 EXPORTS = [
-    "ismhip_abi_version", "ismhip_ctx_create", "ismhip_ctx_destroy", "ismhip_sync", "ismhip_last_error",
+    "ismhip_abi_version", "ismhip_ctx_create", "ismhip_ctx_create_on_stream", "ismhip_ctx_destroy", "ismhip_sync", "ismhip_last_error",
     "ismhip_timers_enable", "ismhip_timers_reset", "ismhip_timer_get",
     "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids",
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
@@ -50,6 +50,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise IsmHipError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(make -C point-cloud-donkey_amd/csrc)")
+        # torch ships its own libamdhip64 (same SONAME as /opt/rocm's): import it FIRST so that the process holds exactly
+        # one HIP runtime and libismhip.so binds to the one that owns torch's device memory and streams.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.ismhip_last_error.restype = C.c_char_p
         L.ismhip_last_error.argtypes = [C.c_void_p]
@@ -77,9 +80,18 @@ def _u32(a):
 
 
 class Ctx:
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream="torch"):
+        """stream: "torch" = torch's current stream on the device (library work is then ordered with torch ops and
+        tensor.cpu() waits for it), None = a private non-blocking stream, or a raw hipStream_t value."""
         self._h = C.c_void_p()
-        rc = lib().ismhip_ctx_create(C.c_int(device), C.c_void_p(stream or 0), C.byref(self._h))
+        L = lib()
+        if stream is None:
+            rc = L.ismhip_ctx_create(C.c_int(device), C.c_void_p(0), C.byref(self._h))
+        else:
+            if stream == "torch":
+                import torch
+                stream = torch.cuda.current_stream(device).cuda_stream
+            rc = L.ismhip_ctx_create_on_stream(C.c_int(device), C.c_void_p(stream), C.byref(self._h))
         if rc != 0:
             raise IsmHipError(f"ismhip_ctx_create failed ({rc}); a gfx950 device is required, there is no CPU fallback")
         self.device = device

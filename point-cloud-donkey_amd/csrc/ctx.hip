@@ -41,7 +41,12 @@ extern "C" {
 
 int ismhip_abi_version(void) { return ISMHIP_ABI_VERSION; }
 
-int ismhip_ctx_create(int device, void* stream, ismhip_ctx** out) {
+static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out);
+
+int ismhip_ctx_create(int device, void* stream, ismhip_ctx** out) { return ctx_create_impl(device, stream, stream == nullptr, out); }
+int ismhip_ctx_create_on_stream(int device, void* stream, ismhip_ctx** out) { return ctx_create_impl(device, stream, false, out); }
+
+static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out) {
     if (!out) return ISMHIP_ERR_INVALID;
     *out = nullptr;
     int n = 0;
@@ -53,7 +58,7 @@ int ismhip_ctx_create(int device, void* stream, ismhip_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ISMHIP_ERR_NODEVICE;   // code objects are gfx950 only
     ismhip_ctx* ctx = new ismhip_ctx();
     ctx->device = device;
-    if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+    if (!own) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ISMHIP_ERR_HIP; }
         ctx->own_stream = true;
