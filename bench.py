@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py — objects/sec classified on the ModelNet10-like SHOT-352 workload (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the recognition hot path (grid -> LRF -> SHOT-352 -> NaN compaction -> exact kNN -> vote casting ->
+mean-shift maxima) over one batch of --batch synthetic objects per GPU, inputs already resident in HBM, followed by the
+path's one exchange: an all-gather of the per-object class-score records (RCCL). Per-GPU work is fixed (weak scaling);
+value = objects processed by all ranks / max-over-ranks time of the K timed steps.
+
+The JSON line also carries
+  roofline      : the dominant kernel (k_knn_l2_mfma, MFMA-bound): algorithmic flop per launch / mean launch time, measured
+                  with HIP events on the stream the kernel runs on (ismhip timers), vs the dense FP32-MFMA peak
+  roofline_shot : descriptor extraction (k_shot<false>, HBM-bound, gather model bytes of SURVEY.md §8d)
+  cpu_baseline  : the CPU oracle (kind "port": the reference itself cannot be built here) timed on this host's cores on a
+                  bounded sample of the same workload; checker/baseline only, never on the measured path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="objects per step per GPU")
+    ap.add_argument("--train-per-class", type=int, default=10, help="training objects per class (codebook ~ 1024 words each)")
+    ap.add_argument("--resident-batches", type=int, default=2, help="distinct input batches kept in HBM and cycled")
+    ap.add_argument("--cpu-objects", type=int, default=4, help="objects of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--keypoints", type=int, default=1024)
+    ap.add_argument("--classes", type=int, default=10)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; the hot path has no CPU fallback"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    pkg = ge.load_package()
+    capi, pipeline, synthetic, shard = pkg.capi, pkg.pipeline, pkg.synthetic, pkg.shard
+    ctx = capi.Ctx(local_rank)            # on torch's current stream
+    C = args.classes
+    cfg = pipeline.IsmConfig(feature="SHOT", radius=0.4, lrf_radius=0.3, distance="Euclidean", k=1, bandwidth=0.6,
+                             n_classes=C, max_maxima=16)
+    rec = pipeline.Recognizer(ctx, cfg)
+
+    # ---- model: codebook trained the reference's way from a subset of the synthetic training split (replicated per rank)
+    t0 = time.time()
+    n_train = args.train_per_class * C
+    train = synthetic.Dataset(C, n_train, split=0, n_points=args.points, n_keypoints=args.keypoints)
+    order = sorted(range(n_train), key=lambda i: (train.label(i), i))
+    tb = []
+    for s in range(0, n_train, 32):
+        tb.append(pipeline.DeviceBatch(train.batch(order[s:s + 32]), dev))
+    cb = rec.train(tb)
+    del tb
+    n_words = cb["words"].shape[0]
+    t_train = time.time() - t0
+
+    # ---- inputs: this rank's shard of the test split, resident in HBM before the clock starts
+    B = args.batch
+    test = synthetic.Dataset(C, 908, split=1, n_points=args.points, n_keypoints=args.keypoints)
+    n_res = max(1, args.resident_batches)
+    batches, batch_ids = [], []
+    for j in range(n_res):
+        ids = [((rank * n_res + j) * B + i) % 908 for i in range(B)]
+        batches.append(pipeline.DeviceBatch(test.batch(ids), dev))
+        batch_ids.append(torch.as_tensor(ids, device=dev))
+    torch.cuda.synchronize()
+
+    def step(i):
+        b = batches[i % n_res]
+        out = rec.detect(b)
+        recs = shard.pack_records(batch_ids[i % n_res], out["class_score"], B)
+        gathered = shard.all_gather_records(recs, world)
+        return out, gathered
+
+    correct = total = 0
+    for i in range(args.warmup):
+        out, g = step(i)
+    torch.cuda.synchronize()
+    ctx.timers_enable(True)
+    ctx.timers_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out, g = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- accuracy of the last gathered step (sanity, not part of the metric)
+    oi, best, _ = shard.unpack_records(g)
+    labels = torch.as_tensor([test.label(int(k)) for k in oi.tolist()], device=best.device)
+    correct, total = int((best == labels).sum().item()), int(len(oi))
+
+    # ---- per-kernel device time (HIP events on the ctx stream, timed region only)
+    tm = {n: ctx.timer(n) for n in ["grid", "lrf", "shot352", "knn", "knn_l2_mfma", "cast_votes", "maxima"]}
+    ctx.timers_enable(False)
+    nq_per_launch = None
+    roofline = roofline_shot = None
+    if tm["knn_l2_mfma"][1] > 0:
+        # features actually searched per launch (NaN rows removed) and neighbour visits come from one extra, untimed pass
+        b = batches[0]
+        f = rec.compute_features(b, want_counts=True)
+        nq_per_launch = int(f["off"][-1])
+        m_sum = int(f["counts"].to(torch.int64).sum().item())
+        nkp = int(b.kp_off[-1])
+        ms_knn = tm["knn_l2_mfma"][0] / tm["knn_l2_mfma"][1]
+        flop = 2.0 * nq_per_launch * n_words * cfg.dim
+        ach = flop / (ms_knn * 1e-3) / 1e12
+        roofline = {"kernel": "k_knn_l2_mfma", "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "flop_per_launch": flop, "ms_per_launch": round(ms_knn, 4)}
+        ms_shot = tm["shot352"][0] / max(1, tm["shot352"][1])
+        bytes_shot = m_sum * 24.0 + nkp * (12 + 36 + 352 * 4)
+        gbs = bytes_shot / (ms_shot * 1e-3) / 1e9
+        roofline_shot = {"kernel": "k_shot<false>", "bound": "hbm", "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_launch": bytes_shot,
+                         "ms_per_launch": round(ms_shot, 4), "mean_neighbours": round(m_sum / max(1, nkp), 1)}
+
+    # ---- CPU baseline: the oracle on a bounded sample (rank 0, N = 1 only)
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_objects > 0:
+        ora = ge.load_oracle()
+        nb = test.batch(list(range(args.cpu_objects)))
+        xyz, nrm, kp = nb["xyz"], nb["normals"], nb["kp"]
+        t0 = time.perf_counter()
+        lrf = ora.shot_lrf(nb["pt_off"], xyz[:, 0], xyz[:, 1], xyz[:, 2], nb["kp_off"], kp[:, 0], kp[:, 1], kp[:, 2], cfg.lrf_radius)
+        desc, _ = ora.shot352(nb["pt_off"], xyz[:, 0], xyz[:, 1], xyz[:, 2], nrm[:, 0], nrm[:, 1], nrm[:, 2], nb["kp_off"],
+                              kp[:, 0], kp[:, 1], kp[:, 2], lrf, cfg.radius)
+        ok = ~np.isnan(desc).any(1)
+        idx, dd = ora.knn(cfg.metric, cb["words"], desc[ok], 1)
+        votes = ora.cast_votes(cb, cfg.weight_flags, lrf[ok], kp[ok, 0], kp[ok, 1], kp[ok, 2], idx, dd)
+        keep_off = np.concatenate([[0], np.cumsum([ok[nb["kp_off"][o]:nb["kp_off"][o + 1]].sum() for o in range(args.cpu_objects)])])
+        ora.find_maxima(keep_off.astype(np.uint32), votes, C, cfg.bandwidth, max_maxima=cfg.max_maxima)
+        t_cpu = time.perf_counter() - t0
+        cpu = {"value": round(args.cpu_objects / t_cpu, 4), "unit": "objects/s", "cores": ora.get_num_threads(), "kind": "port",
+               "sample": f"{args.cpu_objects} objects of the same workload (oracle: SHOT LRF+SHOT-352+exact kNN over {n_words} words"
+                         f"+votes+mean-shift), {t_cpu:.1f} s, OpenMP over keypoints/queries as the reference"}
+
+    n_objects = B * args.steps * world
+    if rank == 0:
+        line = {
+            "metric": "objects/sec classified (ModelNet10-like, SHOT-352)", "value": round(n_objects / dt, 3), "unit": "objects/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: ModelNet10-like test objects, 16384 pts, 1024 uniform keypoints/object, SHOT-352 "
+                                   "(Radius 0.4, LRF 0.3), exact kNN K=1 squared-L2, mean-shift bandwidth 0.6",
+                       "objects_per_step_per_gpu": B, "points_per_object": args.points, "keypoints_per_object": args.keypoints,
+                       "classes": C, "codebook_words": int(n_words), "descriptor_dim": cfg.dim, "parallelism": f"objects sharded over {world} GPU(s), codebook replicated, 1 all-gather/step"},
+            "roofline": roofline, "roofline_shot": roofline_shot, "cpu_baseline": cpu,
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in tm.items()},
+            "accuracy_last_step": round(correct / max(1, total), 4), "train_seconds": round(t_train, 1),
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,3 +10,4 @@ The directory name contains a hyphen; load it with __graft_entry__.load_package(
 from . import capi  # noqa: F401
 from . import synthetic  # noqa: F401
 from . import pipeline  # noqa: F401
+from . import shard  # noqa: F401
