@@ -170,18 +170,38 @@ __global__ __launch_bounds__(256) void k_lrf_tie(CloudView cv, const float* __re
             }
         __threadfence_block();
         if (n > key_cap) n = key_cap;   // cannot happen: key_cap = largest object
+        // rank selection by bitwise bisection: the element of rank t is the largest v with #(key < v) <= t.
+        // Keys are (positive float bits << 32 | index < key_cap): only bits 62..32 and the low index bits can be set.
         const int median = (int)n / 2;
+        const int tsel = median - 2;
+        int idx_bits = 1; while ((1u << idx_bits) < key_cap) ++idx_bits;
+        unsigned long long sel = 0ull;
+        for (int bit = 62; bit >= 0; --bit) {
+            if (bit < 32 && bit >= idx_bits) continue;
+            const unsigned long long cand = sel | (1ull << bit);
+            int c = 0;
+            for (uint32_t i = lane; i < n; i += 64) c += mykeys[i] < cand;
+            c = wave_sum_i(c);
+            if (c <= tsel) sel = cand;
+        }
+        // sel = key of rank median-2; the next four follow by successive minima above the previous one
+        unsigned long long five[5];
+        five[0] = sel;
+        for (int j = 1; j < 5; ++j) {
+            unsigned long long mn = ~0ull;
+            for (uint32_t i = lane; i < n; i += 64) { const unsigned long long kk = mykeys[i]; if (kk > five[j - 1] && kk < mn) mn = kk; }
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) { const unsigned long long tt = __shfl_xor(mn, o2, 64); mn = tt < mn ? tt : mn; }
+            five[j] = mn;
+        }
         int cntx = 0, cntz = 0;
-        for (uint32_t i = lane; i < n; i += 64) {
-            const unsigned long long ki = mykeys[i];
-            int rank = 0;
-            for (uint32_t j = 0; j < n; ++j) rank += mykeys[j] < ki;
-            if (rank >= median - 2 && rank <= median + 2) {
-                const uint32_t orig = (uint32_t)(ki & 0xffffffffull);
-                const double vx = (double)(cv.x[base + orig] - cx), vy = (double)(cv.y[base + orig] - cy), vz = (double)(cv.z[base + orig] - cz);
-                if (vx * r.v1[0] + vy * r.v1[1] + vz * r.v1[2] > 0) cntx++;
-                if (vx * r.v3[0] + vy * r.v3[1] + vz * r.v3[2] > 0) cntz++;
-            }
+        if (lane < 5) {
+            unsigned long long ki = five[0];
+            if (lane == 1) ki = five[1]; else if (lane == 2) ki = five[2]; else if (lane == 3) ki = five[3]; else if (lane == 4) ki = five[4];
+            const uint32_t orig = (uint32_t)(ki & 0xffffffffull);
+            const double vx = (double)(cv.x[base + orig] - cx), vy = (double)(cv.y[base + orig] - cy), vz = (double)(cv.z[base + orig] - cz);
+            if (vx * r.v1[0] + vy * r.v1[1] + vz * r.v1[2] > 0) cntx++;
+            if (vx * r.v3[0] + vy * r.v3[1] + vz * r.v3[2] > 0) cntz++;
         }
         cntx = wave_sum_i(cntx); cntz = wave_sum_i(cntz);
         double v1[3] = {r.v1[0], r.v1[1], r.v1[2]}, v3[3] = {r.v3[0], r.v3[1], r.v3[2]};

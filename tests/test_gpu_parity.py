@@ -1,0 +1,404 @@
+"""GPU parity tests (-m gpu): the HIP path behind the C ABI against the CPU oracle on the same seeded inputs, against the
+hand-derived KATs, and through size-independent properties at BASELINE.json's full sizes.
+Tolerance (north_star): 1e-4 on descriptor vectors and vote weights; indices / labels bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_cloud
+
+pytestmark = pytest.mark.gpu
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+TOL = 1e-4
+
+
+def T(a, dev, dtype=None):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(dev)
+
+
+class Scene:
+    """several objects concatenated: numpy SoA + device tensors + a Cloud"""
+
+    def __init__(self, pkg, gpu, objs, kps, cell, rgba=None, kp_rgba=None):
+        import torch
+        self.ctx, self.dev = gpu
+        self.pt_off = np.concatenate([[0], np.cumsum([len(o[0]) for o in objs])]).astype(np.uint32)
+        self.kp_off = np.concatenate([[0], np.cumsum([len(k) for k in kps])]).astype(np.uint32)
+        cat = lambda parts, w: np.concatenate(parts).astype(np.float32).reshape(-1, w) if len(parts) else np.zeros((0, w), np.float32)
+        self.p = cat([o[0] for o in objs], 3); self.n = cat([o[1] for o in objs], 3); self.kp = cat(kps, 3)
+        self.rgba = None if rgba is None else np.concatenate(rgba).astype(np.uint32)
+        self.kp_rgba = None if kp_rgba is None else np.concatenate(kp_rgba).astype(np.uint32)
+        d = self.dev
+        self.t = [T(self.p[:, i], d) for i in range(3)] + [T(self.n[:, i], d) for i in range(3)]
+        self.tk = [T(self.kp[:, i], d) for i in range(3)]
+        self.t_rgba = None if self.rgba is None else T(self.rgba.astype(np.int64), d, torch.int32)
+        self.t_kp_rgba = None if self.kp_rgba is None else T(self.kp_rgba.astype(np.int64), d, torch.int32)
+        self.cloud = pkg.capi.Cloud(self.ctx, self.pt_off, *self.t, cell, rgba=self.t_rgba)
+
+    def soa(self):
+        return [self.p[:, i].copy() for i in range(3)], [self.n[:, i].copy() for i in range(3)], [self.kp[:, i].copy() for i in range(3)]
+
+
+def edge_scene(pkg, gpu, seed=0, with_color=False, cell=0.15):
+    """ragged batch: sphere, ellipsoid with NaN points, EMPTY object, tiny object (<5 points), noisy plane"""
+    rng = np.random.default_rng(seed)
+    o0 = make_cloud(rng, 3000, "sphere", noise=0.01)
+    o1 = list(make_cloud(rng, 2500, "ellipsoid"))
+    o1[0][::97] = np.nan                                    # non-finite points are dropped by the search surface
+    o2 = (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    o3 = make_cloud(rng, 4, "sphere")
+    o4 = make_cloud(rng, 2000, "plane", noise=0.02)
+    objs = [o0, tuple(o1), o2, o3, o4]
+    kps = []
+    for i, (p, _) in enumerate(objs):
+        if len(p) == 0:
+            kps.append(np.array([[0.1, 0.2, 0.3]], np.float32))        # a keypoint in an empty object
+            continue
+        ok = np.isfinite(p).all(1)
+        sel = p[ok][rng.choice(ok.sum(), min(40, ok.sum()), replace=False)]
+        k = sel * 0.98
+        k[0] = sel[0]                                                     # coincides with a surface point
+        k = np.concatenate([k, [[30.0, 0, 0]], [[np.nan, 0, 0]]]).astype(np.float32)   # far away / non-finite keypoint
+        kps.append(k)
+    rgba = kp_rgba = None
+    if with_color:
+        rgba = [rng.integers(0, 1 << 24, size=len(o[0])).astype(np.uint32) for o in objs]
+        kp_rgba = [rng.integers(0, 1 << 24, size=len(k)).astype(np.uint32) for k in kps]
+    return Scene(pkg, gpu, objs, kps, cell, rgba, kp_rgba)
+
+
+def assert_close_nan(a, b, atol):
+    assert a.shape == b.shape
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), f"NaN pattern differs: {na.sum()} vs {nb.sum()}"
+    if (~na).any():
+        assert np.abs(a[~na] - b[~nb]).max() <= atol, np.abs(a[~na] - b[~nb]).max()
+
+
+# ------------------------------------------------------------------------------------------------ LRF
+@pytest.mark.parametrize("radius", [0.3, 0.12])
+def test_lrf_matches_oracle(pkg, gpu, ora, radius):
+    s = edge_scene(pkg, gpu, 1)
+    ctx, dev = gpu
+    got = pkg.capi.shot_lrf(ctx, s.cloud, s.kp_off, *s.tk, radius).cpu().numpy()
+    (x, y, z), _, (kx, ky, kz) = s.soa()
+    want = ora.shot_lrf(s.pt_off, x, y, z, s.kp_off, kx, ky, kz, radius)
+    assert_close_nan(got, want, 1e-5)
+    assert np.isnan(want).any() and (~np.isnan(want)).any()
+
+
+def test_lrf_kat_and_forced_ties(pkg, gpu, ora):
+    ctx, dev = gpu
+    k = KAT["lrf_paraboloid"]
+    tie = np.array([[0.10, 0.01, 0.0], [0.12, -0.01, 0.001], [0.14, 0.0, -0.001],
+                    [-0.20, 0.01, 0.0], [-0.22, -0.01, 0.001], [-0.24, 0.0, -0.001]], np.float32)
+    rng = np.random.default_rng(3)
+    # symmetric clouds: many exact sign ties (mirror pairs) -> exercises k_lrf_tie
+    base = rng.normal(size=(400, 3)).astype(np.float32) * 0.2
+    sym = np.concatenate([base, -base]).astype(np.float32)
+    objs = [(np.asarray(k["points"], np.float32), np.zeros((len(k["points"]), 3), np.float32)), (tie, np.zeros((6, 3), np.float32)),
+            (sym, np.zeros((800, 3), np.float32))]
+    kps = [np.asarray([k["keypoint"]], np.float32), np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32)]
+    s = Scene(pkg, gpu, objs, kps, 0.25)
+    got = pkg.capi.shot_lrf(ctx, s.cloud, s.kp_off, *s.tk, 0.5).cpu().numpy()
+    np.testing.assert_allclose(got[0], np.asarray(k["expected"], np.float32), atol=k["tol"])
+    (x, y, z), _, (kx, ky, kz) = s.soa()
+    want = ora.shot_lrf(s.pt_off, x, y, z, s.kp_off, kx, ky, kz, 0.5)
+    assert_close_nan(got, want, 1e-5)
+    assert got[1, 0] < 0
+
+
+# ------------------------------------------------------------------------------------------------ descriptors
+def test_shot352_matches_oracle(pkg, gpu, ora):
+    s = edge_scene(pkg, gpu, 2)
+    ctx, dev = gpu
+    lrf = pkg.capi.shot_lrf(ctx, s.cloud, s.kp_off, *s.tk, 0.3)
+    got, cnt = pkg.capi.shot352(ctx, s.cloud, s.kp_off, *s.tk, lrf, 0.4, want_counts=True)
+    (x, y, z), (nx, ny, nz), (kx, ky, kz) = s.soa()
+    want, wcnt = ora.shot352(s.pt_off, x, y, z, nx, ny, nz, s.kp_off, kx, ky, kz, lrf.cpu().numpy(), 0.4)
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), wcnt)
+    assert_close_nan(got.cpu().numpy(), want, TOL)
+    fin = ~np.isnan(want[:, 0])
+    np.testing.assert_allclose(np.linalg.norm(got.cpu().numpy()[fin], axis=1), 1.0, atol=1e-5)
+
+
+def test_shot352_kat(pkg, gpu):
+    ctx, dev = gpu
+    k = KAT["shot_sector_centres"]
+    s = Scene(pkg, gpu, [(np.asarray(k["points"], np.float32), np.asarray(k["normals"], np.float32))], [np.asarray([k["keypoint"]], np.float32)], 0.5)
+    got = pkg.capi.shot352(ctx, s.cloud, s.kp_off, *s.tk, T(np.asarray([k["lrf"]], np.float32), dev), k["radius"]).cpu().numpy()
+    np.testing.assert_allclose(got[0], np.asarray(k["expected"], np.float32), atol=5e-6)
+
+
+def test_cshot1344_matches_oracle(pkg, gpu, ora):
+    s = edge_scene(pkg, gpu, 4, with_color=True)
+    ctx, dev = gpu
+    lrf = pkg.capi.shot_lrf(ctx, s.cloud, s.kp_off, *s.tk, 0.3)
+    got, cnt = pkg.capi.cshot1344(ctx, s.cloud, s.kp_off, *s.tk, s.t_kp_rgba, lrf, 0.35, want_counts=True)
+    (x, y, z), (nx, ny, nz), (kx, ky, kz) = s.soa()
+    want, wcnt = ora.cshot1344(s.pt_off, x, y, z, nx, ny, nz, s.rgba, s.kp_off, kx, ky, kz, s.kp_rgba, lrf.cpu().numpy(), 0.35)
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), wcnt)
+    assert_close_nan(got.cpu().numpy(), want, TOL)
+
+
+def test_fpfh33_matches_oracle(pkg, gpu, ora):
+    s = edge_scene(pkg, gpu, 5, cell=0.1)
+    ctx, dev = gpu
+    got, cnt = pkg.capi.fpfh33(ctx, s.cloud, s.kp_off, *s.tk, 0.2, want_counts=True)
+    (x, y, z), (nx, ny, nz), (kx, ky, kz) = s.soa()
+    want, wcnt = ora.fpfh33(s.pt_off, x, y, z, nx, ny, nz, s.kp_off, kx, ky, kz, 0.2)
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), wcnt)
+    # FPFH lives on a 0..100 scale: 1e-4 relative to the scale
+    assert_close_nan(got.cpu().numpy(), want, 100 * TOL)
+
+
+def test_fpfh33_kat(pkg, gpu):
+    ctx, dev = gpu
+    k = KAT["fpfh_two_points"]
+    s = Scene(pkg, gpu, [(np.asarray(k["points"], np.float32), np.asarray(k["normals"], np.float32))], [np.asarray([k["keypoint"]], np.float32)], 0.25)
+    got = pkg.capi.fpfh33(ctx, s.cloud, s.kp_off, *s.tk, k["radius"]).cpu().numpy()
+    np.testing.assert_allclose(got[0], np.asarray(k["expected"], np.float32), atol=1e-3)
+
+
+def test_centroids_and_center_dist(pkg, gpu, ora):
+    s = edge_scene(pkg, gpu, 6)
+    ctx, dev = gpu
+    (x, y, z), _, (kx, ky, kz) = s.soa()
+    np.testing.assert_allclose(pkg.capi.cloud_centroids(ctx, s.cloud, dev).cpu().numpy(), ora.centroids(s.pt_off, x, y, z), atol=1e-6)
+    got = pkg.capi.center_dist(ctx, s.cloud, s.kp_off, *s.tk).cpu().numpy()
+    want = ora.center_dist(s.pt_off, x, y, z, s.kp_off, kx, ky, kz)
+    assert_close_nan(got, want, 1e-5)
+
+
+def test_compact_features(pkg, gpu):
+    import torch
+    ctx, dev = gpu
+    rng = np.random.default_rng(7)
+    kp_off = np.array([0, 5, 5, 12, 20], np.uint32)
+    desc = rng.random((20, 33)).astype(np.float32)
+    lrf = rng.random((20, 9)).astype(np.float32)
+    desc[[1, 7, 19], 3] = np.nan
+    lrf[[2, 7], 0] = np.nan
+    kp = rng.random((20, 3)).astype(np.float32)
+    keep, d, l, x, y, z, src = pkg.capi.compact_features(ctx, kp_off, T(desc, dev), T(lrf, dev), T(kp[:, 0], dev), T(kp[:, 1], dev), T(kp[:, 2], dev))
+    good = np.array([i for i in range(20) if i not in (1, 2, 7, 19)])
+    assert keep.tolist() == [0, 3, 3, 9, 16]
+    assert np.array_equal(src.cpu().numpy(), good)
+    np.testing.assert_array_equal(d.cpu().numpy(), desc[good]); np.testing.assert_array_equal(l.cpu().numpy(), lrf[good])
+    np.testing.assert_array_equal(y.cpu().numpy(), kp[good, 1])
+
+
+# ------------------------------------------------------------------------------------------------ kNN
+def _cb(pkg, gpu, words, n_classes=4, votes_per_word=1, seed=0):
+    rng = np.random.default_rng(seed)
+    n = len(words)
+    off = np.arange(n + 1, dtype=np.uint32) * votes_per_word
+    nv = int(off[-1])
+    host = dict(words=np.asarray(words, np.float32), vote_offsets=off, vote_xyz=rng.normal(size=(nv, 3)).astype(np.float32),
+                vote_class=rng.integers(0, n_classes, nv).astype(np.uint32), vote_instance=rng.integers(0, 9, nv).astype(np.uint32),
+                class_sigma=rng.uniform(0.2, 2.0, n_classes).astype(np.float32), word_weight=rng.uniform(0.5, 1.5, n).astype(np.float32),
+                vote_weight=rng.uniform(0.5, 1.5, nv).astype(np.float32), vote_class_weight=rng.uniform(0.1, 1, nv).astype(np.float32),
+                vote_bbox_quat=rng.normal(size=(nv, 4)).astype(np.float32), vote_bbox_size=rng.uniform(0.1, 1, (nv, 3)).astype(np.float32))
+    ctx, dev = gpu
+    dev_cb = pkg.capi.Codebook(ctx, host["words"], off, host["vote_xyz"], host["vote_class"], host["vote_instance"], n_classes,
+                               host["class_sigma"], word_weight=host["word_weight"], vote_weight=host["vote_weight"],
+                               vote_class_weight=host["vote_class_weight"], vote_bbox_quat=host["vote_bbox_quat"],
+                               vote_bbox_size=host["vote_bbox_size"])
+    return host, dev_cb
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("shape", [(1000, 352, 777), (130, 33, 65), (5000, 1344, 300), (3, 16, 10)])
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_knn_matches_oracle(pkg, gpu, ora, metric, shape, k):
+    ctx, dev = gpu
+    n_words, dim, nq = shape
+    rng = np.random.default_rng(n_words + dim + k)
+    words = rng.random((n_words, dim)).astype(np.float32)
+    words /= np.linalg.norm(words, axis=1, keepdims=True)
+    q = rng.random((nq, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[: min(5, n_words, nq)] = words[: min(5, n_words, nq)]               # exact hits: distance 0
+    host, cb = _cb(pkg, gpu, words)
+    idx, dist = pkg.capi.knn(ctx, cb, metric, T(q, dev), k)
+    widx, wdist = ora.knn(metric, words, q, k)
+    assert np.array_equal(idx.cpu().numpy(), widx)                           # bit-exact indices
+    got = dist.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(wdist))
+    assert np.array_equal(got[~np.isnan(got)], wdist[~np.isnan(wdist)])    # same functor, same summation order: bit-exact
+
+
+def test_knn_ties_kat_and_ratio(pkg, gpu, ora):
+    ctx, dev = gpu
+    k = KAT["knn_ties"]
+    host, cb = _cb(pkg, gpu, k["words"])
+    idx, dist = pkg.capi.knn(ctx, cb, 0, T(np.asarray(k["q"], np.float32), dev), k["k"])
+    assert idx.cpu().numpy().tolist() == k["expected_idx"]
+    np.testing.assert_allclose(dist.cpu().numpy(), k["expected_l2"], atol=1e-6)
+    rng = np.random.default_rng(11)
+    words = rng.random((500, 64)).astype(np.float32)
+    q = words[:100] + 0.05 * rng.random((100, 64)).astype(np.float32)
+    q[50:] = rng.random((50, 64)).astype(np.float32)
+    host, cb = _cb(pkg, gpu, words)
+    for metric in (0, 1):
+        gi, gd = pkg.capi.knn_ratio(ctx, cb, metric, T(q, dev), 0.8)
+        wi, wd = ora.knn_ratio(metric, words, q, 0.8)
+        assert np.array_equal(gi.cpu().numpy(), wi) and (wi == -1).any() and (wi >= 0).any()
+        assert np.array_equal(gd.cpu().numpy(), wd)
+
+
+# ------------------------------------------------------------------------------------------------ votes + maxima
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 8, 15])
+def test_cast_votes_matches_oracle(pkg, gpu, ora, flags):
+    ctx, dev = gpu
+    rng = np.random.default_rng(20 + flags)
+    words = rng.random((200, 32)).astype(np.float32)
+    host, cb = _cb(pkg, gpu, words, votes_per_word=3, seed=flags)
+    nq, k = 300, 2
+    q = rng.random((nq, 32)).astype(np.float32)
+    idx, dist = ora.knn(0, words, q, k)
+    idx[::17, 1] = -1
+    A = rng.normal(size=(nq, 3, 3)); Qm, _ = np.linalg.qr(A)
+    Qm[np.linalg.det(Qm) < 0, 2] *= -1
+    lrf = Qm.reshape(nq, 9).astype(np.float32)
+    kp = rng.normal(size=(nq, 3)).astype(np.float32)
+    got = pkg.capi.cast_votes(ctx, cb, flags, T(lrf, dev), T(kp[:, 0], dev), T(kp[:, 1], dev), T(kp[:, 2], dev), T(idx, dev), T(dist, dev), want_bbox=True)
+    want = ora.cast_votes(host, flags, lrf, kp[:, 0], kp[:, 1], kp[:, 2], idx, dist)
+    for key in ("cls", "inst", "codeword"):
+        assert np.array_equal(got[key].cpu().numpy(), want[key]), key
+    assert (want["cls"] >= 0).any() and (want["cls"] < 0).any()
+    for key in ("pos", "weight", "bbox_quat", "bbox_size"):
+        np.testing.assert_allclose(got[key].cpu().numpy(), want[key], atol=1e-5, rtol=1e-5, err_msg=key)
+
+
+def _vote_scene(rng, n_obj, n_classes, with_empty=True):
+    pos, w, cls, inst, bs, off = [], [], [], [], [], [0]
+    for o in range(n_obj):
+        if with_empty and o == 1:
+            off.append(off[-1]); continue
+        n_blobs = rng.integers(1, 4)
+        for b in range(n_blobs):
+            c = rng.integers(0, n_classes)
+            m = rng.integers(5, 120)
+            centre = rng.uniform(-2, 2, 3)
+            pos.append(centre + 0.15 * rng.normal(size=(m, 3))); w.append(rng.uniform(0.2, 1.0, m))
+            cls.append(np.full(m, c)); inst.append(rng.integers(0, 4, m)); bs.append(rng.uniform(0.5, 1.5, (m, 3)))
+        m = rng.integers(0, 40)                                   # clutter + slots without a vote
+        pos.append(rng.uniform(-3, 3, (m, 3))); w.append(rng.uniform(0.2, 1.0, m)); cls.append(rng.integers(-1, n_classes, m))
+        inst.append(rng.integers(0, 4, m)); bs.append(rng.uniform(0.5, 1.5, (m, 3)))
+        off.append(off[-1] + sum(len(x) for x in pos) - off[-1])
+    v = dict(pos=np.concatenate(pos).astype(np.float32), weight=np.concatenate(w).astype(np.float32), cls=np.concatenate(cls).astype(np.int32),
+             inst=np.concatenate(inst).astype(np.int32), bbox_size=np.concatenate(bs).astype(np.float32))
+    # shuffle inside every object so that classes interleave like real vote slots
+    for o in range(n_obj):
+        s, e = off[o], off[o + 1]
+        p = s + rng.permutation(e - s)
+        for key in v:
+            v[key][s:e] = v[key][p]
+    return np.asarray(off, np.uint32), v
+
+
+@pytest.mark.parametrize("suppression,kernel", [(0, 0), (1, 0), (0, 1)])
+def test_find_maxima_matches_oracle(pkg, gpu, ora, suppression, kernel):
+    import torch
+    ctx, dev = gpu
+    rng = np.random.default_rng(30 + suppression + 2 * kernel)
+    off, v = _vote_scene(rng, 12, 5)
+    tv = {k2: T(a, dev) for k2, a in v.items()}
+    kw = dict(n_classes=5, bandwidth=0.5, suppression=suppression, kernel=kernel, max_maxima=12, min_votes_threshold=2)
+    got = pkg.capi.find_maxima(ctx, off, tv, **kw)
+    want = ora.find_maxima(off, v, **kw)
+    assert np.array_equal(got["n"].cpu().numpy(), want["n"])
+    assert np.array_equal(got["cls"].cpu().numpy(), want["cls"])
+    assert np.array_equal(got["inst"].cpu().numpy(), want["inst"])
+    assert np.array_equal(got["n_votes"].cpu().numpy(), want["n_votes"])
+    np.testing.assert_allclose(got["weight"].cpu().numpy(), want["weight"], atol=TOL)
+    np.testing.assert_allclose(got["inst_weight"].cpu().numpy(), want["inst_weight"], atol=TOL)
+    np.testing.assert_allclose(got["pos"].cpu().numpy(), want["pos"], atol=2e-3)          # mean-shift stops at Threshold = 1e-3
+    np.testing.assert_allclose(got["bbox_size"].cpu().numpy(), want["bbox_size"], atol=1e-3)
+    np.testing.assert_allclose(got["class_score"].cpu().numpy(), want["class_score"], atol=TOL)
+    assert want["n"][1] == 0 and want["n"].max() >= 2
+
+
+def test_find_maxima_two_blobs_property(pkg, gpu):
+    ctx, dev = gpu
+    rng = np.random.default_rng(40)
+    centres = np.array([[0.0, 0, 0], [3.0, 0, 0]])
+    pos = np.concatenate([c + 0.05 * rng.normal(size=(60, 3)) for c in centres]).astype(np.float32)
+    v = dict(pos=T(pos, dev), weight=T(np.ones(120, np.float32), dev), cls=T(np.full(120, 1, np.int32), dev), inst=T(np.zeros(120, np.int32), dev))
+    out = pkg.capi.find_maxima(ctx, [0, 120], v, n_classes=3, bandwidth=0.5, max_maxima=8)
+    assert int(out["n"][0]) == 2
+    p = out["pos"][0, :2].cpu().numpy(); p = p[np.argsort(p[:, 0])]
+    np.testing.assert_allclose(p, centres, atol=0.03)
+    assert abs(float(out["weight"][0, :2].sum()) - 1) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ end to end, full sizes
+def test_end_to_end_full_size_properties_and_oracle_sample(pkg, gpu, ora):
+    """BASELINE configs[1] sizes (16384 points, 1024 keypoints): properties on all objects, oracle comparison on one."""
+    import torch
+    ctx, dev = gpu
+    capi, pipeline, synthetic = pkg.capi, pkg.pipeline, pkg.synthetic
+    cfg = pipeline.IsmConfig(n_classes=4)
+    train = synthetic.Dataset(4, 8, split=0)
+    test = synthetic.Dataset(4, 4, split=1)
+    rec = pipeline.Recognizer(ctx, cfg)
+    order = sorted(range(8), key=lambda i: (train.label(i), i))
+    cb = rec.train([pipeline.DeviceBatch(train.batch(order), dev)])
+    nb = test.batch(range(4))
+    out = rec.detect(pipeline.DeviceBatch(nb, dev), keep_intermediates=True)
+    f = out["features"]
+    desc = f["desc"].cpu().numpy()
+    np.testing.assert_allclose(np.linalg.norm(desc, axis=1), 1.0, atol=1e-5)               # L2-normalised
+    assert desc.min() >= 0
+    R = f["lrf"].cpu().numpy().reshape(-1, 3, 3)
+    np.testing.assert_allclose(R @ R.transpose(0, 2, 1), np.tile(np.eye(3), (len(R), 1, 1)), atol=5e-6)
+    np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=1e-5)
+    # training features are their own nearest codeword at distance 0 (self query)
+    self_idx, self_d = capi.knn(ctx, rec.codebook, cfg.metric, T(cb["words"][:2000], dev), 1)
+    assert np.array_equal(self_idx.cpu().numpy()[:, 0], np.arange(2000)) and float(self_d.max()) == 0.0
+    assert (out["cls"][:, 0].cpu().numpy() == nb["labels"]).all()
+    s = out["class_score"].cpu().numpy()
+    assert (s >= 0).all() and (s.sum(1) <= 1 + 1e-5).all()
+    # oracle on object 0 only (full size)
+    o = 0
+    ps, pe, ks, ke = nb["pt_off"][o], nb["pt_off"][o + 1], nb["kp_off"][o], nb["kp_off"][o + 1]
+    xyz, nrm, kp = nb["xyz"][ps:pe], nb["normals"][ps:pe], nb["kp"][ks:ke]
+    lrf = ora.shot_lrf([0, pe - ps], xyz[:, 0], xyz[:, 1], xyz[:, 2], [0, ke - ks], kp[:, 0], kp[:, 1], kp[:, 2], cfg.lrf_radius)
+    wdesc, _ = ora.shot352([0, pe - ps], xyz[:, 0], xyz[:, 1], xyz[:, 2], nrm[:, 0], nrm[:, 1], nrm[:, 2], [0, ke - ks], kp[:, 0], kp[:, 1], kp[:, 2], lrf, cfg.radius)
+    ok = ~np.isnan(wdesc).any(1)
+    n0 = int(f["off"][1])
+    assert n0 == ok.sum()
+    assert np.abs(desc[:n0] - wdesc[ok]).max() < TOL
+    widx, wd = ora.knn(cfg.metric, cb["words"], wdesc[ok], 1)
+    gidx = out["idx"].cpu().numpy()[:n0]
+    same = gidx[:, 0] == widx[:, 0]
+    # the descriptors agree to ~1e-7, so a different winner is only possible on a near tie of the two best distances
+    if not same.all():
+        _, d2 = ora.knn(cfg.metric, cb["words"], wdesc[ok][~same], 2)
+        assert ((d2[:, 1] - d2[:, 0]) < 1e-5).all()
+    votes = ora.cast_votes(cb, cfg.weight_flags, lrf[ok], kp[ok, 0], kp[ok, 1], kp[ok, 2], gidx, out["dist"].cpu().numpy()[:n0])
+    mx = ora.find_maxima([0, n0], votes, cfg.n_classes, cfg.bandwidth, max_maxima=cfg.max_maxima)
+    n = int(mx["n"][0])
+    assert n == int(out["n"][0])
+    assert np.array_equal(mx["cls"][0, :n], out["cls"][0, :n].cpu().numpy())
+    np.testing.assert_allclose(mx["weight"][0, :n], out["weight"][0, :n].cpu().numpy(), atol=TOL)
+    np.testing.assert_allclose(mx["pos"][0, :n], out["pos"][0, :n].cpu().numpy(), atol=2e-3)
+
+
+def test_errors_are_loud(pkg, gpu):
+    import ctypes as C
+    ctx, dev = gpu
+    L = pkg.capi.lib()
+    h = C.c_void_p()
+    assert L.ismhip_cloud_create(ctx._h, 0, None, None, None, None, None, None, None, None, C.c_float(0.1), C.byref(h)) == -1
+    assert b"cloud_create" in L.ismhip_last_error(ctx._h)
+    with pytest.raises(pkg.capi.IsmHipError):
+        pkg.capi.Ctx(99)
+    words = np.eye(8, dtype=np.float32)
+    _, cb = _cb(pkg, gpu, words)
+    with pytest.raises(pkg.capi.IsmHipError):
+        pkg.capi.knn(ctx, cb, 0, T(words, dev), 5)          # k > 4 is not built -> ISMHIP_ERR_UNSUPPORTED, not a silent fallback
