@@ -92,6 +92,8 @@ class Ctx:
                 import torch
                 if not torch.cuda.is_available():
                     raise IsmHipError("no gfx950 device visible: the hot path has no CPU fallback (ISMHIP_ERR_NODEVICE)")
+                if not (0 <= device < torch.cuda.device_count()):
+                    raise IsmHipError(f"device {device} out of range (ISMHIP_ERR_INVALID)")
                 stream = torch.cuda.current_stream(device).cuda_stream
             rc = L.ismhip_ctx_create_on_stream(C.c_int(device), C.c_void_p(stream), C.byref(self._h))
         if rc != 0:

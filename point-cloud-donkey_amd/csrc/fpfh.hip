@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
     if (p >= n || !a.flag[base + p]) return;
     unsigned int* hist = s_hist[wv];
     if (lane < 36) hist[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
     const float px = a.sx[base + p], py = a.sy[base + p], pz = a.sz[base + p];
     const float pnx = a.snx[base + p], pny = a.sny[base + p], pnz = a.snz[base + p];
     const GridMeta m = a.meta[o];
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
         }
     total = (uint32_t)wave_sum_i((int)total);
     const float hist_incr = 100.0f / (float)(total - 1u);
-    if (lane < 33) a.spfh[(size_t)(base + p) * 33 + lane] = (float)hist[lane] * hist_incr;
+    // a bin that received nothing stays 0 even when hist_incr = 100/0 (point alone in its ball), as in the reference's += loop
+    if (lane < 33) a.spfh[(size_t)(base + p) * 33 + lane] = hist[lane] ? (float)hist[lane] * hist_incr : 0.f;
 }
 
 __global__ __launch_bounds__(256) void k_fpfh_sum(FpfhArgs a) {

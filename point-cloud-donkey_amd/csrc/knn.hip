@@ -21,6 +21,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define KNN_BM 128       // codeword rows per tile
 #define KNN_BN 128       // queries per tile
@@ -96,15 +97,15 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-        float4 ga[4], gb[4];
+        f32x4 ga[4], gb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ga[i] = *(const float4*)(abase[i]); gb[i] = *(const float4*)(qbase[i]); }
+        for (int i = 0; i < 4; ++i) { ga[i] = *(const f32x4*)(abase[i]); gb[i] = *(const f32x4*)(qbase[i]); }
         __syncthreads();                                   // previous tile's epilogue has finished reading sCn / LDS
         if (tid < KNN_BM) sCn[tid] = word_norm[mt * KNN_BM + tid];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(float4*)(&sA[0][(srow + 32 * i) * KNN_LDK + scol]) = ga[i];
-            *(float4*)(&sB[0][(srow + 32 * i) * KNN_LDK + scol]) = gb[i];
+            *(f32x4*)(&sA[0][(srow + 32 * i) * KNN_LDK + scol]) = ga[i];
+            *(f32x4*)(&sB[0][(srow + 32 * i) * KNN_LDK + scol]) = gb[i];
         }
         __syncthreads();
 
@@ -113,43 +114,39 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
             if (kc + 1 < nk) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    ga[i] = *(const float4*)(abase[i] + (kc + 1) * KNN_BK);
-                    gb[i] = *(const float4*)(qbase[i] + (kc + 1) * KNN_BK);
+                    ga[i] = *(const f32x4*)(abase[i] + (kc + 1) * KNN_BK);
+                    gb[i] = *(const f32x4*)(qbase[i] + (kc + 1) * KNN_BK);
                 }
             }
             // operand fragments: lane half h owns k = 16h .. 16h+15 of the slice (any pairing of k is valid as long as
             // A and B agree); step s of the 32x32x2 MFMA consumes element s of both halves.
-            float fa[2][16], fb[2][16];
+            f32x4 fa[2][4], fb[2][4];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const float* p = &sA[cur][(wr * 64 + mi * 32 + r) * KNN_LDK + h * 16];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float4 t4 = *(const float4*)(p + v * 4);
-                    fa[mi][v * 4 + 0] = t4.x; fa[mi][v * 4 + 1] = t4.y; fa[mi][v * 4 + 2] = t4.z; fa[mi][v * 4 + 3] = t4.w;
-                }
+                for (int v = 0; v < 4; ++v) fa[mi][v] = *(const f32x4*)(p + v * 4);
             }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const float* p = &sB[cur][(wc * 64 + ni * 32 + r) * KNN_LDK + h * 16];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float4 t4 = *(const float4*)(p + v * 4);
-                    fb[ni][v * 4 + 0] = t4.x; fb[ni][v * 4 + 1] = t4.y; fb[ni][v * 4 + 2] = t4.z; fb[ni][v * 4 + 3] = t4.w;
-                }
+                for (int v = 0; v < 4; ++v) fb[ni][v] = *(const f32x4*)(p + v * 4);
             }
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
+            for (int v = 0; v < 4; ++v)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][s], fb[ni][s], acc[mi][ni], 0, 0, 0);
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][v][e], fb[ni][v][e], acc[mi][ni], 0, 0, 0);
             if (kc + 1 < nk) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    *(float4*)(&sA[cur ^ 1][(srow + 32 * i) * KNN_LDK + scol]) = ga[i];
-                    *(float4*)(&sB[cur ^ 1][(srow + 32 * i) * KNN_LDK + scol]) = gb[i];
+                    *(f32x4*)(&sA[cur ^ 1][(srow + 32 * i) * KNN_LDK + scol]) = ga[i];
+                    *(f32x4*)(&sB[cur ^ 1][(srow + 32 * i) * KNN_LDK + scol]) = gb[i];
                 }
             }
             __syncthreads();
