@@ -1,0 +1,80 @@
+// capi_host.cpp — small C shim over the C++ host classes so that the Python test-suite can drive ImplicitShapeModel
+// (train / write / read / detectBatch) through ctypes. Not part of the drop-in boundary (that is include/ismhip.h).
+#include <cstring>
+#include <string>
+
+#include "ism3d.h"
+
+using namespace ism3d;
+
+static thread_local std::string g_err;
+static PointCloud makeCloud(int n, const float* x, const float* y, const float* z, const float* nx, const float* ny, const float* nz, const uint32_t* rgba) {
+    PointCloud c;
+    c.x.assign(x, x + n); c.y.assign(y, y + n); c.z.assign(z, z + n); c.nx.assign(nx, nx + n); c.ny.assign(ny, ny + n); c.nz.assign(nz, nz + n);
+    if (rgba) c.rgba.assign(rgba, rgba + n);
+    return c;
+}
+#define GUARD(...) try { __VA_ARGS__ } catch (const std::exception& e) { g_err = e.what(); return -1; }
+
+extern "C" {
+const char* ism3d_last_error() { return g_err.c_str(); }
+void* ism3d_new() { return new ImplicitShapeModel(); }
+void ism3d_delete(void* m) { delete (ImplicitShapeModel*)m; }
+int ism3d_set_logging(void* m, int on) { ((ImplicitShapeModel*)m)->setLogging(on != 0); return 0; }
+int ism3d_read(void* m, const char* file, int training) { GUARD(return ((ImplicitShapeModel*)m)->readObject(file, training != 0) ? 0 : -2;) }
+int ism3d_write(void* m, const char* file) { GUARD(return ((ImplicitShapeModel*)m)->writeObject(file) ? 0 : -2;) }
+int ism3d_config_from_json(void* m, const char* text) { GUARD(Json j = Json::parse(text); return ((ImplicitShapeModel*)m)->configFromJson(j) ? 0 : -2;) }
+int ism3d_config_to_json(void* m, char* out, int cap) {
+    GUARD(std::string s = ((ImplicitShapeModel*)m)->configToJson().dump(1); if ((int)s.size() + 1 > cap) return (int)s.size() + 1; std::memcpy(out, s.c_str(), s.size() + 1); return 0;)
+}
+int ism3d_add_training(void* m, int n, const float* x, const float* y, const float* z, const float* nx, const float* ny, const float* nz,
+                       const uint32_t* rgba, unsigned class_id, unsigned instance_id) {
+    GUARD(return ((ImplicitShapeModel*)m)->addTrainingModel(makeCloud(n, x, y, z, nx, ny, nz, rgba), class_id, instance_id) ? 0 : -2;)
+}
+int ism3d_add_training_file(void* m, const char* file, unsigned class_id, unsigned instance_id) {
+    GUARD(return ((ImplicitShapeModel*)m)->addTrainingModel(std::string(file), class_id, instance_id) ? 0 : -2;)
+}
+int ism3d_train(void* m) { GUARD(((ImplicitShapeModel*)m)->train(); return 0;) }
+int ism3d_codebook_size(void* m) { return ((ImplicitShapeModel*)m)->getCodebook()->getSize(); }
+int ism3d_num_classes(void* m) { return ((ImplicitShapeModel*)m)->numClasses(); }
+// copies the codebook tables out (for cross-checks against the Python harness); pass NULL to query sizes
+int ism3d_codebook_get(void* m, float* words, float* vote_xyz, uint32_t* vote_class, float* class_sigma) {
+    const CodebookData& d = ((ImplicitShapeModel*)m)->getCodebook()->data();
+    if (words) std::memcpy(words, d.words.data(), d.words.size() * 4);
+    if (vote_xyz) std::memcpy(vote_xyz, d.vote_xyz.data(), d.vote_xyz.size() * 4);
+    if (vote_class) std::memcpy(vote_class, d.vote_class.data(), d.vote_class.size() * 4);
+    if (class_sigma) std::memcpy(class_sigma, d.class_sigma.data(), d.class_sigma.size() * 4);
+    return (int)d.vote_class.size();
+}
+// detectBatch over concatenated SoA arrays; outputs per object up to max_maxima records sorted by weight
+int ism3d_detect_batch(void* m, int n_obj, const uint32_t* pt_off, const float* x, const float* y, const float* z, const float* nx, const float* ny,
+                       const float* nz, const uint32_t* rgba, int max_maxima, int32_t* n_out, float* pos_out, float* weight_out, int32_t* cls_out,
+                       int32_t* inst_out, int32_t* nvotes_out) {
+    GUARD(
+        std::vector<PointCloud> clouds(n_obj);
+        std::vector<const PointCloud*> ptrs;
+        for (int o = 0; o < n_obj; ++o) {
+            const uint32_t s = pt_off[o]; const int n = (int)(pt_off[o + 1] - s);
+            clouds[o] = makeCloud(n, x + s, y + s, z + s, nx + s, ny + s, nz + s, rgba ? rgba + s : nullptr);
+            ptrs.push_back(&clouds[o]);
+        }
+        auto res = ((ImplicitShapeModel*)m)->detectBatch(ptrs);
+        for (int o = 0; o < n_obj; ++o) {
+            const int nm = std::min((int)res[o].size(), max_maxima);
+            n_out[o] = nm;
+            for (int i = 0; i < max_maxima; ++i) {
+                const size_t t = (size_t)o * max_maxima + i;
+                const bool ok = i < nm;
+                pos_out[t * 3] = ok ? res[o][i].position[0] : 0; pos_out[t * 3 + 1] = ok ? res[o][i].position[1] : 0; pos_out[t * 3 + 2] = ok ? res[o][i].position[2] : 0;
+                weight_out[t] = ok ? res[o][i].weight : 0; cls_out[t] = ok ? (int)res[o][i].classId : -1; inst_out[t] = ok ? (int)res[o][i].instanceId : -1;
+                nvotes_out[t] = ok ? res[o][i].numVotes : 0;
+            }
+        }
+        return 0;)
+}
+int ism3d_detect_file(void* m, const char* file, int32_t* cls_out, float* weight_out) {
+    GUARD(std::vector<VotingMaximum> maxima; std::map<std::string, double> times;
+          if (!((ImplicitShapeModel*)m)->detect(std::string(file), maxima, times)) return -2;
+          *cls_out = maxima.empty() ? -1 : (int)maxima[0].classId; *weight_out = maxima.empty() ? 0.f : maxima[0].weight; return 0;)
+}
+}

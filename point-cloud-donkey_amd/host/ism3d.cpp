@@ -1,0 +1,877 @@
+// ism3d.cpp — bodies of the C++ host mirror (ism3d.h). Every hot-path body is a call into libismhip.so (C ABI);
+// this file only owns configuration, batching, device buffers and the training-side bookkeeping the reference does on
+// the host (reference files cited per function, relative to /root/reference/src/implicit_shape_model).
+#include "ism3d.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <numeric>
+#include <random>
+
+namespace ism3d {
+
+// ---------------------------------------------------------------------------------------------------------------
+// logging (reference: log4cxx macros utils/utils.h:27-38; INFO<->WARN switch implicit_shape_model.cpp:145-151)
+// ---------------------------------------------------------------------------------------------------------------
+static bool g_log_info = true;
+#define LOG_INFO(x) do { if (g_log_info) std::cout << "INFO: " << x << std::endl; } while (0)
+#define LOG_WARN(x) do { std::cout << "WARN: " << x << std::endl; } while (0)
+#define LOG_ERROR(x) do { std::cerr << "ERROR: " << x << std::endl; } while (0)
+void jsonWarnMissing(const std::string& name) { LOG_WARN("parameter \"" << name << "\" not found, using default"); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// device plumbing
+// ---------------------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void reserve(size_t n) {
+        if (n <= bytes) return;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        size_t want = n + n / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) throw RuntimeException("hipMalloc failed");
+        bytes = want;
+    }
+    template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+    template <typename T> const T* as() const { return reinterpret_cast<const T*>(p); }
+};
+
+struct DeviceFeatures {
+    std::vector<uint32_t> off{0};     // per-object ranges of the kept features
+    int dim = 0;
+    uint32_t n = 0;
+    DevBuf desc, lrf, kx, ky, kz, src;
+};
+
+class DeviceSession {
+public:
+    ismhip_ctx* ctx = nullptr;
+    int n_obj = 0;
+    std::vector<uint32_t> pt_off, kp_off;
+    DevBuf x, y, z, nx, ny, nz, rgba, kx, ky, kz, krgba;
+    ismhip_cloud* cloud = nullptr;
+    bool has_color = false;
+    // vote space of the current batch (Voting::m_votes)
+    DevBuf v_pos, v_w, v_cls, v_inst, v_cw, v_bs, idx, dist;
+    std::vector<uint32_t> slot_off;
+    size_t n_slots = 0;
+    int n_classes = 0;
+    // scratch for raw (uncompacted) features
+    DevBuf raw_lrf, raw_desc, raw_cnt;
+
+    explicit DeviceSession(int device) {
+        int rc = ismhip_ctx_create(device, nullptr, &ctx);
+        if (rc == ISMHIP_ERR_NODEVICE) throw RuntimeException("no gfx950 device available: the recognition path has no CPU fallback");
+        if (rc != ISMHIP_OK) throw RuntimeException("ismhip_ctx_create failed");
+    }
+    ~DeviceSession() {
+        if (cloud) ismhip_cloud_destroy(ctx, cloud);
+        if (ctx) ismhip_ctx_destroy(ctx);
+    }
+    void check(int rc, const char* what) const {
+        if (rc != ISMHIP_OK) throw RuntimeException(std::string(what) + " failed (" + std::to_string(rc) + "): " + ismhip_last_error(ctx));
+    }
+    void sync() const { check(ismhip_sync(ctx), "ismhip_sync"); }
+    template <typename T> static void h2d(DevBuf& b, const std::vector<T>& v) {
+        b.reserve(std::max<size_t>(v.size(), 1) * sizeof(T));
+        if (!v.empty() && hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw RuntimeException("hipMemcpy H2D failed");
+    }
+    template <typename T> void d2h(std::vector<T>& v, const DevBuf& b, size_t n) const {
+        sync();
+        v.resize(n);
+        if (n && hipMemcpy(v.data(), b.p, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) throw RuntimeException("hipMemcpy D2H failed");
+    }
+    // concatenates the objects into SoA arrays, uploads them and builds the search surface
+    void uploadBatch(const std::vector<const PointCloud*>& clouds, const std::vector<KeypointSet>& kps, float cell, bool with_color) {
+        n_obj = (int)clouds.size();
+        pt_off.assign(1, 0); kp_off.assign(1, 0);
+        std::vector<float> hx, hy, hz, hnx, hny, hnz, hkx, hky, hkz;
+        std::vector<uint32_t> hrgba, hkrgba;
+        for (int o = 0; o < n_obj; ++o) {
+            const PointCloud& c = *clouds[o];
+            hx.insert(hx.end(), c.x.begin(), c.x.end()); hy.insert(hy.end(), c.y.begin(), c.y.end()); hz.insert(hz.end(), c.z.begin(), c.z.end());
+            hnx.insert(hnx.end(), c.nx.begin(), c.nx.end()); hny.insert(hny.end(), c.ny.begin(), c.ny.end()); hnz.insert(hnz.end(), c.nz.begin(), c.nz.end());
+            if (with_color) {
+                if (c.rgba.size() == c.size()) hrgba.insert(hrgba.end(), c.rgba.begin(), c.rgba.end());
+                else hrgba.insert(hrgba.end(), c.size(), 0u);
+            }
+            pt_off.push_back((uint32_t)hx.size());
+            const KeypointSet& k = kps[o];
+            hkx.insert(hkx.end(), k.x.begin(), k.x.end()); hky.insert(hky.end(), k.y.begin(), k.y.end()); hkz.insert(hkz.end(), k.z.begin(), k.z.end());
+            if (with_color) {
+                if (k.rgba.size() == k.size()) hkrgba.insert(hkrgba.end(), k.rgba.begin(), k.rgba.end());
+                else hkrgba.insert(hkrgba.end(), k.size(), 0u);
+            }
+            kp_off.push_back((uint32_t)hkx.size());
+        }
+        if (cloud) { ismhip_cloud_destroy(ctx, cloud); cloud = nullptr; }
+        h2d(x, hx); h2d(y, hy); h2d(z, hz); h2d(nx, hnx); h2d(ny, hny); h2d(nz, hnz); h2d(kx, hkx); h2d(ky, hky); h2d(kz, hkz);
+        has_color = with_color;
+        if (with_color) { h2d(rgba, hrgba); h2d(krgba, hkrgba); }
+        check(ismhip_cloud_create(ctx, n_obj, pt_off.data(), x.as<float>(), y.as<float>(), z.as<float>(), nx.as<float>(), ny.as<float>(),
+                                  nz.as<float>(), with_color ? rgba.as<uint32_t>() : nullptr, cell, &cloud), "ismhip_cloud_create");
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// JSONObject (utils/json_object.cpp)
+// ---------------------------------------------------------------------------------------------------------------
+JSONObject::JSONObject() {}
+JSONObject::~JSONObject() { for (auto* p : m_params) delete p; }
+
+Json JSONObject::configToJson() const {        // json_object.cpp:180-205
+    Json object = Json::object();
+    if (!getType().empty()) object["Type"] = Json::of(getType());
+    Json params = Json::object();
+    for (auto* p : m_params) params[p->name] = p->toJson();
+    if (!params.obj.empty()) object["Parameters"] = params;
+    Json children = iChildConfigsToJson();
+    if (children.isObject() && !children.obj.empty()) object["Children"] = children;
+    return object;
+}
+
+bool JSONObject::configFromJson(const Json& object) {   // json_object.cpp:207-240
+    if (!object.isObject()) return false;
+    const Json* params = object.find("Parameters");
+    for (auto* p : m_params) p->fromJson(params && params->isObject() ? params->find(p->name) : nullptr);
+    iPostInitConfig();
+    static const Json empty = Json::object();
+    const Json* children = object.find("Children");
+    return iChildConfigsFromJson(children ? *children : empty);
+}
+
+static std::string dirOf(const std::string& f) { size_t p = f.find_last_of('/'); return p == std::string::npos ? std::string() : f.substr(0, p + 1); }
+static std::string baseOf(const std::string& f) { size_t p = f.find_last_of('/'); return p == std::string::npos ? f : f.substr(p + 1); }
+
+bool JSONObject::writeObject(std::string file) {
+    std::string data = file;
+    size_t p = data.find_last_of('.');
+    if (p != std::string::npos && p > data.find_last_of('/') + 0) data = data.substr(0, p);
+    return writeObject(file, data + ".ismd");
+}
+bool JSONObject::writeObject(std::string file, std::string fileData) {     // json_object.cpp:50-95
+    Json root = Json::object();
+    root["ObjectConfig"] = configToJson();
+    root["ObjectData"] = Json::of(baseOf(fileData));
+    std::ofstream cfg(file);
+    if (!cfg) { LOG_ERROR("could not write file: " << file); return false; }
+    cfg << root.dump(3) << std::endl;
+    std::ofstream data(fileData, std::ios::binary);
+    if (!data) { LOG_ERROR("could not write file: " << fileData); return false; }
+    iSaveData(data);
+    return true;
+}
+bool JSONObject::readObject(std::string file, bool training) {            // json_object.cpp:97-178
+    std::ifstream in(file);
+    if (!in) { LOG_ERROR("could not read file: " << file); return false; }
+    std::stringstream ss; ss << in.rdbuf();
+    Json root;
+    try { root = Json::parse(ss.str()); } catch (const std::exception& e) { throw JSONException(std::string("could not parse ") + file + ": " + e.what()); }
+    const Json* cfg = root.find("ObjectConfig");
+    if (!cfg) throw JSONException("no ObjectConfig in " + file);
+    m_input_config_file = file;
+    if (!configFromJson(*cfg)) return false;
+    const Json* data = root.find("ObjectData");
+    if (!training && data && data->type == Json::String && !data->str.empty()) {
+        std::ifstream d(dirOf(file) + data->str, std::ios::binary);
+        if (!d) { LOG_ERROR("could not read data file: " << dirOf(file) + data->str); return false; }
+        return iLoadData(d);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Keypoints: pcl::VoxelGrid centroids (keypoints/keypoints_voxel_grid.cpp:30-46). Host side:
+// the step BEFORE the hot path.
+// ---------------------------------------------------------------------------------------------------------------
+KeypointsVoxelGrid::KeypointsVoxelGrid() { addParameter(m_leafSize, "LeafSize", 0.1f); }
+
+KeypointSet KeypointsVoxelGrid::iComputeKeypoints(const PointCloud& c) const {
+    KeypointSet out;
+    const size_t n = c.size();
+    if (n == 0) return out;
+    float mn[3] = {c.x[0], c.y[0], c.z[0]}, mx[3] = {c.x[0], c.y[0], c.z[0]};
+    for (size_t i = 0; i < n; ++i) {
+        mn[0] = std::min(mn[0], c.x[i]); mx[0] = std::max(mx[0], c.x[i]);
+        mn[1] = std::min(mn[1], c.y[i]); mx[1] = std::max(mx[1], c.y[i]);
+        mn[2] = std::min(mn[2], c.z[i]); mx[2] = std::max(mx[2], c.z[i]);
+    }
+    const float inv = 1.0f / m_leafSize;
+    int minb[3], divb[3];
+    for (int a = 0; a < 3; ++a) { minb[a] = (int)std::floor(mn[a] * inv); divb[a] = (int)std::floor(mx[a] * inv) - minb[a] + 1; }
+    const int64_t mul1 = divb[0], mul2 = (int64_t)divb[0] * divb[1];
+    std::vector<std::pair<int64_t, uint32_t>> iv(n);
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t i0 = (int64_t)(std::floor(c.x[i] * inv) - (float)minb[0]);
+        const int64_t i1 = (int64_t)(std::floor(c.y[i] * inv) - (float)minb[1]);
+        const int64_t i2 = (int64_t)(std::floor(c.z[i] * inv) - (float)minb[2]);
+        iv[i] = {i0 + i1 * mul1 + i2 * mul2, (uint32_t)i};
+    }
+    std::stable_sort(iv.begin(), iv.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    const bool color = c.rgba.size() == n;
+    size_t i = 0;
+    while (i < n) {
+        size_t j = i;
+        float s[3] = {0, 0, 0}, col[3] = {0, 0, 0};
+        while (j < n && iv[j].first == iv[i].first) {
+            const uint32_t p = iv[j].second;
+            s[0] += c.x[p]; s[1] += c.y[p]; s[2] += c.z[p];
+            if (color) { col[0] += (float)((c.rgba[p] >> 16) & 0xff); col[1] += (float)((c.rgba[p] >> 8) & 0xff); col[2] += (float)(c.rgba[p] & 0xff); }
+            ++j;
+        }
+        const float cnt = (float)(j - i);
+        out.x.push_back(s[0] / cnt); out.y.push_back(s[1] / cnt); out.z.push_back(s[2] / cnt);
+        if (color) out.rgba.push_back(((uint32_t)(uint8_t)(col[0] / cnt) << 16) | ((uint32_t)(uint8_t)(col[1] / cnt) << 8) | (uint32_t)(uint8_t)(col[2] / cnt));
+        i = j;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Features (features/features.cpp)
+// ---------------------------------------------------------------------------------------------------------------
+Features::Features() : m_numThreads(0) {
+    addParameter(m_referenceFrameRadius, "ReferenceFrameRadius", 0.2f);
+    addParameter(m_referenceFrameType, "ReferenceFrameType", std::string("SHOT"));
+}
+
+std::shared_ptr<DeviceFeatures> Features::operator()(DeviceSession& s) const {   // features.cpp:40-116
+    if (m_referenceFrameType != "SHOT") {
+        if (m_referenceFrameType == "BOARD" || m_referenceFrameType == "FLARE" || m_referenceFrameType == "SHOTNA")
+            throw RuntimeException("reference frame type \"" + m_referenceFrameType + "\" is not built on the MI355X path (only \"SHOT\")");
+        throw BadParamExceptionType<std::string>("invalid reference frame type", m_referenceFrameType);   // features.cpp:178
+    }
+    const uint32_t nkp = s.kp_off.back();
+    const int D = getDescriptorLength();
+    auto f = std::make_shared<DeviceFeatures>();
+    f->dim = D;
+    f->off.assign(s.n_obj + 1, 0);
+    if (nkp == 0) return f;
+    LOG_INFO("computing reference frames");
+    s.raw_lrf.reserve((size_t)nkp * 9 * 4); s.raw_desc.reserve((size_t)nkp * D * 4); s.raw_cnt.reserve((size_t)nkp * 4);
+    s.check(ismhip_shot_lrf(s.ctx, s.cloud, s.kp_off.data(), s.kx.as<float>(), s.ky.as<float>(), s.kz.as<float>(), m_referenceFrameRadius,
+                            s.raw_lrf.as<float>()), "ismhip_shot_lrf");
+    LOG_INFO("computing descriptors at keypoint positions");
+    iComputeDescriptors(s, s.raw_lrf.as<float>(), s.raw_desc.as<float>(), s.raw_cnt.as<uint32_t>());
+    // invalid frames and NaN descriptors are dropped, order preserved (features.cpp:66-76, implicit_shape_model.cpp:1276-1308)
+    f->desc.reserve((size_t)nkp * D * 4); f->lrf.reserve((size_t)nkp * 9 * 4);
+    f->kx.reserve((size_t)nkp * 4); f->ky.reserve((size_t)nkp * 4); f->kz.reserve((size_t)nkp * 4); f->src.reserve((size_t)nkp * 4);
+    s.check(ismhip_compact_features(s.ctx, s.n_obj, s.kp_off.data(), D, s.raw_desc.as<float>(), s.raw_lrf.as<float>(), s.kx.as<float>(),
+                                    s.ky.as<float>(), s.kz.as<float>(), f->desc.as<float>(), f->lrf.as<float>(), f->kx.as<float>(),
+                                    f->ky.as<float>(), f->kz.as<float>(), f->src.as<uint32_t>(), f->off.data()), "ismhip_compact_features");
+    f->n = f->off.back();
+    if (f->n < nkp) LOG_WARN("discarded " << (nkp - f->n) << " keypoint(s) with invalid reference frame or NaN descriptor");
+    LOG_INFO("obtained " << f->n << " " << getType() << " descriptors");
+    return f;
+}
+
+FeaturesSHOT::FeaturesSHOT() { addParameter(m_radius, "Radius", 0.1f); }
+FeaturesCSHOT::FeaturesCSHOT() { addParameter(m_radius, "Radius", 0.1f); }
+FeaturesFPFH::FeaturesFPFH() { addParameter(m_radius, "Radius", 0.1f); }
+
+void FeaturesSHOT::iComputeDescriptors(DeviceSession& s, const float* lrf9, float* desc_out, uint32_t* counts_out) const {   // features_shot.cpp:28-81
+    s.check(ismhip_shot352(s.ctx, s.cloud, s.kp_off.data(), s.kx.as<float>(), s.ky.as<float>(), s.kz.as<float>(), lrf9, m_radius, desc_out, counts_out),
+            "ismhip_shot352");
+}
+void FeaturesCSHOT::iComputeDescriptors(DeviceSession& s, const float* lrf9, float* desc_out, uint32_t* counts_out) const {  // features_cshot.cpp:28-103
+    if (!s.has_color) throw RuntimeException("CSHOT needs coloured point clouds");
+    s.check(ismhip_cshot1344(s.ctx, s.cloud, s.kp_off.data(), s.kx.as<float>(), s.ky.as<float>(), s.kz.as<float>(), s.krgba.as<uint32_t>(), lrf9,
+                             m_radius, desc_out, counts_out), "ismhip_cshot1344");
+}
+void FeaturesFPFH::iComputeDescriptors(DeviceSession& s, const float*, float* desc_out, uint32_t* counts_out) const {        // features_fpfh.cpp:27-72
+    s.check(ismhip_fpfh33(s.ctx, s.cloud, s.kp_off.data(), s.kx.as<float>(), s.ky.as<float>(), s.kz.as<float>(), m_radius, desc_out, counts_out),
+            "ismhip_fpfh33");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// activation strategy + codebook
+// ---------------------------------------------------------------------------------------------------------------
+ActivationStrategy::ActivationStrategy() {       // activation_strategy.cpp:16-22
+    addParameter(m_use_distance_ratio, "UseDistanceRatio", false);
+    addParameter(m_distance_ratio_threshold, "DistanceRatioThreshold", 0.95f);
+}
+ActivationStrategyKNN::ActivationStrategyKNN() { addParameter(m_k, "K", 1); }   // activation_strategy_knn.cpp:19
+
+Codebook::Codebook() {                           // codebook.cpp:28-41
+    m_activationStrategy.reset(new ActivationStrategyKNN());
+    addParameter(m_useClassWeight, "UseClassWeight", false);
+    addParameter(m_useVoteWeight, "UseVoteWeight", false);
+    addParameter(m_useMatchingWeight, "UseMatchingWeight", false);
+    addParameter(m_useCodewordWeight, "UseCodewordWeight", false);
+    addParameter(m_use_partial_shot, "UsePartialShot", false);
+    addParameter(m_partial_shot_type, "PartialShotType", std::string("front"));
+    addParameter(m_use_random_codebook, "UseRandomCodebook", false);
+    addParameter(m_random_codebook_factor, "RandomCodebookFactor", 1.0f);
+}
+Codebook::~Codebook() {
+    if (m_dev && m_dev_session) ismhip_codebook_destroy(m_dev_session->ctx, m_dev);
+}
+Json Codebook::iChildConfigsToJson() const {
+    Json c = Json::object();
+    if (m_activationStrategy) c["ActivationStrategy"] = m_activationStrategy->configToJson();
+    return c;
+}
+bool Codebook::iChildConfigsFromJson(const Json& c) {
+    if (const Json* a = c.find("ActivationStrategy")) m_activationStrategy.reset(Factory<ActivationStrategy>::create(*a));
+    return m_activationStrategy != nullptr;
+}
+
+void Codebook::upload(DeviceSession& s) const {
+    if (!m_dirty && m_dev && m_dev_session == &s) return;
+    if (m_dev && m_dev_session) ismhip_codebook_destroy(m_dev_session->ctx, m_dev);
+    m_dev = nullptr; m_dev_session = &s;
+    const CodebookData& d = m_data;
+    if (d.numWords() == 0) return;
+    s.check(ismhip_codebook_create(s.ctx, d.numWords(), d.dim, d.words.data(), d.word_weight.empty() ? nullptr : d.word_weight.data(),
+                                   d.vote_offsets.data(), d.vote_xyz.data(), d.vote_weight.empty() ? nullptr : d.vote_weight.data(),
+                                   d.vote_class_weight.empty() ? nullptr : d.vote_class_weight.data(), d.vote_class.data(), d.vote_instance.data(),
+                                   d.vote_bbox_quat.empty() ? nullptr : d.vote_bbox_quat.data(), d.vote_bbox_size.empty() ? nullptr : d.vote_bbox_size.data(),
+                                   (int)d.class_sigma.size(), d.class_sigma.data(), &m_dev), "ismhip_codebook_create");
+    m_dirty = false;
+}
+
+int ActivationStrategyKNN::activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric,
+                                       int32_t* idx_out, float* dist_out) const {     // activation_strategy_knn.h:41-126
+    if (m_k > 4) throw RuntimeException("KNN activation with K > 4 is not built");
+    if (f.n == 0) return m_k;
+    if (m_use_distance_ratio && m_is_detection && m_k == 1)
+        s.check(ismhip_knn_ratio(s.ctx, codewords, metric, (int)f.n, f.desc.as<float>(), m_distance_ratio_threshold, idx_out, dist_out), "ismhip_knn_ratio");
+    else
+        s.check(ismhip_knn(s.ctx, codewords, metric, (int)f.n, f.desc.as<float>(), m_k, idx_out, dist_out), "ismhip_knn");
+    return m_k;
+}
+
+// FLANN functors on the host, used by the training statistics only (utils/distance.cpp:33-52)
+static float hostDistance(int metric, const float* a, const float* b, int n) {
+    float result = 0.f;
+    if (metric == ISMHIP_METRIC_CHI2) {
+        for (int i = 0; i < n; ++i) { const float sum = a[i] + b[i]; if (sum > 0) { const float diff = a[i] - b[i]; result += diff * diff / sum; } }
+        return result;
+    }
+    int i = 0;
+    for (; i + 3 < n; i += 4) {
+        const float d0 = a[i] - b[i], d1 = a[i + 1] - b[i + 1], d2 = a[i + 2] - b[i + 2], d3 = a[i + 3] - b[i + 3];
+        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    for (; i < n; ++i) { const float d0 = a[i] - b[i]; result += d0 * d0; }
+    return result;
+}
+
+void Codebook::activate(DeviceSession& s, const DeviceFeatures& f, const std::vector<unsigned>& feat_class, const std::vector<unsigned>& feat_instance,
+                        const std::vector<unsigned>& feat_model, const std::vector<std::array<float, 3>>& feat_center, int metric, int n_classes) {
+    // codebook.cpp:64-368 for Clustering "None" (one codeword per training feature, clustering_none.cpp:25-35) and KNN activation.
+    const uint32_t n = f.n;
+    const int D = f.dim;
+    if (n == 0) throw RuntimeException("no training features");
+    const ActivationStrategyKNN* knn = dynamic_cast<const ActivationStrategyKNN*>(m_activationStrategy.get());
+    if (!knn) throw RuntimeException("activation strategy \"" + m_activationStrategy->getType() + "\" is not built (only \"KNN\")");
+    const int k = knn->getK();
+    if (k > 4) throw RuntimeException("KNN activation with K > 4 is not built");
+    std::vector<float> words, lrf, kx, ky, kz;
+    s.d2h(words, f.desc, (size_t)n * D); s.d2h(lrf, f.lrf, (size_t)n * 9); s.d2h(kx, f.kx, n); s.d2h(ky, f.ky, n); s.d2h(kz, f.kz, n);
+    // step 1: every training feature activates its k nearest codewords (the codebook holds the feature itself)
+    CodebookData tmp; tmp.dim = D; tmp.words = words; tmp.vote_offsets.resize(n + 1);
+    std::iota(tmp.vote_offsets.begin(), tmp.vote_offsets.end(), 0u);
+    tmp.vote_xyz.assign((size_t)n * 3, 0.f); tmp.vote_class.assign(n, 0u); tmp.vote_instance.assign(n, 0u); tmp.class_sigma.assign(std::max(1, n_classes), 1.f);
+    ismhip_codebook* dev = nullptr;
+    s.check(ismhip_codebook_create(s.ctx, n, D, tmp.words.data(), nullptr, tmp.vote_offsets.data(), tmp.vote_xyz.data(), nullptr, nullptr, tmp.vote_class.data(),
+                                   tmp.vote_instance.data(), nullptr, nullptr, (int)tmp.class_sigma.size(), tmp.class_sigma.data(), &dev), "ismhip_codebook_create");
+    DevBuf didx, ddist;
+    didx.reserve((size_t)n * k * 4); ddist.reserve((size_t)n * k * 4);
+    knn->activateKNN(s, dev, f, metric, didx.as<int32_t>(), ddist.as<float>());
+    std::vector<int32_t> act;
+    s.d2h(act, didx, (size_t)n * k);
+    ismhip_codebook_destroy(s.ctx, dev);
+    // distributions: votes per codeword in activation order; vote = rotateInto(center - keyPos, LRF) (codeword_distribution.cpp:37-71)
+    std::vector<std::vector<uint32_t>> dist_feats(n);
+    for (uint32_t i = 0; i < n; ++i) for (int j = 0; j < k; ++j) { const int32_t w = act[(size_t)i * k + j]; if (w >= 0) dist_feats[w].push_back(i); }
+    // per-class sigma (codebook.cpp:94-193)
+    std::vector<float> sigma(n_classes, std::nanf(""));
+    for (int c = 0; c < n_classes; ++c) {
+        std::vector<uint32_t> ids;
+        for (uint32_t i = 0; i < n; ++i) if ((int)feat_class[i] == c) ids.push_back(i);
+        if (ids.empty()) continue;
+        const int max_elements = (int)std::sqrt((double)ids.size());
+        std::vector<uint32_t> allFeat; std::vector<int32_t> allWords;
+        size_t i = 0;
+        while (i < ids.size()) {
+            size_t j = i;
+            while (j < ids.size() && feat_model[ids[j]] == feat_model[ids[i]]) {
+                for (int t = 0; t < k; ++t) { const int32_t w = act[(size_t)ids[j] * k + t]; if ((int)allWords.size() < max_elements && w >= 0) allWords.push_back(w); }
+                ++j;
+            }
+            if ((int)allFeat.size() < max_elements) for (size_t t = i; t < j; ++t) allFeat.push_back(ids[t]);
+            i = j;
+        }
+        float sum = 0; std::vector<float> ds;
+        for (uint32_t fi : allFeat) for (int32_t w : allWords) { const float d = hostDistance(metric, &words[(size_t)fi * D], &words[(size_t)w * D], D); sum += d; ds.push_back(d); }
+        const int num = (int)ds.size();
+        const float mean = sum / num;
+        float variance = 0;
+        for (float d : ds) { const float diff = d - mean; variance += diff * diff; }
+        variance /= num - 1;
+        sigma[c] = variance;
+    }
+    // K = 1 clean-up: keep distributions with exactly one vote (codebook.cpp:201-224); otherwise every activated codeword stays
+    const bool clean_up = (k == 1);
+    CodebookData out; out.dim = D; out.class_sigma = sigma; out.vote_offsets.assign(1, 0u);
+    std::vector<uint32_t> kept;
+    for (uint32_t w = 0; w < n; ++w) {
+        if (dist_feats[w].empty()) continue;
+        if (clean_up && dist_feats[w].size() != 1) continue;
+        kept.push_back(w);
+    }
+    if (m_use_random_codebook && m_random_codebook_factor < 1.0f) {   // codebook.cpp:821-829, seeded instead of std::random_device
+        std::mt19937 rng(0x5EED);
+        std::uniform_int_distribution<uint32_t> distr(0, (uint32_t)kept.size());
+        std::vector<uint32_t> sub;
+        for (uint32_t w : kept) if (!(distr(rng) > m_random_codebook_factor * kept.size())) sub.push_back(w);
+        kept.swap(sub);
+    }
+    std::vector<int> words_per_class(n_classes, 0);
+    for (uint32_t w : kept) { std::vector<char> seen(n_classes, 0); for (uint32_t fi : dist_feats[w]) if (!seen[feat_class[fi]]) { seen[feat_class[fi]] = 1; words_per_class[feat_class[fi]]++; } }
+    for (uint32_t w : kept) {
+        out.words.insert(out.words.end(), words.begin() + (size_t)w * D, words.begin() + (size_t)(w + 1) * D);
+        out.word_weight.push_back(1.0f);
+        for (uint32_t fi : dist_feats[w]) {
+            const float* L = &lrf[(size_t)fi * 9];
+            const float v[3] = {feat_center[fi][0] - kx[fi], feat_center[fi][1] - ky[fi], feat_center[fi][2] - kz[fi]};
+            // rotateInto: rows of the frame are the axes (utils.cpp:154-165)
+            out.vote_xyz.push_back(L[0] * v[0] + L[1] * v[1] + L[2] * v[2]);
+            out.vote_xyz.push_back(L[3] * v[0] + L[4] * v[1] + L[5] * v[2]);
+            out.vote_xyz.push_back(L[6] * v[0] + L[7] * v[1] + L[8] * v[2]);
+            out.vote_class.push_back(feat_class[fi]); out.vote_instance.push_back(feat_instance[fi]);
+            out.vote_weight.push_back(1.0f);                                                     // computeWeights: exact centre -> exp(0)
+            out.vote_class_weight.push_back(1.0f / (float)std::max(1, words_per_class[feat_class[fi]]));   // term1 * term2 * term3 for single-vote words
+        }
+        out.vote_offsets.push_back((uint32_t)out.vote_class.size());
+    }
+    LOG_INFO("Size of distribution at the end of training: " << kept.size());
+    setData(out);
+}
+
+void Codebook::castVotes(DeviceSession& s, const DeviceFeatures& f, int metric, Voting& voting) const {   // codebook.cpp:403-555
+    (void)voting;
+    s.n_slots = 0; s.slot_off.assign(s.n_obj + 1, 0);
+    if (isEmpty()) return;
+    if (m_use_partial_shot) throw RuntimeException("UsePartialShot is not built on the MI355X path");
+    upload(s);
+    m_activationStrategy->setIsDetection();
+    const ActivationStrategyKNN* knn = dynamic_cast<const ActivationStrategyKNN*>(m_activationStrategy.get());
+    if (!knn) throw RuntimeException("activation strategy \"" + m_activationStrategy->getType() + "\" is not built (only \"KNN\")");
+    int k = knn->getK();
+    if (k > 4) throw RuntimeException("KNN activation with K > 4 is not built");
+    const uint32_t n = f.n;
+    if (n == 0) return;
+    s.idx.reserve((size_t)n * k * 4); s.dist.reserve((size_t)n * k * 4);
+    knn->activateKNN(s, m_dev, f, metric, s.idx.as<int32_t>(), s.dist.as<float>());
+    const int maxv = ismhip_codebook_max_votes_per_word(m_dev);
+    const size_t ns = (size_t)n * k * maxv;
+    s.v_pos.reserve(ns * 12); s.v_w.reserve(ns * 4); s.v_cls.reserve(ns * 4); s.v_inst.reserve(ns * 4); s.v_cw.reserve(ns * 4); s.v_bs.reserve(ns * 12);
+    const uint32_t flags = (m_useClassWeight ? ISMHIP_W_CLASS : 0u) | (m_useVoteWeight ? ISMHIP_W_VOTE : 0u) |
+                           (m_useMatchingWeight ? ISMHIP_W_MATCHING : 0u) | (m_useCodewordWeight ? ISMHIP_W_CODEWORD : 0u);
+    s.check(ismhip_cast_votes(s.ctx, m_dev, flags, (int)n, f.lrf.as<float>(), f.kx.as<float>(), f.ky.as<float>(), f.kz.as<float>(), k, s.idx.as<int32_t>(),
+                              s.dist.as<float>(), s.v_pos.as<float>(), s.v_w.as<float>(), s.v_cls.as<int32_t>(), s.v_inst.as<int32_t>(), s.v_cw.as<int32_t>(),
+                              nullptr, s.v_bs.as<float>()), "ismhip_cast_votes");
+    s.n_slots = ns;
+    for (int o = 0; o <= s.n_obj; ++o) s.slot_off[o] = f.off[o] * (uint32_t)(k * maxv);
+    s.n_classes = (int)m_data.class_sigma.size();
+}
+
+static void writeVec(std::ostream& os, const void* p, size_t bytes) { uint64_t n = bytes; os.write((const char*)&n, 8); os.write((const char*)p, bytes); }
+template <typename T> static void writeVec(std::ostream& os, const std::vector<T>& v) { writeVec(os, v.data(), v.size() * sizeof(T)); }
+template <typename T> static bool readVec(std::istream& is, std::vector<T>& v) {
+    uint64_t n = 0; is.read((char*)&n, 8);
+    if (!is || n % sizeof(T)) return false;
+    v.resize(n / sizeof(T));
+    is.read((char*)v.data(), n);
+    return (bool)is;
+}
+void Codebook::save(std::ostream& os) const {
+    const CodebookData& d = m_data;
+    int32_t dim = d.dim; os.write((const char*)&dim, 4);
+    writeVec(os, d.words); writeVec(os, d.word_weight); writeVec(os, d.vote_offsets); writeVec(os, d.vote_xyz); writeVec(os, d.vote_weight);
+    writeVec(os, d.vote_class_weight); writeVec(os, d.vote_class); writeVec(os, d.vote_instance); writeVec(os, d.vote_bbox_quat);
+    writeVec(os, d.vote_bbox_size); writeVec(os, d.class_sigma);
+}
+bool Codebook::load(std::istream& is) {
+    CodebookData d; int32_t dim = 0; is.read((char*)&dim, 4); d.dim = dim;
+    bool ok = readVec(is, d.words) && readVec(is, d.word_weight) && readVec(is, d.vote_offsets) && readVec(is, d.vote_xyz) && readVec(is, d.vote_weight) &&
+              readVec(is, d.vote_class_weight) && readVec(is, d.vote_class) && readVec(is, d.vote_instance) && readVec(is, d.vote_bbox_quat) &&
+              readVec(is, d.vote_bbox_size) && readVec(is, d.class_sigma);
+    if (!ok) return false;
+    setData(d);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Voting (voting/voting.cpp, voting_mean_shift.cpp)
+// ---------------------------------------------------------------------------------------------------------------
+Voting::Voting() {                                // voting.cpp:28-50 (hot-path subset; the global-feature / RANSAC keys are accepted and must stay off)
+    addParameter(m_minThreshold, "MinThreshold", 0.0f);
+    addParameter(m_minVotesThreshold, "MinVotesThreshold", 1);
+    addParameter(m_bestK, "BestK", -1);
+    addParameter(m_averageRotation, "AverageRotation", false);
+    addParameter(m_radiusType, "BinOrBandwidthType", std::string("Config"));
+    addParameter(m_radiusFactor, "BinOrBandwidthFactor", 1.0f);
+    addParameter(m_max_filter_type, "MaxFilterType", std::string("None"));
+    addParameter(m_max_type_param, "SingleObjectMaxType", std::string("Default"));
+    addParameter(m_single_object_mode, "SingleObjectMode", false);
+    addParameter(m_use_global_features, "UseGlobalFeatures", false);
+    addParameter(m_vote_filtering_with_ransac, "RansacVoteFiltering", false);
+}
+void Voting::clear() {}
+std::vector<std::vector<VotingMaximum>> Voting::findMaxima(DeviceSession& s) {
+    if (m_use_global_features) throw RuntimeException("UseGlobalFeatures is out of scope of the MI355X path (SURVEY §2 row 10)");
+    if (m_vote_filtering_with_ransac) throw RuntimeException("RansacVoteFiltering is not built on the MI355X path");
+    if (m_radiusType != "Config" && m_radiusType != "Fixed") throw RuntimeException("BinOrBandwidthType \"" + m_radiusType + "\" is not built (only \"Config\")");
+    if (m_max_filter_type != "None") throw RuntimeException("MaxFilterType \"" + m_max_filter_type + "\" is not built (only \"None\")");
+    if (m_single_object_mode && m_max_type_param != "None" && m_max_type_param != "Default")
+        throw RuntimeException("SingleObjectMaxType \"" + m_max_type_param + "\" is not built (only \"None\"/\"Default\")");
+    std::vector<std::vector<VotingMaximum>> out(s.n_obj);
+    if (s.n_slots == 0) return out;
+    iFindMaxima(s, out);
+    return out;
+}
+
+VotingMeanShift::VotingMeanShift() {              // voting_mean_shift.cpp:20-27
+    addParameter(m_bandwidth, "Bandwidth", 0.2f);
+    addParameter(m_threshold, "Threshold", 1e-3f);
+    addParameter(m_maxIter, "MaxIter", 1000);
+    addParameter(m_kernel, "Kernel", std::string("Gaussian"));
+    addParameter(m_maxima_suppression_type, "MaximaSuppression", std::string("Average"));
+}
+void VotingMeanShift::iFindMaxima(DeviceSession& s, std::vector<std::vector<VotingMaximum>>& out) {
+    const int C = std::max(1, s.n_classes);
+    const int M = 32;
+    ismhip_maxima_params P;
+    P.n_classes = C; P.class_bandwidth_h = nullptr; P.bandwidth = m_bandwidth; P.threshold = m_threshold; P.max_iter = m_maxIter;
+    P.kernel = m_kernel == "Uniform" ? ISMHIP_KERNEL_UNIFORM : ISMHIP_KERNEL_GAUSSIAN;
+    P.suppression = m_maxima_suppression_type == "Average" ? ISMHIP_SUPPRESS_AVERAGE : (m_maxima_suppression_type == "Suppress" ? ISMHIP_SUPPRESS_SUPPRESS : ISMHIP_SUPPRESS_NONE);
+    P.min_votes_threshold = m_minVotesThreshold; P.min_threshold = m_minThreshold; P.best_k = m_bestK; P.max_maxima = M;
+    DevBuf n_max, pos, w, cls, inst, iw, bs, nv, score;
+    const size_t t = (size_t)s.n_obj * M;
+    n_max.reserve(s.n_obj * 4); pos.reserve(t * 12); w.reserve(t * 4); cls.reserve(t * 4); inst.reserve(t * 4); iw.reserve(t * 4); bs.reserve(t * 12);
+    nv.reserve(t * 4); score.reserve((size_t)s.n_obj * C * 4);
+    s.check(ismhip_find_maxima(s.ctx, s.n_obj, s.slot_off.data(), s.v_pos.as<float>(), s.v_w.as<float>(), s.v_cls.as<int32_t>(), s.v_inst.as<int32_t>(),
+                               s.v_bs.as<float>(), &P, n_max.as<int32_t>(), pos.as<float>(), w.as<float>(), cls.as<int32_t>(), inst.as<int32_t>(),
+                               iw.as<float>(), bs.as<float>(), nv.as<int32_t>(), score.as<float>()), "ismhip_find_maxima");
+    std::vector<int32_t> hn, hcls, hinst, hnv; std::vector<float> hpos, hw, hiw, hbs;
+    s.d2h(hn, n_max, s.n_obj); s.d2h(hpos, pos, t * 3); s.d2h(hw, w, t); s.d2h(hcls, cls, t); s.d2h(hinst, inst, t); s.d2h(hiw, iw, t); s.d2h(hbs, bs, t * 3); s.d2h(hnv, nv, t);
+    for (int o = 0; o < s.n_obj; ++o)
+        for (int m = 0; m < hn[o]; ++m) {
+            const size_t i = (size_t)o * M + m;
+            VotingMaximum vm;
+            vm.position = {hpos[i * 3], hpos[i * 3 + 1], hpos[i * 3 + 2]}; vm.weight = hw[i]; vm.classId = (unsigned)hcls[i]; vm.instanceId = (unsigned)hinst[i];
+            vm.instanceWeight = hiw[i]; vm.numVotes = hnv[i];
+            vm.boundingBox.position = vm.position; vm.boundingBox.size = {hbs[i * 3], hbs[i * 3 + 1], hbs[i * 3 + 2]};
+            out[o].push_back(vm);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Factories (features_factory.h:47-110, keypoints_factory.h:24-38, activation_strategy_factory.h:22-35, voting_factory.h:20-29)
+// ---------------------------------------------------------------------------------------------------------------
+template <> Features* Factory<Features>::createByType(const std::string& type) {
+    if (type == FeaturesSHOT::getTypeStatic()) return new FeaturesSHOT();
+    if (type == FeaturesCSHOT::getTypeStatic()) return new FeaturesCSHOT();
+    if (type == FeaturesFPFH::getTypeStatic()) return new FeaturesFPFH();
+    throw RuntimeException("feature type \"" + type + "\" is outside the MI355X hot path (built: SHOT, CSHOT, FPFH)");
+}
+template <> Keypoints* Factory<Keypoints>::createByType(const std::string& type) {
+    if (type == KeypointsVoxelGrid::getTypeStatic()) return new KeypointsVoxelGrid();
+    throw RuntimeException("keypoint type \"" + type + "\" is not built (built: VoxelGrid)");
+}
+template <> ActivationStrategy* Factory<ActivationStrategy>::createByType(const std::string& type) {
+    if (type == ActivationStrategyKNN::getTypeStatic()) return new ActivationStrategyKNN();
+    throw RuntimeException("activation strategy \"" + type + "\" is not built (built: KNN)");
+}
+template <> Voting* Factory<Voting>::createByType(const std::string& type) {
+    if (type == VotingMeanShift::getTypeStatic()) return new VotingMeanShift();
+    throw RuntimeException("voting type \"" + type + "\" is not built (built: MeanShift)");
+}
+template <> Codebook* Factory<Codebook>::createByType(const std::string&) { return new Codebook(); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// ImplicitShapeModel (implicit_shape_model.cpp)
+// ---------------------------------------------------------------------------------------------------------------
+ImplicitShapeModel::ImplicitShapeModel() {        // :91-168 (hot-path subset + the filter switches, which must stay off)
+    addParameter(m_distanceType, "DistanceType", std::string("Euclidean"));
+    addParameter(m_normal_radius, "NormalRadius", 0.05f);
+    addParameter(m_consistent_normals_method, "ConsistentNormalsMethod", 2);
+    addParameter(m_num_threads, "NumThreads", 0);
+    addParameter(m_bounding_box_type, "BoundingBoxType", std::string("MVBB"));
+    addParameter(m_num_kd_trees, "FLANNNumKDTrees", 4);
+    addParameter(m_flann_exact_match, "FLANNExactMatch", false);
+    addParameter(m_instance_labels_primary, "InstanceLabelsPrimary", true);
+    addParameter(m_single_object_mode_legacy, "SingleObjectMode", false);
+    addParameter(m_use_smoothing, "UseSmoothing", false);
+    addParameter(m_use_sor, "UseStatisticalOutlierRemoval", false);
+    addParameter(m_use_ror, "UseRadiusOutlierRemoval", false);
+    addParameter(m_use_voxel_filtering, "UseVoxelFiltering", false);
+    m_codebook.reset(new Codebook());
+    m_keypoints_detector.reset(new KeypointsVoxelGrid());
+    m_feature_descriptor.reset(new FeaturesSHOT());
+    m_voting.reset(new VotingMeanShift());
+}
+ImplicitShapeModel::~ImplicitShapeModel() {
+    m_codebook.reset();     // releases its device handle while the session is alive
+    m_session.reset();
+}
+void ImplicitShapeModel::iPostInitConfig() {      // :1260-1273
+    if (m_distanceType != "Euclidean" && m_distanceType != "ChiSquared") throw BadParamExceptionType<std::string>("invalid distance type", m_distanceType);
+    if (!m_flann_exact_match)
+        LOG_WARN("FLANNExactMatch is false: the MI355X path always searches exactly (FLANN's randomized kd-forest with 128 checks is not reproduced)");
+}
+void ImplicitShapeModel::clear() { m_training_clouds.clear(); m_training_instances.clear(); }
+
+Json ImplicitShapeModel::iChildConfigsToJson() const {   // :1070-1083
+    Json c = Json::object();
+    c["Codebook"] = m_codebook->configToJson();
+    c["Keypoints"] = m_keypoints_detector->configToJson();
+    c["Features"] = m_feature_descriptor->configToJson();
+    if (!m_global_features_cfg.isNull()) c["GlobalFeatures"] = m_global_features_cfg;
+    c["Clustering"] = m_clustering_cfg.isNull() ? Json::parse("{\"Type\":\"None\"}") : m_clustering_cfg;
+    c["Voting"] = m_voting->configToJson();
+    c["FeatureWeighting"] = m_feature_ranking_cfg.isNull() ? Json::parse("{\"Type\":\"Uniform\"}") : m_feature_ranking_cfg;
+    return c;
+}
+bool ImplicitShapeModel::iChildConfigsFromJson(const Json& c) {   // :1085-1142
+    const Json* cb = c.find("Codebook"); const Json* kp = c.find("Keypoints"); const Json* ft = c.find("Features");
+    const Json* cl = c.find("Clustering"); const Json* vo = c.find("Voting"); const Json* fw = c.find("FeatureWeighting");
+    if (!cb || !kp || !ft || !cl || !vo || !fw) { LOG_ERROR("missing child section (Codebook, Keypoints, Features, Clustering, Voting, FeatureWeighting are required)"); return false; }
+    m_codebook.reset(Factory<Codebook>::create(*cb));
+    m_keypoints_detector.reset(Factory<Keypoints>::create(*kp));
+    m_feature_descriptor.reset(Factory<Features>::create(*ft));
+    m_voting.reset(Factory<Voting>::create(*vo));
+    m_clustering_cfg = *cl; m_feature_ranking_cfg = *fw;
+    if (const Json* gf = c.find("GlobalFeatures")) m_global_features_cfg = *gf;
+    const Json* ct = cl->find("Type");
+    if (!ct || ct->str != "None") throw RuntimeException("clustering type \"" + (ct ? ct->str : std::string()) + "\" is out of scope (training-only; built: None)");
+    const Json* rt = fw->find("Type");
+    if (!rt || rt->str != "Uniform") throw RuntimeException("feature ranking type \"" + (rt ? rt->str : std::string()) + "\" is out of scope (built: Uniform)");
+    if (m_use_smoothing || m_use_sor || m_use_ror || m_use_voxel_filtering) throw RuntimeException("point cloud pre-filters (smoothing / outlier removal / voxel filtering) are not built");
+    return m_codebook && m_keypoints_detector && m_feature_descriptor && m_voting;
+}
+
+void ImplicitShapeModel::iSaveData(std::ostream& os) const {      // :1144-1179 (own container, not Boost's archive: DESIGN.md §7)
+    const char magic[8] = {'I', 'S', 'M', 'D', 'A', 'M', 'D', '1'};
+    os.write(magic, 8);
+    int32_t nc = m_n_classes; os.write((const char*)&nc, 4);
+    m_codebook->save(os);
+    auto writeMap = [&](const std::map<unsigned, std::string>& m) {
+        uint32_t n = (uint32_t)m.size(); os.write((const char*)&n, 4);
+        for (auto& kv : m) { uint32_t k = kv.first, l = (uint32_t)kv.second.size(); os.write((const char*)&k, 4); os.write((const char*)&l, 4); os.write(kv.second.data(), l); }
+    };
+    writeMap(m_class_labels); writeMap(m_instance_labels);
+    uint32_t n = (uint32_t)m_instance_to_class_map.size(); os.write((const char*)&n, 4);
+    for (auto& kv : m_instance_to_class_map) { uint32_t a = kv.first, b = kv.second; os.write((const char*)&a, 4); os.write((const char*)&b, 4); }
+}
+bool ImplicitShapeModel::iLoadData(std::istream& is) {            // :1181-1237
+    char magic[8]; is.read(magic, 8);
+    if (!is || std::memcmp(magic, "ISMDAMD1", 8) != 0) { LOG_ERROR("not an ISMD-AMD1 data file (Boost binary archives of the reference are not readable yet)"); return false; }
+    int32_t nc = 0; is.read((char*)&nc, 4); m_n_classes = nc;
+    if (!m_codebook->load(is)) return false;
+    auto readMap = [&](std::map<unsigned, std::string>& m) {
+        uint32_t n = 0; is.read((char*)&n, 4);
+        for (uint32_t i = 0; i < n && is; ++i) { uint32_t k = 0, l = 0; is.read((char*)&k, 4); is.read((char*)&l, 4); std::string s(l, ' '); is.read(&s[0], l); m[k] = s; }
+    };
+    readMap(m_class_labels); readMap(m_instance_labels);
+    uint32_t n = 0; is.read((char*)&n, 4);
+    for (uint32_t i = 0; i < n && is; ++i) { uint32_t a = 0, b = 0; is.read((char*)&a, 4); is.read((char*)&b, 4); m_instance_to_class_map[a] = b; }
+    return (bool)is;
+}
+
+DeviceSession& ImplicitShapeModel::session() {
+    if (!m_session) m_session.reset(new DeviceSession(m_device));
+    return *m_session;
+}
+int ImplicitShapeModel::metric() const { return m_distanceType == "ChiSquared" ? ISMHIP_METRIC_CHI2 : ISMHIP_METRIC_L2SQ; }
+
+bool ImplicitShapeModel::addTrainingModel(const std::string& filename, unsigned class_id, unsigned instance_id) {   // :182-211
+    LOG_INFO("adding training model with class id " << class_id << " and instance id " << instance_id);
+    std::shared_ptr<PointCloud> c = loadPointCloud(filename);
+    if (!c) return false;
+    m_training_clouds[class_id].push_back(c); m_training_instances[class_id].push_back(instance_id);
+    return true;
+}
+bool ImplicitShapeModel::addTrainingModel(const PointCloud& cloud, unsigned class_id, unsigned instance_id) {
+    m_training_clouds[class_id].push_back(std::make_shared<PointCloud>(cloud)); m_training_instances[class_id].push_back(instance_id);
+    return true;
+}
+
+static bool firstNormalValid(const PointCloud& c) {   // :615-625 — decided from the FIRST point only
+    if (c.nx.size() != c.size() || c.empty()) return false;
+    if ((c.nx[0] == 0 && c.ny[0] == 0 && c.nz[0] == 0) || std::isnan(c.nx[0])) return false;
+    return true;
+}
+
+std::shared_ptr<DeviceFeatures> ImplicitShapeModel::computeFeatures(const std::vector<const PointCloud*>& clouds, bool) {   // :733-927
+    DeviceSession& s = session();
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<KeypointSet> kps;
+    for (const PointCloud* c : clouds) {
+        if (!firstNormalValid(*c)) throw RuntimeException("input cloud has no normals: normal estimation on the device is not built yet (SURVEY §8f row 3)");
+        kps.push_back((*m_keypoints_detector)(*c));
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    m_processing_times["keypoints"] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    const float cell = std::min(m_feature_descriptor->getRadius(), m_feature_descriptor->getType() == "FPFH" ? m_feature_descriptor->getRadius()
+                                                                                                           : m_feature_descriptor->getReferenceFrameRadius()) * 0.5f;
+    s.uploadBatch(clouds, kps, cell, m_feature_descriptor->needsColor());
+    auto f = (*m_feature_descriptor)(s);
+    s.sync();
+    m_processing_times["features"] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    return f;
+}
+
+void ImplicitShapeModel::train() {                // :252-500
+    if (m_training_clouds.empty()) { LOG_WARN("no training objects found"); return; }
+    g_log_info = m_logging;
+    if (m_bounding_box_type != "AABB")
+        LOG_WARN("BoundingBoxType \"" << m_bounding_box_type << "\": MVBB is not built, using the axis-aligned box centre for the training votes");
+    DeviceSession& s = session();
+    const int met = metric();
+    // all training objects, class by class (std::map order), model by model
+    std::vector<const PointCloud*> clouds; std::vector<unsigned> obj_class, obj_inst;
+    for (auto& kv : m_training_clouds)
+        for (size_t i = 0; i < kv.second.size(); ++i) { clouds.push_back(kv.second[i].get()); obj_class.push_back(kv.first); obj_inst.push_back(m_training_instances[kv.first][i]); }
+    m_n_classes = 0;
+    for (unsigned c : obj_class) m_n_classes = std::max(m_n_classes, (int)c + 1);
+    // features in chunks of objects, gathered on the host as one DeviceFeatures for activation
+    auto all = std::make_shared<DeviceFeatures>();
+    std::vector<float> hdesc, hlrf, hkx, hky, hkz;
+    std::vector<unsigned> fclass, finst, fmodel; std::vector<std::array<float, 3>> fcenter;
+    const size_t chunk = 32;
+    const int D = m_feature_descriptor->getDescriptorLength();
+    for (size_t b = 0; b < clouds.size(); b += chunk) {
+        std::vector<const PointCloud*> part(clouds.begin() + b, clouds.begin() + std::min(clouds.size(), b + chunk));
+        auto f = computeFeatures(part, true);
+        std::vector<float> t;
+        s.d2h(t, f->desc, (size_t)f->n * D); hdesc.insert(hdesc.end(), t.begin(), t.end());
+        s.d2h(t, f->lrf, (size_t)f->n * 9); hlrf.insert(hlrf.end(), t.begin(), t.end());
+        s.d2h(t, f->kx, f->n); hkx.insert(hkx.end(), t.begin(), t.end());
+        s.d2h(t, f->ky, f->n); hky.insert(hky.end(), t.begin(), t.end());
+        s.d2h(t, f->kz, f->n); hkz.insert(hkz.end(), t.begin(), t.end());
+        for (size_t o = 0; o < part.size(); ++o) {
+            const PointCloud& c = *part[o];
+            float mn[3] = {c.x[0], c.y[0], c.z[0]}, mx[3] = {c.x[0], c.y[0], c.z[0]};
+            for (size_t i = 0; i < c.size(); ++i) {
+                mn[0] = std::min(mn[0], c.x[i]); mx[0] = std::max(mx[0], c.x[i]); mn[1] = std::min(mn[1], c.y[i]); mx[1] = std::max(mx[1], c.y[i]);
+                mn[2] = std::min(mn[2], c.z[i]); mx[2] = std::max(mx[2], c.z[i]);
+            }
+            const std::array<float, 3> center = {(mn[0] + mx[0]) * 0.5f, (mn[1] + mx[1]) * 0.5f, (mn[2] + mx[2]) * 0.5f};
+            const uint32_t cnt = f->off[o + 1] - f->off[o];
+            fclass.insert(fclass.end(), cnt, obj_class[b + o]); finst.insert(finst.end(), cnt, obj_inst[b + o]);
+            fmodel.insert(fmodel.end(), cnt, (unsigned)(b + o)); fcenter.insert(fcenter.end(), cnt, center);
+        }
+    }
+    all->dim = D; all->n = (uint32_t)fclass.size();
+    DeviceSession::h2d(all->desc, hdesc); DeviceSession::h2d(all->lrf, hlrf); DeviceSession::h2d(all->kx, hkx); DeviceSession::h2d(all->ky, hky); DeviceSession::h2d(all->kz, hkz);
+    LOG_INFO("activating codewords with " << all->n << " training features");
+    m_codebook->activate(s, *all, fclass, finst, fmodel, fcenter, met, m_n_classes);
+    LOG_INFO("training done");
+}
+
+std::vector<std::vector<VotingMaximum>> ImplicitShapeModel::detectBatch(const std::vector<const PointCloud*>& clouds) {   // detect() :583-712 over a batch
+    g_log_info = m_logging;
+    if (m_single_object_mode_legacy)
+        throw RuntimeException("The parameter for \"single object mode\" must be set inside the \"Voting\" section of the config file. You are using the \"Parameters\" section.");
+    auto t_all = std::chrono::steady_clock::now();
+    DeviceSession& s = session();
+    std::vector<const PointCloud*> nonempty;
+    std::vector<int> map;
+    for (size_t i = 0; i < clouds.size(); ++i) { if (clouds[i]->empty()) LOG_WARN("point cloud is empty"); else { map.push_back((int)i); nonempty.push_back(clouds[i]); } }
+    std::vector<std::vector<VotingMaximum>> out(clouds.size());
+    if (nonempty.empty()) return out;
+    auto f = computeFeatures(nonempty, false);
+    auto t0 = std::chrono::steady_clock::now();
+    LOG_INFO("activating codewords and casting votes");
+    m_voting->clear();
+    m_codebook->castVotes(s, *f, metric(), *m_voting);
+    s.sync();
+    auto t1 = std::chrono::steady_clock::now();
+    m_processing_times["voting"] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    LOG_INFO("finding maxima");
+    auto res = m_voting->findMaxima(s);
+    auto t2 = std::chrono::steady_clock::now();
+    m_processing_times["maxima"] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+    m_processing_times["complete"] += std::chrono::duration<double, std::milli>(t2 - t_all).count();
+    m_processing_times["normals"] += 0; m_processing_times["flann"] += 0;
+    for (size_t i = 0; i < res.size(); ++i) out[map[i]] = res[i];
+    return out;
+}
+
+std::tuple<std::vector<VotingMaximum>, std::map<std::string, double>> ImplicitShapeModel::detect(const PointCloud& pointCloud, bool hasNormals) {
+    if (pointCloud.empty()) { LOG_WARN("point cloud is empty"); return std::make_tuple(std::vector<VotingMaximum>(), m_processing_times); }
+    if (!hasNormals) throw RuntimeException("input cloud has no normals: normal estimation on the device is not built yet (SURVEY §8f row 3)");
+    auto r = detectBatch({&pointCloud});
+    LOG_INFO("detected " << r[0].size() << " maxima");
+    return std::make_tuple(r[0], m_processing_times);
+}
+bool ImplicitShapeModel::detect(const std::string& filename, std::vector<VotingMaximum>& maxima, std::map<std::string, double>& times) {   // :564-573
+    std::shared_ptr<PointCloud> c = loadPointCloud(filename);
+    if (!c) return false;
+    std::tie(maxima, times) = detect(*c, true);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// file lists (eval_tool/eval_helpers.h:60-177)
+// ---------------------------------------------------------------------------------------------------------------
+static unsigned convertLabel(const std::string& label, std::map<std::string, unsigned>& labels_map, std::map<unsigned, std::string>& labels_rmap) {
+    auto it = labels_map.find(label);
+    if (it != labels_map.end()) return it->second;
+    const unsigned id = (unsigned)labels_map.size();
+    labels_map.insert({label, id}); labels_rmap.insert({id, label});
+    return id;
+}
+FileList parseFileList(const std::string& input_file_name) {
+    FileList L;
+    std::ifstream infile(input_file_name);
+    if (!infile) throw RuntimeException("could not read file list: " + input_file_name);
+    std::string file, class_label, instance_label;
+    infile >> file; infile >> class_label; infile >> instance_label;
+    if (file == "#" && (class_label == "train" || class_label == "test")) {
+        L.mode = class_label;
+        if (instance_label == "inst") L.using_instances = true;
+        if (instance_label == "detection") throw RuntimeException("detection data sets are out of scope (eval_tool_detection)");
+    }
+    if (L.using_instances) {
+        while (infile >> file >> class_label >> instance_label) {
+            if (file[0] == '#') continue;
+            L.filenames.push_back(file);
+            const unsigned c = convertLabel(class_label, L.class_labels_map, L.class_labels_rmap);
+            const unsigned i = convertLabel(instance_label, L.instance_labels_map, L.instance_labels_rmap);
+            L.instance_to_class_map.insert({i, c});
+            L.class_labels.push_back(c); L.instance_labels.push_back(i);
+        }
+    } else {
+        file = instance_label;
+        infile >> class_label;
+        L.filenames.push_back(file);
+        L.class_labels.push_back(convertLabel(class_label, L.class_labels_map, L.class_labels_rmap));
+        while (infile >> file >> class_label) {
+            if (file[0] == '#') continue;
+            L.filenames.push_back(file);
+            const unsigned c = convertLabel(class_label, L.class_labels_map, L.class_labels_rmap);
+            L.class_labels.push_back(c);
+            L.instance_to_class_map.insert({c, c});
+        }
+        L.instance_labels = L.class_labels;
+    }
+    return L;
+}
+
+}  // namespace ism3d

@@ -1,0 +1,130 @@
+"""ctypes binding of the C++ host mirror (point-cloud-donkey_amd/libism3d_amd.so, capi_host.cpp) for the tests."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "point-cloud-donkey_amd", "libism3d_amd.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (one HIP runtime per process, see capi.lib)
+        C.CDLL(os.path.join(ROOT, "point-cloud-donkey_amd", "libismhip.so"), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(LIB)
+        L.ism3d_new.restype = C.c_void_p
+        L.ism3d_last_error.restype = C.c_char_p
+        L.ism3d_delete.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _f(a):
+    return np.ascontiguousarray(np.asarray(a, np.float32))
+
+
+def _p(a):
+    return C.c_void_p(0) if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Model:
+    def __init__(self):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.ism3d_new())
+        self.L.ism3d_set_logging(self.h, 0)
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise HostError(f"{what}: {self.L.ism3d_last_error().decode()} (rc {rc})")
+
+    def read(self, path, training=False):
+        self._ck(self.L.ism3d_read(self.h, path.encode(), int(training)), "readObject")
+
+    def write(self, path):
+        self._ck(self.L.ism3d_write(self.h, path.encode()), "writeObject")
+
+    def config_from_json(self, text):
+        self._ck(self.L.ism3d_config_from_json(self.h, text.encode()), "configFromJson")
+
+    def config_to_json(self):
+        buf = C.create_string_buffer(1 << 16)
+        self._ck(self.L.ism3d_config_to_json(self.h, buf, len(buf)), "configToJson")
+        return buf.value.decode()
+
+    def add_training(self, xyz, normals, class_id, instance_id, rgba=None):
+        x, y, z = (_f(xyz[:, i]) for i in range(3)); nx, ny, nz = (_f(normals[:, i]) for i in range(3))
+        c = None if rgba is None else np.ascontiguousarray(rgba, np.uint32)
+        self._ck(self.L.ism3d_add_training(self.h, len(x), _p(x), _p(y), _p(z), _p(nx), _p(ny), _p(nz), _p(c), class_id, instance_id), "addTrainingModel")
+
+    def add_training_file(self, path, class_id, instance_id):
+        self._ck(self.L.ism3d_add_training_file(self.h, path.encode(), class_id, instance_id), "addTrainingModel(file)")
+
+    def train(self):
+        self._ck(self.L.ism3d_train(self.h), "train")
+
+    def codebook_size(self):
+        return self.L.ism3d_codebook_size(self.h)
+
+    def codebook(self, dim, n_classes):
+        n = self.codebook_size()
+        words = np.empty((n, dim), np.float32); vx = np.empty((n * 4, 3), np.float32); vc = np.empty(n * 4, np.uint32); sg = np.empty(n_classes, np.float32)
+        nv = self.L.ism3d_codebook_get(self.h, _p(words), _p(vx), _p(vc), _p(sg))
+        return words, vx[:nv], vc[:nv], sg
+
+    def detect_batch(self, pt_off, xyz, normals, max_maxima=8, rgba=None):
+        po = np.ascontiguousarray(pt_off, np.uint32)
+        n_obj = len(po) - 1
+        x, y, z = (_f(xyz[:, i]) for i in range(3)); nx, ny, nz = (_f(normals[:, i]) for i in range(3))
+        c = None if rgba is None else np.ascontiguousarray(rgba, np.uint32)
+        n = np.empty(n_obj, np.int32); pos = np.empty((n_obj, max_maxima, 3), np.float32); w = np.empty((n_obj, max_maxima), np.float32)
+        cls = np.empty((n_obj, max_maxima), np.int32); inst = np.empty((n_obj, max_maxima), np.int32); nv = np.empty((n_obj, max_maxima), np.int32)
+        self._ck(self.L.ism3d_detect_batch(self.h, n_obj, _p(po), _p(x), _p(y), _p(z), _p(nx), _p(ny), _p(nz), _p(c), max_maxima, _p(n), _p(pos), _p(w),
+                                           _p(cls), _p(inst), _p(nv)), "detectBatch")
+        return dict(n=n, pos=pos, weight=w, cls=cls, inst=inst, n_votes=nv)
+
+    def detect_file(self, path):
+        cls, w = C.c_int32(), C.c_float()
+        self._ck(self.L.ism3d_detect_file(self.h, path.encode(), C.byref(cls), C.byref(w)), "detect(file)")
+        return cls.value, w.value
+
+    def close(self):
+        if self.h:
+            self.L.ism3d_delete(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_pcd(path, xyz, normals, rgba=None, binary=False):
+    n = len(xyz)
+    fields = ["x", "y", "z"] + (["rgb"] if rgba is not None else []) + ["normal_x", "normal_y", "normal_z", "curvature"]
+    types = ["F", "F", "F"] + (["U"] if rgba is not None else []) + ["F", "F", "F", "F"]
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\nWIDTH %d\nHEIGHT 1\n"
+           "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n") % (" ".join(fields), " ".join(["4"] * len(fields)), " ".join(types),
+                                                              " ".join(["1"] * len(fields)), n, n, "binary" if binary else "ascii")
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        if binary:
+            cols = [xyz.astype(np.float32)]
+            if rgba is not None:
+                cols.append(rgba.astype(np.uint32).view(np.float32).reshape(-1, 1))
+            cols += [normals.astype(np.float32), np.zeros((n, 1), np.float32)]
+            f.write(np.ascontiguousarray(np.concatenate(cols, axis=1)).tobytes())
+        else:
+            for i in range(n):
+                row = ["%.9g" % v for v in xyz[i]]
+                if rgba is not None:
+                    row.append(str(int(rgba[i])))
+                row += ["%.9g" % v for v in normals[i]] + ["0"]
+                f.write((" ".join(row) + "\n").encode())

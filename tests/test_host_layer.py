@@ -1,0 +1,161 @@
+"""Tests of the C++ host mirror (ism3d.h): configuration / factory / error behaviour on the CPU, and on the GPU
+train -> writeObject -> readObject -> detectBatch and the eval_tool harness against the Python harness and the labels."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import host_binding as hb
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "config", "modelnet10_shot.ism")
+
+
+def _cfg(**edits):
+    j = json.load(open(CFG))["ObjectConfig"]
+    for path, v in edits.items():
+        node = j
+        keys = path.split("/")
+        for k in keys[:-1]:
+            node = node[k]
+        node[keys[-1]] = v
+    return json.dumps(j)
+
+
+def test_config_roundtrip_defaults_and_unknown_keys():
+    m = hb.Model()
+    j = json.loads(_cfg())
+    j["Parameters"]["SetColorToZero"] = True                     # dead key in the reference's configs: silently ignored
+    del j["Children"]["Voting"]["Parameters"]["MaxIter"]         # missing key -> default 1000 (+ warning)
+    m.config_from_json(json.dumps(j))
+    out = json.loads(m.config_to_json())
+    assert out["Type"] == "ImplicitShapeModel"
+    assert out["Children"]["Features"]["Type"] == "SHOT" and abs(out["Children"]["Features"]["Parameters"]["Radius"] - 0.4) < 1e-6
+    assert out["Children"]["Voting"]["Parameters"]["MaxIter"] == 1000
+    assert out["Children"]["Codebook"]["Children"]["ActivationStrategy"]["Type"] == "KNN"
+    assert out["Children"]["Keypoints"]["Type"] == "VoxelGrid" and out["Children"]["Clustering"]["Type"] == "None"
+    assert "SetColorToZero" not in out["Parameters"]
+    m2 = hb.Model()
+    m2.config_from_json(m.config_to_json())                      # what we write, we read
+    assert json.loads(m2.config_to_json()) == out
+
+
+@pytest.mark.parametrize("cfgfile", ["modelnet10_shot.ism", "qs_chi2_shot.ism", "kinect_cshot.ism"])
+def test_shipped_configs_load(cfgfile):
+    m = hb.Model()
+    m.read(os.path.join(ROOT, "config", cfgfile), training=True)
+    out = json.loads(m.config_to_json())
+    assert out["Children"]["Features"]["Type"] in ("SHOT", "CSHOT")
+
+
+def test_config_errors_match_reference_behaviour():
+    for edits, needle in [({"Children/Features/Type": "PFH"}, "outside the MI355X hot path"),
+                          ({"Children/Voting/Type": "Hough3D"}, "not built"),
+                          ({"Children/Codebook/Children/ActivationStrategy/Type": "INN"}, "not built"),
+                          ({"Children/Clustering/Type": "KMeans"}, "out of scope"),
+                          ({"Parameters/DistanceType": "Manhattan"}, "invalid distance type"),
+                          ({"Children/Voting/Parameters/MaxIter": "many"}, "invalid type for parameter"),
+                          ({"Parameters/UseSmoothing": True}, "not built")]:
+        m = hb.Model()
+        with pytest.raises(hb.HostError) as e:
+            m.config_from_json(_cfg(**edits))
+        assert needle in str(e.value), (edits, str(e.value))
+    m = hb.Model()
+    j = json.loads(_cfg()); del j["Children"]["FeatureWeighting"]
+    with pytest.raises(hb.HostError):                            # the reference's loader rejects a config without this child too
+        m.config_from_json(json.dumps(j))
+
+
+def test_pcd_reader_ascii_and_binary(tmp_path):
+    rng = np.random.default_rng(0)
+    xyz = rng.normal(size=(50, 3)).astype(np.float32); nrm = rng.normal(size=(50, 3)).astype(np.float32)
+    rgba = rng.integers(0, 1 << 24, 50).astype(np.uint32)
+    xyz[7, 0] = np.nan                                           # NaN points are removed on load
+    for binary in (False, True):
+        p = str(tmp_path / ("c%d.pcd" % binary))
+        hb.write_pcd(p, xyz, nrm, rgba, binary=binary)
+        m = hb.Model()
+        m.config_from_json(_cfg())
+        m.add_training_file(p, 0, 0)
+    with pytest.raises(hb.HostError):
+        hb.Model().add_training_file(str(tmp_path / "missing.pcd"), 0, 0)
+
+
+def _dataset(pkg, n_classes, n_train, n_test):
+    syn = pkg.synthetic
+    train = syn.Dataset(n_classes, n_train, split=0, n_points=4096, leaf=0.2)
+    test = syn.Dataset(n_classes, n_test, split=1, n_points=4096, leaf=0.2)
+    return train, test
+
+
+@pytest.mark.gpu
+def test_host_train_write_read_detect_matches_python_harness(pkg, gpu, tmp_path):
+    import torch
+    ctx, dev = gpu
+    train, test = _dataset(pkg, 3, 9, 6)
+    order = sorted(range(9), key=lambda i: (train.label(i), i))
+    m = hb.Model()
+    m.config_from_json(_cfg())
+    for i in order:
+        o = train.get(i)
+        m.add_training(o["xyz"], o["normals"], o["label"], i)
+    m.train()
+    # the Python harness on the same data (keypoints = VoxelGrid leaf 0.2 in both)
+    cfg = pkg.pipeline.IsmConfig(n_classes=3)
+    rec = pkg.pipeline.Recognizer(ctx, cfg)
+    cb = rec.train([pkg.pipeline.DeviceBatch(train.batch(order), dev)], instance_ids=order)
+    words, vxyz, vcls, sigma = m.codebook(352, 3)
+    assert words.shape == cb["words"].shape
+    np.testing.assert_allclose(words, cb["words"], atol=1e-6)
+    np.testing.assert_allclose(vxyz, cb["vote_xyz"], atol=1e-5)
+    assert np.array_equal(vcls, cb["vote_class"])
+    np.testing.assert_allclose(sigma, cb["class_sigma"], rtol=2e-4)
+    # persistence: .ism (JSON) + .ismd
+    path = str(tmp_path / "model.ism")
+    m.write(path)
+    assert os.path.exists(str(tmp_path / "model.ismd")) and json.load(open(path))["ObjectData"] == "model.ismd"
+    m2 = hb.Model()
+    m2.read(path)
+    assert m2.codebook_size() == m.codebook_size()
+    nb = test.batch(range(6))
+    got = m2.detect_batch(nb["pt_off"], nb["xyz"], nb["normals"], max_maxima=8)
+    want = rec.detect(pkg.pipeline.DeviceBatch(nb, dev))
+    assert np.array_equal(got["n"], np.minimum(want["n"].cpu().numpy(), 8))
+    k = 4
+    assert np.array_equal(got["cls"][:, :k], want["cls"][:, :k].cpu().numpy())
+    np.testing.assert_allclose(got["weight"][:, :k], want["weight"][:, :k].cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose(got["pos"][:, :k], want["pos"][:, :k].cpu().numpy(), atol=1e-4)
+    assert (got["cls"][:, 0] == nb["labels"]).all()
+
+
+@pytest.mark.gpu
+def test_eval_tool_end_to_end(pkg, tmp_path):
+    train, test = _dataset(pkg, 3, 6, 6)
+    names = ["chair", "table", "lamp"]
+    def dump(ds, n, tag, header):
+        lines = [header]
+        for i in range(n):
+            o = ds.get(i)
+            p = str(tmp_path / f"{tag}_{i}.pcd")
+            hb.write_pcd(p, o["xyz"], o["normals"], binary=True)
+            lines.append(f"{p} {names[o['label']]}")
+        lp = str(tmp_path / f"{tag}_list.txt")
+        open(lp, "w").write("\n".join(lines) + "\n")
+        return lp
+    ltrain = dump(train, 6, "train", "# train")
+    ltest = dump(test, 6, "test", "# test")
+    tool = os.path.join(ROOT, "point-cloud-donkey_amd", "eval_tool")
+    out = str(tmp_path / "out")
+    r = subprocess.run([tool, "-t", CFG, "-f", ltrain, "-o", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    model = os.path.join(out, "modelnet10_shot.ism")
+    assert os.path.exists(model)
+    r = subprocess.run([tool, "-d", model, "-f", ltest, "-o", out, "-b", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    s = open(os.path.join(out, "summary.txt")).read()
+    assert s.count("ground truth class:") == 6 and "Accuracy: 100 %" in s and "compute features:" in s and "0: chair" in s
+    # wrong mode is refused like the reference does
+    r = subprocess.run([tool, "-d", model, "-f", ltrain, "-o", out], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
