@@ -154,6 +154,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_objects > 0:
         ora = ge.load_oracle()
+        n_thr = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1)
+        ora.set_num_threads(n_thr)
         nb = test.batch(list(range(args.cpu_objects)))
         xyz, nrm, kp = nb["xyz"], nb["normals"], nb["kp"]
         t0 = time.perf_counter()
