@@ -10,8 +10,8 @@
 // Structure per wave: stream the candidate x-runs of the query ball (coalesced SoA loads of the cell-sorted
 // cloud); lanes whose point is inside the ball are COMPACTED with a ballot + prefix popcount into a 128-entry
 // LDS queue; whenever 64 are queued, all 64 lanes run the per-neighbour math on a full wave (no divergence on
-// the radius test) and deposit into a per-wave LDS histogram with ds_add_f32. The wave then L2-normalises and
-// writes the row with coalesced stores.
+// the radius test) and deposit into a per-wave LDS histogram (64-bit fixed point, ds_add_u64 — see ShotSmem). The wave then
+// L2-normalises and writes the row with coalesced stores.
 #include "common.h"
 
 uint32_t* ism_upload_offsets(ismhip_ctx* ctx, int slot, const uint32_t* off_h, int n);
@@ -32,17 +32,30 @@ struct ShotArgs {
     float* desc; uint32_t* count;
 };
 
+// The per-wave LDS histogram is kept in 64-bit FIXED POINT (2^-28 units) and updated with ds_add_u64.
+// Measured on gfx950 (tools/lds_atomic_bench.hip): ds_add_f32 costs ~195 CU-cycles per wave-instruction whatever the
+// addresses, ds_add_u64 17-24, ds_add_u32 15 — with float atomics the kernel spent 64 % of its wave cycles in
+// SQ_WAIT_INST_LDS. Every deposit is a non-negative interpolation weight < 8, so round(v * 2^28) fits 32 bits and a bin
+// (<= 4 * 2^14 neighbours) needs 46 bits. Integer adds are associative: the histogram no longer depends on the order in
+// which neighbours arrive (bitwise reproducible), and its error (<= 2^-29 per deposit) is far below the float
+// accumulation error of the reference itself.
+#define SHOT_FIX_SCALE 268435456.0f          /* 2^28 */
+#define SHOT_FIX_INV   3.7252902984619140625e-09 /* 2^-28 */
+typedef unsigned long long shot_bin_t;
 template <bool COLOR>
 struct ShotSmem {
-    float hist[4][COLOR ? 1344 : 352];
-    float qd[4][128][3];     // dx, dy, dz of queued neighbours
-    float qd2[4][128];
+    static constexpr int D = COLOR ? 1344 : 352;
+    shot_bin_t hist[4][D];
+    float4 qd[4][128];       // dx, dy, dz, d2 of queued neighbours
     uint32_t qi[4][128];     // sorted index of queued neighbours
 };
+__device__ __forceinline__ void shot_dep(shot_bin_t* hist, int bin, float v) {
+    atomicAdd(&hist[bin], (shot_bin_t)__float2uint_rn(v * SHOT_FIX_SCALE));
+}
 
 // Per-neighbour SHOT update. All 64 lanes call it; 'act' marks lanes that hold a neighbour.
 template <bool COLOR>
-__device__ __forceinline__ void shot_neighbour(const ShotArgs& a, float* hist, bool act, uint32_t gi,
+__device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hist, bool act, uint32_t gi,
                                                float dx, float dy, float dz, float d2,
                                                const float fx[3], const float fy[3], const float fz[3],
                                                float r12, float r14, float r34, float inv_r12,
@@ -75,8 +88,8 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, float* hist, b
     const int vol = di * 11;
     bd -= (float)step;
     float w_shape = 1.f - fabsf(bd);
-    if (bd > 0.f) atomicAdd(&hist[vol + ((step + 1) % 10)], bd);
-    else atomicAdd(&hist[vol + ((step - 1 + 10) % 10)], -bd);
+    if (bd > 0.f) shot_dep(hist, vol + ((step + 1) % 10), bd);
+    else shot_dep(hist, vol + ((step - 1 + 10) % 10), -bd);
 
     int step_c = 0, vol_c = 0; float w_col = 0.f;
     if (COLOR) {
@@ -88,13 +101,13 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, float* hist, b
         vol_c = 352 + di * 31;
         bc -= (float)step_c;
         w_col = 1.f - fabsf(bc);
-        if (bc > 0.f) atomicAdd(&hist[vol_c + ((step_c + 1) % 30)], bc);
-        else atomicAdd(&hist[vol_c + ((step_c - 1 + 30) % 30)], -bc);
+        if (bc > 0.f) shot_dep(hist, vol_c + ((step_c + 1) % 30), bc);
+        else shot_dep(hist, vol_c + ((step_c - 1 + 30) % 30), -bc);
     }
 #define SHOT_DEP(sector, v)                                                          \
     do {                                                                             \
-        atomicAdd(&hist[(sector) * 11 + step], (v));                                 \
-        if (COLOR) atomicAdd(&hist[352 + (sector) * 31 + step_c], (v));              \
+        shot_dep(hist, (sector) * 11 + step, (v));                                   \
+        if (COLOR) shot_dep(hist, 352 + (sector) * 31 + step_c, (v));                \
     } while (0)
     float winc = 0.f;
     // radial
@@ -130,8 +143,8 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, float* hist, b
         else { winc += 1.f + ad; SHOT_DEP((di - 4 + 32) % 32, -ad); }
     }
 #undef SHOT_DEP
-    atomicAdd(&hist[vol + step], w_shape + winc);
-    if (COLOR) atomicAdd(&hist[vol_c + step_c], w_col + winc);
+    shot_dep(hist, vol + step, w_shape + winc);
+    if (COLOR) shot_dep(hist, vol_c + step_c, w_col + winc);
 }
 
 __device__ __forceinline__ void rgb2lab_norm(const float* lut_srgb, const float* lut_sxyz, uint32_t c4, float& L, float& A, float& B) {
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
     const int lane = lane_id();
     const uint32_t k = a.kp_off[o] + blockIdx.x * 4 + wv;
     if (k >= a.kp_off[o + 1]) return;          // wave-uniform; no block-level barrier below
-    float* hist = sm.hist[wv];
+    shot_bin_t* hist = sm.hist[wv];
     float* out = a.desc + (size_t)k * D;
     const float cx = a.kx[k], cy = a.ky[k], cz = a.kz[k];
     const float* f = a.lrf + (size_t)k * 9;
@@ -171,7 +184,7 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
         if (a.count && lane == 0) a.count[k] = 0;
         return;
     }
-    for (int i = lane; i < D; i += 64) hist[i] = 0.f;
+    for (int i = lane; i < D; i += 64) hist[i] = 0ull;
     float LRef = 0.f, aRef = 0.f, bRef = 0.f;
     if (COLOR) rgb2lab_norm(a.lut_srgb, a.lut_sxyz, a.kp_rgba[k], LRef, aRef, bRef);
     const float r12 = a.radius * 0.5f, r14 = a.radius * 0.25f, r34 = (a.radius * 3.0f) * 0.25f, inv_r12 = 1.0f / r12;
@@ -194,33 +207,26 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
                 const unsigned long long mask = __ballot(pass);
                 if (pass) {
                     const uint32_t pos = qn + __popcll(mask & ((1ull << lane) - 1ull));
-                    sm.qd[wv][pos][0] = dx; sm.qd[wv][pos][1] = dy; sm.qd[wv][pos][2] = dz;
-                    sm.qd2[wv][pos] = d2; sm.qi[wv][pos] = base + i;
+                    sm.qd[wv][pos] = make_float4(dx, dy, dz, d2); sm.qi[wv][pos] = base + i;
                 }
                 const uint32_t c = __popcll(mask);
                 qn += c; total += c;
                 if (qn >= 64) {
                     // a full wave of neighbours (LDS traffic of one wave is ordered; no barrier needed)
-                    shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][lane], sm.qd[wv][lane][0], sm.qd[wv][lane][1], sm.qd[wv][lane][2],
-                                          sm.qd2[wv][lane], fx, fy, fz, r12, r14, r34, inv_r12, LRef, aRef, bRef);
+                    const float4 e = sm.qd[wv][lane];
+                    shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][lane], e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, LRef, aRef, bRef);
                     const uint32_t rem = qn - 64;
-                    float t0x = 0, t0y = 0, t0z = 0, t0d = 0; uint32_t t0i = 0;
-                    if ((uint32_t)lane < rem) {
-                        t0x = sm.qd[wv][64 + lane][0]; t0y = sm.qd[wv][64 + lane][1]; t0z = sm.qd[wv][64 + lane][2];
-                        t0d = sm.qd2[wv][64 + lane]; t0i = sm.qi[wv][64 + lane];
-                    }
-                    if ((uint32_t)lane < rem) {
-                        sm.qd[wv][lane][0] = t0x; sm.qd[wv][lane][1] = t0y; sm.qd[wv][lane][2] = t0z;
-                        sm.qd2[wv][lane] = t0d; sm.qi[wv][lane] = t0i;
-                    }
+                    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f); uint32_t t0i = 0;
+                    if ((uint32_t)lane < rem) { t4 = sm.qd[wv][64 + lane]; t0i = sm.qi[wv][64 + lane]; }
+                    if ((uint32_t)lane < rem) { sm.qd[wv][lane] = t4; sm.qi[wv][lane] = t0i; }
                     qn = rem;
                 }
             }
         }
     if (qn > 0) {
         const bool act = (uint32_t)lane < qn;
-        shot_neighbour<COLOR>(a, hist, act, act ? sm.qi[wv][lane] : 0u, sm.qd[wv][lane][0], sm.qd[wv][lane][1], sm.qd[wv][lane][2],
-                              sm.qd2[wv][lane], fx, fy, fz, r12, r14, r34, inv_r12, LRef, aRef, bRef);
+        const float4 e = sm.qd[wv][lane];
+        shot_neighbour<COLOR>(a, hist, act, act ? sm.qi[wv][lane] : 0u, e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, LRef, aRef, bRef);
     }
     if (a.count && lane == 0) a.count[k] = total;
     if (total < 5) {                                    // computePointSHOT: fewer than 5 neighbours -> NaN descriptor
@@ -229,10 +235,10 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
     }
     // normalizeHistogram: double accumulate of float squares, divide by float(norm)
     double acc = 0.0;
-    for (int i = lane; i < D; i += 64) { const float v = hist[i]; acc += (double)(v * v); }
+    for (int i = lane; i < D; i += 64) { const float v = (float)((double)hist[i] * SHOT_FIX_INV); acc += (double)(v * v); }
     acc = wave_sum_d(acc);
     const float fn = (float)sqrt(acc);
-    for (int i = lane; i < D; i += 64) out[i] = hist[i] / fn;
+    for (int i = lane; i < D; i += 64) out[i] = (float)((double)hist[i] * SHOT_FIX_INV) / fn;
 }
 
 template <bool COLOR>

@@ -81,7 +81,7 @@ class Recognizer:
     # -- ImplicitShapeModel::computeFeatures step f + removeNaNFeatures -------------------------------------
     def compute_features(self, b: DeviceBatch, want_counts=False):
         c, ctx = self.cfg, self.ctx
-        cell = max(c.radius, c.lrf_radius if c.feature != "FPFH" else c.radius) * 0.5
+        cell = min(c.radius, c.lrf_radius if c.feature != "FPFH" else c.radius) * 0.5
         cloud = capi.Cloud(ctx, b.pt_off, b.x, b.y, b.z, b.nx, b.ny, b.nz, cell, rgba=b.rgba if c.feature == "CSHOT" else None)
         lrf = capi.shot_lrf(ctx, cloud, b.kp_off, b.kx, b.ky, b.kz, c.lrf_radius)   # Features::operator() always computes LRFs
         if c.feature == "SHOT":
