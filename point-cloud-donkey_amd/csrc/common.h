@@ -85,7 +85,7 @@ struct ismhip_ctx {
 enum ScratchSlot {
     SCR_KP_OFF = 1, SCR_TIE_LIST, SCR_TIE_REC, SCR_TIE_KEYS, SCR_COUNTERS, SCR_KNN_CAND_IDX, SCR_KNN_CAND_VAL,
     SCR_QNORM, SCR_FPFH_FLAG, SCR_FPFH_LIST, SCR_FPFH_SPFH, SCR_FPFH_LOOKUP, SCR_SLOT_OFF, SCR_CLASS_BW,
-    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD
+    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV
 };
 
 int  ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg);
@@ -163,5 +163,23 @@ __device__ __forceinline__ bool ball_cells(const GridMeta& m, float qx, float qy
         cr.hi[a] = h > m.dim[a] - 1 ? m.dim[a] - 1 : h;
     }
     return true;
+}
+
+// Clips the x cell range of one (gy, gz) cell row to the chord of the ball (q, r) in that row. Conservative: the padding
+// absorbs the float rounding of the cell bounds and of the point binning. Returns false when the row misses the ball.
+__device__ __forceinline__ bool row_cells(const GridMeta& m, const CellRange& cr, int gy, int gz,
+                                          float qx, float qy, float qz, float r, int& lo, int& hi) {
+    const float pad = r * 2e-5f + (fabsf(qx) + fabsf(qy) + fabsf(qz)) * 1e-6f + 1e-30f;
+    const float y0 = m.minv[1] + (float)gy * m.cell, z0 = m.minv[2] + (float)gz * m.cell;
+    const float dy = fmaxf(fmaxf(y0 - qy, qy - (y0 + m.cell)) - pad, 0.f);
+    const float dz = fmaxf(fmaxf(z0 - qz, qz - (z0 + m.cell)) - pad, 0.f);
+    const float rr = r + pad;
+    const float rem = rr * rr - (dy * dy + dz * dz);
+    if (!(rem > 0.f)) return false;
+    const float hc = sqrtf(rem) + pad;
+    int l = (int)floorf((qx - hc - m.minv[0]) * m.inv_cell), h = (int)floorf((qx + hc - m.minv[0]) * m.inv_cell);
+    lo = l < cr.lo[0] ? cr.lo[0] : l;
+    hi = h > cr.hi[0] ? cr.hi[0] : h;
+    return lo <= hi;
 }
 #endif

@@ -38,8 +38,10 @@ __global__ __launch_bounds__(256) void k_fpfh_mark(FpfhArgs a) {
         const uint32_t base = a.pt_off[o];
         for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
             for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+                int xl, xh;
+                if (!row_cells(m, cr, gy, gz, cx, cy, cz, a.radius, xl, xh)) continue;
                 const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-                const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+                const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
                 for (uint32_t t = s + lane; t < e; t += 64) {
                     const float d2 = sqdist3(a.sx[base + t], a.sy[base + t], a.sz[base + t], cx, cy, cz);
                     if (d2 < a.r2) { a.flag[base + t] = 1; total++; }
@@ -99,8 +101,10 @@ __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
     uint32_t total = 0;
     for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
         for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+            int xl, xh;
+            if (!row_cells(m, cr, gy, gz, px, py, pz, a.radius, xl, xh)) continue;
             const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-            const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+            const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
             for (uint32_t t = s + lane; t < e; t += 64) {
                 const float qx = a.sx[base + t], qy = a.sy[base + t], qz = a.sz[base + t];
                 const float d2 = sqdist3(qx, qy, qz, px, py, pz);
@@ -143,8 +147,10 @@ __global__ __launch_bounds__(256) void k_fpfh_sum(FpfhArgs a) {
     uint32_t total = 0;
     for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
         for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+            int xl, xh;
+            if (!row_cells(m, cr, gy, gz, cx, cy, cz, a.radius, xl, xh)) continue;
             const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-            const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+            const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
             for (uint32_t t0 = s; t0 < e; t0 += 64) {
                 const uint32_t i = t0 + lane;
                 bool pass = false; float d2 = 0.f;

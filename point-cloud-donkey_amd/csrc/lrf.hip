@@ -1,13 +1,17 @@
-// lrf.hip — SHOT local reference frames, one 64-lane wavefront per keypoint.
+// lrf.hip — SHOT local reference frames.
 // Reference seam: Features::computeSHOTReferenceFrames (features/features.cpp:238-252) ->
 // pcl::SHOTLocalReferenceFrameEstimationOMP; arithmetic as third_party/pcl_shot_na_lrf/shot_na_lrf.hpp:48-178
 // with upstream's z-sign rule (vij . v3 >= 0), SURVEY Appendix A.1.
 //
 // Roofline: HBM-bound gather, algorithmic bytes = sum_k M'_k * 12 + K * 48.
-// Pass 1 streams the candidate x-runs of the query ball (coalesced SoA loads of the cell-sorted cloud),
-// accumulates the weighted covariance per lane in FP64 and wave-reduces it; every lane then runs the same
-// 3x3 Jacobi solve; pass 2 re-streams the runs and counts the sign votes with ballots. Keypoints whose sign
-// vote ties (needs the 5 median neighbours BY DISTANCE, shot_na_lrf.hpp:139-151) are queued for k_lrf_tie.
+// Four small kernels instead of one fat one (the fused version needed 245 VGPRs -> 2 waves/SIMD and sat 51 % of its
+// wave cycles in s_waitcnt):
+//   k_lrf_cov  : wave per keypoint, streams the clipped candidate runs (coalesced SoA loads of the cell-sorted cloud),
+//                FP64 weighted covariance per lane + wave reduction -> 8 doubles per keypoint
+//   k_lrf_eig  : thread per keypoint, cyclic Jacobi 3x3 (eigen3.h) -> x / z axis candidates
+//   k_lrf_sign : wave per keypoint, re-streams the runs, counts the sign votes, writes the frame or queues a tie
+//   k_lrf_tie  : work-queue kernel for sign ties (~3 % of keypoints): the 5 median neighbours BY DISTANCE decide
+//                (shot_na_lrf.hpp:139-151); rank selection by bitwise bisection over 64-bit (d^2, index) keys
 #include "common.h"
 #include "eigen3.h"
 
@@ -38,23 +42,29 @@ __device__ __forceinline__ void write_lrf(float* out, const double v1[3], const 
     out[6] = zf[0]; out[7] = zf[1]; out[8] = zf[2];
 }
 
-__global__ __launch_bounds__(256) void k_lrf(CloudView cv, const uint32_t* __restrict__ kp_off,
-                                             const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ kz,
-                                             float radius, float r2, float* __restrict__ lrf_out,
-                                             uint32_t* __restrict__ tie_count, TieRec* __restrict__ tie_rec) {
+// sqrt(double(d2)) to full double precision from the float estimate + one Newton step (v_sqrt_f64 is slow)
+__device__ __forceinline__ double sqrt_f32_as_f64(float d2) {
+    if (d2 <= 0.f) return 0.0;
+    const float s0f = sqrtf(d2);
+    const double s0 = (double)s0f, x = (double)d2;
+    return s0 + (x - s0 * s0) * (double)(0.5f / s0f);
+}
+
+// cov_out[k*8 + 0..6] = c00,c01,c02,c11,c12,c22,sum ; [7] = number of valid neighbours (as double), -1 = no search possible
+__global__ __launch_bounds__(256) void k_lrf_cov(CloudView cv, const uint32_t* __restrict__ kp_off,
+                                                 const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ kz,
+                                                 float radius, float r2, double* __restrict__ cov_out) {
     const int o = blockIdx.y;
     const uint32_t k = kp_off[o] + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= kp_off[o + 1]) return;
     const int lane = lane_id();
-    float* out = lrf_out + (size_t)k * 9;
     const float cx = kx[k], cy = ky[k], cz = kz[k];
     const GridMeta m = cv.meta[o];
     const uint32_t* cs = cv.cell_start + (size_t)o * ISM_GRID_STRIDE;
     const uint32_t base = cv.pt_off[o];
     CellRange cr;
-    const bool finite_q = isfinite(cx) && isfinite(cy) && isfinite(cz);
-    if (!finite_q || !ball_cells(m, cx, cy, cz, radius, cr)) {
-        if (lane < 9) out[lane] = __builtin_nanf("");
+    if (!(isfinite(cx) && isfinite(cy) && isfinite(cz)) || !ball_cells(m, cx, cy, cz, radius, cr)) {
+        if (lane == 0) cov_out[(size_t)k * 8 + 7] = -1.0;
         return;
     }
     double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, sum = 0;
@@ -62,16 +72,19 @@ __global__ __launch_bounds__(256) void k_lrf(CloudView cv, const uint32_t* __res
     const double rd = (double)radius;
     for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
         for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+            int xl, xh;
+            if (!row_cells(m, cr, gy, gz, cx, cy, cz, radius, xl, xh)) continue;
             const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-            const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+            const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
             for (uint32_t t = s + lane; t < e; t += 64) {
                 const float px = cv.sx[base + t], py = cv.sy[base + t], pz = cv.sz[base + t];
                 const float d2 = sqdist3(px, py, pz, cx, cy, cz);
                 if (d2 < r2 && !(px == cx && py == cy && pz == cz)) {
                     const double vx = (double)(px - cx), vy = (double)(py - cy), vz = (double)(pz - cz);
-                    const double w = rd - sqrt((double)d2);
-                    c00 += w * (vx * vx); c01 += w * (vx * vy); c02 += w * (vx * vz);
-                    c11 += w * (vy * vy); c12 += w * (vy * vz); c22 += w * (vz * vz);
+                    const double w = rd - sqrt_f32_as_f64(d2);
+                    const double wx = w * vx, wy = w * vy, wz = w * vz;
+                    c00 = fma(wx, vx, c00); c01 = fma(wx, vy, c01); c02 = fma(wx, vz, c02);
+                    c11 = fma(wy, vy, c11); c12 = fma(wy, vz, c12); c22 = fma(wz, vz, c22);
                     sum += w; valid++;
                 }
             }
@@ -79,24 +92,63 @@ __global__ __launch_bounds__(256) void k_lrf(CloudView cv, const uint32_t* __res
     c00 = wave_sum_d(c00); c01 = wave_sum_d(c01); c02 = wave_sum_d(c02);
     c11 = wave_sum_d(c11); c12 = wave_sum_d(c12); c22 = wave_sum_d(c22);
     sum = wave_sum_d(sum); valid = wave_sum_i(valid);
-    if (valid < 5) {
-        if (lane < 9) out[lane] = __builtin_nanf("");
-        return;
+    if (lane == 0) {
+        double* c = cov_out + (size_t)k * 8;
+        c[0] = c00; c[1] = c01; c[2] = c02; c[3] = c11; c[4] = c12; c[5] = c22; c[6] = sum; c[7] = (double)valid;
     }
-    double A[3][3] = {{c00 / sum, c01 / sum, c02 / sum}, {c01 / sum, c11 / sum, c12 / sum}, {c02 / sum, c12 / sum, c22 / sum}};
+}
+
+// axes_out[k*6 + 0..2] = x candidate (largest eigenvalue), [3..5] = z candidate (smallest); invalid frames are written as NaN
+__global__ __launch_bounds__(256) void k_lrf_eig(uint32_t nkp, const double* __restrict__ cov, double* __restrict__ axes_out,
+                                                 float* __restrict__ lrf_out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nkp) return;
+    const double* c = cov + (size_t)k * 8;
+    const double valid = c[7];
+    bool bad = valid < 5.0;                                                   // shot_na_lrf.hpp:80-86
     double w[3], V[3][3];
-    eigen_sym3(A, w, V);
-    if (!(isfinite(w[0]) && isfinite(w[1]) && isfinite(w[2]))) {
-        if (lane < 9) out[lane] = __builtin_nanf("");
+    if (!bad) {
+        const double sum = c[6];
+        double A[3][3] = {{c[0] / sum, c[1] / sum, c[2] / sum}, {c[1] / sum, c[3] / sum, c[4] / sum}, {c[2] / sum, c[4] / sum, c[5] / sum}};
+        eigen_sym3(A, w, V);
+        bad = !(isfinite(w[0]) && isfinite(w[1]) && isfinite(w[2]));
+    }
+    double* a = axes_out + (size_t)k * 6;
+    if (bad) {
+        for (int i = 0; i < 9; ++i) lrf_out[(size_t)k * 9 + i] = __builtin_nanf("");
+        a[0] = __builtin_nan("");
         return;
     }
-    double v1[3] = {V[0][2], V[1][2], V[2][2]};
-    double v3[3] = {V[0][0], V[1][0], V[2][0]};
+    a[0] = V[0][2]; a[1] = V[1][2]; a[2] = V[2][2];
+    a[3] = V[0][0]; a[4] = V[1][0]; a[5] = V[2][0];
+}
+
+__global__ __launch_bounds__(256, 4) void k_lrf_sign(CloudView cv, const uint32_t* __restrict__ kp_off,
+                                                  const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ kz,
+                                                  float radius, float r2, const double* __restrict__ cov, const double* __restrict__ axes,
+                                                  float* __restrict__ lrf_out, uint32_t* __restrict__ tie_count, TieRec* __restrict__ tie_rec) {
+    const int o = blockIdx.y;
+    const uint32_t k = kp_off[o] + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= kp_off[o + 1]) return;
+    const double* a = axes + (size_t)k * 6;
+    if (isnan(a[0]) || cov[(size_t)k * 8 + 7] < 5.0) return;             // frame already written as NaN
+    const int lane = lane_id();
+    const int valid = (int)cov[(size_t)k * 8 + 7];
+    double v1[3] = {a[0], a[1], a[2]}, v3[3] = {a[3], a[4], a[5]};
+    const float cx = kx[k], cy = ky[k], cz = kz[k];
+    const GridMeta m = cv.meta[o];
+    const uint32_t* cs = cv.cell_start + (size_t)o * ISM_GRID_STRIDE;
+    const uint32_t base = cv.pt_off[o];
+    CellRange cr;
+    ball_cells(m, cx, cy, cz, radius, cr);
     int plusT = 0, plusN = 0;
     for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
         for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+            int xl, xh;
+            if (!row_cells(m, cr, gy, gz, cx, cy, cz, radius, xl, xh)) continue;
             const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-            const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+            const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
+#pragma unroll 1
             for (uint32_t t = s + lane; t < e; t += 64) {
                 const float px = cv.sx[base + t], py = cv.sy[base + t], pz = cv.sz[base + t];
                 const float d2 = sqdist3(px, py, pz, cx, cy, cz);
@@ -121,21 +173,22 @@ __global__ __launch_bounds__(256) void k_lrf(CloudView cv, const uint32_t* __res
         }
         return;   // finished by k_lrf_tie
     }
-    if (lane == 0) write_lrf(out, v1, v3);
+    if (lane == 0) write_lrf(lrf_out + (size_t)k * 9, v1, v3);
 }
 
-// Sign ties: the 5 neighbours around the median BY DISTANCE decide (ascending (d^2, index) order).
-// One wave per queued keypoint; keys = (d2 bits << 32 | original index) in a per-wave global scratch.
-__global__ __launch_bounds__(256) void k_lrf_tie(CloudView cv, const float* __restrict__ kx, const float* __restrict__ ky,
+#define TIE_LDS_KEYS 2048
+__global__ __launch_bounds__(128) void k_lrf_tie(CloudView cv, const float* __restrict__ kx, const float* __restrict__ ky,
                                                  const float* __restrict__ kz, float radius, float r2,
                                                  float* __restrict__ lrf_out, const uint32_t* __restrict__ tie_count,
                                                  const TieRec* __restrict__ tie_rec, unsigned long long* __restrict__ keys,
                                                  uint32_t key_cap) {
+    // keys live in LDS when the neighbourhood fits (the common case), else in a per-wave global scratch row
+    __shared__ unsigned long long s_keys[2][TIE_LDS_KEYS];
     const int lane = lane_id();
-    const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t nw = gridDim.x * 4;
+    const uint32_t gw = blockIdx.x * 2 + (threadIdx.x >> 6);
+    const uint32_t nw = gridDim.x * 2;
     const uint32_t n_tie = *tie_count;
-    unsigned long long* mykeys = keys + (size_t)gw * key_cap;
+    unsigned long long* gkeys = keys + (size_t)gw * key_cap;
     for (uint32_t t = gw; t < n_tie; t += nw) {
         const TieRec r = tie_rec[t];
         const int o = (int)r.obj;
@@ -146,11 +199,16 @@ __global__ __launch_bounds__(256) void k_lrf_tie(CloudView cv, const float* __re
         const uint32_t base = cv.pt_off[o];
         CellRange cr;
         ball_cells(m, cx, cy, cz, radius, cr);
+        // r.valid neighbours will be collected (same test as k_lrf_cov): choose the key store up front (wave-uniform)
+        unsigned long long* mykeys = r.valid <= TIE_LDS_KEYS ? s_keys[threadIdx.x >> 6] : gkeys;
+        const uint32_t cap = r.valid <= TIE_LDS_KEYS ? (uint32_t)TIE_LDS_KEYS : key_cap;
         uint32_t n = 0;
         for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
             for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+                int xl, xh;
+                if (!row_cells(m, cr, gy, gz, cx, cy, cz, radius, xl, xh)) continue;
                 const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-                const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+                const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
                 for (uint32_t t0 = s; t0 < e; t0 += 64) {
                     const uint32_t i = t0 + lane;
                     bool pass = false; float d2 = 0.f; uint32_t orig = 0;
@@ -163,13 +221,13 @@ __global__ __launch_bounds__(256) void k_lrf_tie(CloudView cv, const float* __re
                     const unsigned long long mask = __ballot(pass);
                     if (pass) {
                         const uint32_t pos = n + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (pos < key_cap) mykeys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | orig;
+                        if (pos < cap) mykeys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | orig;
                     }
                     n += __popcll(mask);
                 }
             }
         __threadfence_block();
-        if (n > key_cap) n = key_cap;   // cannot happen: key_cap = largest object
+        if (n > cap) n = cap;   // cannot happen: n == r.valid <= cap
         // rank selection by bitwise bisection: the element of rank t is the largest v with #(key < v) <= t.
         // Keys are (positive float bits << 32 | index < key_cap): only bits 62..32 and the low index bits can be set.
         const int median = (int)n / 2;
@@ -223,23 +281,31 @@ extern "C" int ismhip_shot_lrf(ismhip_ctx* ctx, const ismhip_cloud* cloud, const
         if (kp_offsets_h[o + 1] < kp_offsets_h[o]) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "shot_lrf: offsets not monotone");
         maxk = std::max(maxk, kp_offsets_h[o + 1] - kp_offsets_h[o]);
     }
-    const uint32_t nkp = kp_offsets_h[n_obj] - kp_offsets_h[0];
+    if (kp_offsets_h[0] != 0) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "shot_lrf: offsets must start at 0");
+    const uint32_t nkp = kp_offsets_h[n_obj];
     if (nkp == 0 || maxk == 0) return ISMHIP_OK;
     uint32_t* ko = ism_upload_offsets(ctx, SCR_KP_OFF, kp_offsets_h, n_obj + 1);
     if (!ko) return ISMHIP_ERR_HIP;
     uint32_t* tie_count = (uint32_t*)ism_scratch(ctx, SCR_COUNTERS, 64);
     TieRec* tie_rec = (TieRec*)ism_scratch(ctx, SCR_TIE_REC, (size_t)nkp * sizeof(TieRec));
-    const int tie_blocks = 128;   // 512 waves
+    double* cov = (double*)ism_scratch(ctx, SCR_LRF_COV, (size_t)nkp * 14 * sizeof(double));
+    const int tie_blocks = 512;   // 1024 waves of 2-wave workgroups
     const uint32_t key_cap = cloud->max_pts ? cloud->max_pts : 1;
-    unsigned long long* keys = (unsigned long long*)ism_scratch(ctx, SCR_TIE_KEYS, (size_t)tie_blocks * 4 * key_cap * 8);
-    if (!tie_count || !tie_rec || !keys) return ISMHIP_ERR_NOMEM;
+    unsigned long long* keys = (unsigned long long*)ism_scratch(ctx, SCR_TIE_KEYS, (size_t)tie_blocks * 2 * key_cap * 8);
+    if (!tie_count || !tie_rec || !keys || !cov) return ISMHIP_ERR_NOMEM;
+    double* axes = cov + (size_t)nkp * 8;
     CloudView cv{cloud->pt_off, cloud->meta, cloud->cell_start, cloud->sx, cloud->sy, cloud->sz, cloud->sorig, cloud->x, cloud->y, cloud->z};
     const float r2 = (float)((double)radius * (double)radius);   // PCL: static_cast<float>(radius*radius) with double radius
     TimerScope ts(ctx, "lrf");
     ISM_HIP(ctx, hipMemsetAsync(tie_count, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_lrf, dim3((maxk + 3) / 4, n_obj), dim3(256), 0, ctx->stream, cv, ko, kpx, kpy, kpz, radius, r2, lrf9_out, tie_count, tie_rec);
-    ISM_CHECK_LAUNCH(ctx, "k_lrf");
-    hipLaunchKernelGGL(k_lrf_tie, dim3(tie_blocks), dim3(256), 0, ctx->stream, cv, kpx, kpy, kpz, radius, r2, lrf9_out, tie_count, tie_rec, keys, key_cap);
+    const dim3 grid((maxk + 3) / 4, n_obj);
+    hipLaunchKernelGGL(k_lrf_cov, grid, dim3(256), 0, ctx->stream, cv, ko, kpx, kpy, kpz, radius, r2, cov);
+    ISM_CHECK_LAUNCH(ctx, "k_lrf_cov");
+    hipLaunchKernelGGL(k_lrf_eig, dim3((nkp + 255) / 256), dim3(256), 0, ctx->stream, nkp, cov, axes, lrf9_out);
+    ISM_CHECK_LAUNCH(ctx, "k_lrf_eig");
+    hipLaunchKernelGGL(k_lrf_sign, grid, dim3(256), 0, ctx->stream, cv, ko, kpx, kpy, kpz, radius, r2, cov, axes, lrf9_out, tie_count, tie_rec);
+    ISM_CHECK_LAUNCH(ctx, "k_lrf_sign");
+    hipLaunchKernelGGL(k_lrf_tie, dim3(tie_blocks), dim3(128), 0, ctx->stream, cv, kpx, kpy, kpz, radius, r2, lrf9_out, tie_count, tie_rec, keys, key_cap);
     ISM_CHECK_LAUNCH(ctx, "k_lrf_tie");
     return ISMHIP_OK;
 }

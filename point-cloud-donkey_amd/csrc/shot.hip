@@ -193,8 +193,10 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
     uint32_t qn = 0, total = 0;
     for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
         for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
+            int xl, xh;
+            if (!row_cells(m, cr, gy, gz, cx, cy, cz, a.radius, xl, xh)) continue;
             const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-            const uint32_t s = cs[rb + cr.lo[0]], e = cs[rb + cr.hi[0] + 1];
+            const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
             for (uint32_t t0 = s; t0 < e; t0 += 64) {
                 const uint32_t i = t0 + lane;
                 bool pass = false; float dx = 0, dy = 0, dz = 0, d2 = 0;
