@@ -51,7 +51,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ        # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -104,18 +105,18 @@ def main():
     torch.cuda.synchronize()
     ctx.timers_enable(True)
     ctx.timers_reset()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out, g = step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -187,7 +188,7 @@ def main():
             "accuracy_last_step": round(correct / max(1, total), 4), "train_seconds": round(t_train, 1),
         }
         print(json.dumps(line))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

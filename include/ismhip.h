@@ -142,6 +142,9 @@ int  ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* 
                             const float* vote_bbox_size_h,       /* [n_votes*3], NULL = 0 */
                             int n_classes, const float* class_sigma_h, /* [n_classes] variance per class id */
                             ismhip_codebook** out);
+/* Codeword::getClassId per word (codebook/codeword.h:73-75; only meaningful for one-feature codewords). Default when not set:
+ * the class of the word's first stored vote. Needed by ismhip_knn_rule only. */
+int  ismhip_codebook_set_word_class(ismhip_ctx* ctx, ismhip_codebook* cb, const uint32_t* word_class_h);
 int  ismhip_codebook_destroy(ismhip_ctx* ctx, ismhip_codebook* cb);
 int  ismhip_codebook_max_votes_per_word(const ismhip_codebook* cb);
 
@@ -154,6 +157,12 @@ int  ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, 
 /* distance-ratio test of activateKNN (:74-85), k must be 1: needs the 2-NN; idx -> -1 when d1/d2 > threshold */
 int  ismhip_knn_ratio(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q,
                       float ratio_threshold, int32_t* idx_out, float* dist_out);
+
+/* ActivationStrategyKnnRule::activateKNN at detection time (activation_strategy/activation_strategy_knn_rule.h:41-152): exact
+ * 3-NN, then the class-consistency rules over (c1,c2,c3) with the ratio tests d1/d3 and d1/d2; idx_out[nq] = accepted codeword
+ * row (k1 or k2) or -1, dist_out[nq] = its functor distance. (At training time the rule is plain 1-NN: use ismhip_knn.) */
+int  ismhip_knn_rule(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q,
+                     float ratio_threshold, int32_t* idx_out, float* dist_out);
 
 /* ---- vote casting: Codebook::castVotes second loop + CodewordDistribution::castVotes/castVote
  *      (codebook.cpp:541-554, codeword_distribution.cpp:73-167), sink = Voting::vote (voting/voting.cpp:58-77).

@@ -901,6 +901,24 @@ int ismref_knn_ratio(int metric, int n_words, int dim, const float* words, int n
     return 0;
 }
 
+int ismref_knn_rule(int metric, int n_words, int dim, const float* words, const uint32_t* word_class, int nq, const float* q,
+                    float thr, int32_t* idx_out, float* dist_out) {
+    std::vector<int32_t> idx(static_cast<size_t>(nq) * 3); std::vector<float> d(static_cast<size_t>(nq) * 3);
+    ismref_knn(metric, n_words, dim, words, nq, q, 3, idx.data(), d.data());
+    for (int i = 0; i < nq; ++i) {
+        const int i0 = idx[i * 3], i1 = idx[i * 3 + 1], i2 = idx[i * 3 + 2];
+        const float a = d[i * 3], b = d[i * 3 + 1], c = d[i * 3 + 2];
+        idx_out[i] = -1; dist_out[i] = kNaN;
+        if (i2 < 0) { if (i0 >= 0) { idx_out[i] = i0; dist_out[i] = a; } continue; }
+        const uint32_t c0 = word_class[i0], c1 = word_class[i1], c2 = word_class[i2];
+        if (c0 == c1 && c0 == c2) { idx_out[i] = i0; dist_out[i] = a; }
+        else if (c0 == c1 && c0 != c2) { if (a / c < thr) { idx_out[i] = i0; dist_out[i] = a; } }
+        else if (c0 != c1 && c1 == c2) { if (a / b >= thr) { idx_out[i] = i1; dist_out[i] = b; } }
+        else if (c0 != c1 && c1 != c2) { if (a / b < thr) { idx_out[i] = i0; dist_out[i] = a; } }
+    }
+    return 0;
+}
+
 void ismref_rot_quaternion(const float* lrf9, float* out) { Quat q = rot_quaternion(lrf9); out[0] = q.w; out[1] = q.x; out[2] = q.y; out[3] = q.z; }
 void ismref_rotate_into(const float* lrf9, const float* v, float* out) {
     Quat q = rot_quaternion(lrf9); out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; quat_rotate(q, out);

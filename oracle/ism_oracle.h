@@ -73,6 +73,10 @@ int  ismref_knn(int metric, int n_words, int dim, const float* words, int nq, co
 int  ismref_knn_ratio(int metric, int n_words, int dim, const float* words, int nq, const float* q,
                       float ratio_threshold, int32_t* idx_out, float* dist_out);
 
+/* ActivationStrategyKnnRule::activateKNN, detection branch (activation_strategy/activation_strategy_knn_rule.h:79-118) */
+int  ismref_knn_rule(int metric, int n_words, int dim, const float* words, const uint32_t* word_class, int nq, const float* q,
+                     float ratio_threshold, int32_t* idx_out, float* dist_out);
+
 /* Utils::rotateInto / rotateBack / getRotQuaternion (utils/utils.cpp:136-178) */
 void ismref_rot_quaternion(const float* lrf9, float* quat_wxyz_out);
 void ismref_rotate_into(const float* lrf9, const float* v, float* out);

@@ -167,6 +167,16 @@ def knn_ratio(metric, words, q, thr):
     return idx, dist
 
 
+def knn_rule(metric, words, word_class, q, thr):
+    words, q = _f(words), _f(q)
+    nq = q.shape[0]
+    idx = np.empty((nq, 1), np.int32)
+    dist = np.empty((nq, 1), np.float32)
+    lib().ismref_knn_rule(C.c_int(metric), C.c_int(words.shape[0]), C.c_int(words.shape[1]), _p(words), _p(_u(word_class)), C.c_int(nq), _p(q),
+                          C.c_float(thr), _p(idx), _p(dist))
+    return idx, dist
+
+
 def rot_quaternion(lrf9):
     l = _f(lrf9).reshape(9)
     out = np.empty(4, np.float32)

@@ -24,8 +24,8 @@ EXPORTS = [
     "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids",
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
     "ismhip_compact_features",
-    "ismhip_codebook_create", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word",
-    "ismhip_knn", "ismhip_knn_ratio", "ismhip_cast_votes", "ismhip_find_maxima",
+    "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word",
+    "ismhip_knn", "ismhip_knn_ratio", "ismhip_knn_rule", "ismhip_cast_votes", "ismhip_find_maxima",
 ]
 
 
@@ -172,6 +172,9 @@ class Codebook:
         ctx.check(rc, "ismhip_codebook_create")
         self.max_votes = lib().ismhip_codebook_max_votes_per_word(self._h)
 
+    def set_word_class(self, word_class):
+        self.ctx.check(lib().ismhip_codebook_set_word_class(self.ctx._h, self._h, _p(_u32(word_class))), "ismhip_codebook_set_word_class")
+
     def close(self):
         if self._h:
             lib().ismhip_codebook_destroy(self.ctx._h, self._h)
@@ -278,6 +281,16 @@ def knn_ratio(ctx, cb, metric, q, ratio_threshold):
     dist = torch.empty((nq, 1), dtype=torch.float32, device=q.device)
     ctx.check(lib().ismhip_knn_ratio(ctx._h, cb._h, C.c_int(metric), C.c_int(nq), _p(q), C.c_float(ratio_threshold), _p(idx), _p(dist)),
               "ismhip_knn_ratio")
+    return idx, dist
+
+
+def knn_rule(ctx, cb, metric, q, ratio_threshold):
+    torch = _torch()
+    nq = q.shape[0]
+    idx = torch.empty((nq, 1), dtype=torch.int32, device=q.device)
+    dist = torch.empty((nq, 1), dtype=torch.float32, device=q.device)
+    ctx.check(lib().ismhip_knn_rule(ctx._h, cb._h, C.c_int(metric), C.c_int(nq), _p(q), C.c_float(ratio_threshold), _p(idx), _p(dist)),
+              "ismhip_knn_rule")
     return idx, dist
 
 

@@ -169,6 +169,11 @@ int ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* w
     if (ok && vote_class_weight_h) ok = upload(&cb->vote_class_weight, vote_class_weight_h, nv);
     if (ok && vote_bbox_quat_h) ok = upload(&cb->vote_bbox_quat, vote_bbox_quat_h, nv * 4);
     if (ok && vote_bbox_size_h) ok = upload(&cb->vote_bbox_size, vote_bbox_size_h, nv * 3);
+    if (ok) {
+        std::vector<uint32_t> wc(n_words, 0u);
+        for (int c = 0; c < n_words; ++c) if (vote_offsets_h[c + 1] > vote_offsets_h[c]) wc[c] = vote_class_h[vote_offsets_h[c]];
+        ok = upload(&cb->word_class, wc.data(), (size_t)n_words);
+    }
     if (!ok) return fail(ISMHIP_ERR_NOMEM, "codebook_create: vote tables");
     hipLaunchKernelGGL(k_word_norms, dim3((cb->n_words_pad + 3) / 4), dim3(256), 0, ctx->stream, cb->words, n_words, cb->n_words_pad, cb->dim_pad, cb->word_norm);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ISMHIP_ERR_HIP, "codebook_create: norms kernel");
@@ -180,9 +185,15 @@ int ismhip_codebook_destroy(ismhip_ctx* ctx, ismhip_codebook* cb) {
     if (!cb) return ISMHIP_ERR_INVALID;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     void* ptrs[] = {cb->words, cb->word_norm, cb->word_weight, cb->vote_off, cb->vote_xyz, cb->vote_weight, cb->vote_class_weight,
-                    cb->vote_class, cb->vote_instance, cb->vote_bbox_quat, cb->vote_bbox_size, cb->class_sigma};
+                    cb->vote_class, cb->vote_instance, cb->vote_bbox_quat, cb->vote_bbox_size, cb->class_sigma, cb->word_class};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete cb;
+    return ISMHIP_OK;
+}
+
+int ismhip_codebook_set_word_class(ismhip_ctx* ctx, ismhip_codebook* cb, const uint32_t* word_class_h) {
+    if (!ctx || !cb || !word_class_h) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "codebook_set_word_class: bad argument");
+    ISM_HIP(ctx, hipMemcpy(cb->word_class, word_class_h, (size_t)cb->n_words * 4, hipMemcpyHostToDevice));
     return ISMHIP_OK;
 }
 

@@ -58,6 +58,7 @@ struct ismhip_codebook {
     float* vote_bbox_quat = nullptr; // [n_votes*4]
     float* vote_bbox_size = nullptr; // [n_votes*3]
     float* class_sigma = nullptr;    // [n_classes]
+    uint32_t* word_class = nullptr;  // [n_words] Codeword::getClassId
 };
 
 struct TimerAcc {

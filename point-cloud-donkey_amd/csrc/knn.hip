@@ -346,6 +346,26 @@ __global__ void k_ratio(int nq, float thr, const int32_t* __restrict__ idx2, con
     idx_out[i] = id; dist_out[i] = a;
 }
 
+// ActivationStrategyKnnRule::activateKNN, detection branch (activation_strategy_knn_rule.h:79-118)
+__global__ void k_rule(int nq, float thr, const int32_t* __restrict__ idx3, const float* __restrict__ d3, const uint32_t* __restrict__ word_class,
+                       int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int i0 = idx3[i * 3], i1 = idx3[i * 3 + 1], i2 = idx3[i * 3 + 2];
+    const float a = d3[i * 3], b = d3[i * 3 + 1], c = d3[i * 3 + 2];
+    int id = -1; float dd = __builtin_nanf("");
+    if (i2 < 0) {                       // fewer than 4 codewords: the reference returns all of them; report the nearest
+        if (i0 >= 0) { id = i0; dd = a; }
+    } else {
+        const uint32_t c0 = word_class[i0], c1 = word_class[i1], c2 = word_class[i2];
+        if (c0 == c1 && c0 == c2) { id = i0; dd = a; }
+        else if (c0 == c1 && c0 != c2) { if (a / c < thr) { id = i0; dd = a; } }
+        else if (c0 != c1 && c1 == c2) { if (a / b >= thr) { id = i1; dd = b; } }
+        else if (c0 != c1 && c1 != c2) { if (a / b < thr) { id = i0; dd = a; } }
+    }
+    idx_out[i] = id; dist_out[i] = dd;
+}
+
 template <int T>
 int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q, int k,
             int32_t* idx_out, float* dist_out) {
@@ -423,6 +443,20 @@ int ismhip_knn_ratio(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int
     if (rc != ISMHIP_OK) return rc;
     hipLaunchKernelGGL(k_ratio, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, nq, ratio_threshold, idx2, d2, idx_out, dist_out);
     ISM_CHECK_LAUNCH(ctx, "k_ratio");
+    return ISMHIP_OK;
+}
+
+int ismhip_knn_rule(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q,
+                    float ratio_threshold, int32_t* idx_out, float* dist_out) {
+    if (!ctx || !cb || !q || !idx_out || !dist_out || nq < 0) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "knn_rule: bad argument");
+    if (nq == 0) return ISMHIP_OK;
+    int32_t* idx3 = (int32_t*)ism_scratch(ctx, SCR_QNORM, (size_t)nq * 3 * (sizeof(int32_t) + sizeof(float)));
+    if (!idx3) return ISMHIP_ERR_NOMEM;
+    float* d3 = (float*)(idx3 + (size_t)nq * 3);
+    int rc = ismhip_knn(ctx, cb, metric, nq, q, 3, idx3, d3);
+    if (rc != ISMHIP_OK) return rc;
+    hipLaunchKernelGGL(k_rule, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, nq, ratio_threshold, idx3, d3, cb->word_class, idx_out, dist_out);
+    ISM_CHECK_LAUNCH(ctx, "k_rule");
     return ISMHIP_OK;
 }
 

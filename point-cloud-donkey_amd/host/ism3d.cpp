@@ -352,6 +352,15 @@ int ActivationStrategyKNN::activateKNN(DeviceSession& s, const ismhip_codebook* 
     return m_k;
 }
 
+ActivationStrategyKnnRule::ActivationStrategyKnnRule() { addParameter(m_k, "K", 3); m_is_detection = false; m_k = 3; }   // activation_strategy_knn_rule.cpp:16-22
+int ActivationStrategyKnnRule::activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric,
+                                           int32_t* idx_out, float* dist_out) const {
+    if (f.n == 0) return 1;
+    if (!m_is_detection) s.check(ismhip_knn(s.ctx, codewords, metric, (int)f.n, f.desc.as<float>(), 1, idx_out, dist_out), "ismhip_knn");
+    else s.check(ismhip_knn_rule(s.ctx, codewords, metric, (int)f.n, f.desc.as<float>(), m_distance_ratio_threshold, idx_out, dist_out), "ismhip_knn_rule");
+    return 1;
+}
+
 // FLANN functors on the host, used by the training statistics only (utils/distance.cpp:33-52)
 static float hostDistance(int metric, const float* a, const float* b, int n) {
     float result = 0.f;
@@ -374,9 +383,9 @@ void Codebook::activate(DeviceSession& s, const DeviceFeatures& f, const std::ve
     const uint32_t n = f.n;
     const int D = f.dim;
     if (n == 0) throw RuntimeException("no training features");
-    const ActivationStrategyKNN* knn = dynamic_cast<const ActivationStrategyKNN*>(m_activationStrategy.get());
-    if (!knn) throw RuntimeException("activation strategy \"" + m_activationStrategy->getType() + "\" is not built (only \"KNN\")");
-    const int k = knn->getK();
+    const ActivationStrategy* knn = m_activationStrategy.get();
+    const bool is_knn = m_activationStrategy->getType() == "KNN";
+    const int k = is_knn ? knn->getK() : 1;                      // KNNRule trains with plain 1-NN
     if (k > 4) throw RuntimeException("KNN activation with K > 4 is not built");
     std::vector<float> words, lrf, kx, ky, kz;
     s.d2h(words, f.desc, (size_t)n * D); s.d2h(lrf, f.lrf, (size_t)n * 9); s.d2h(kx, f.kx, n); s.d2h(ky, f.ky, n); s.d2h(kz, f.kz, n);
@@ -424,7 +433,7 @@ void Codebook::activate(DeviceSession& s, const DeviceFeatures& f, const std::ve
         sigma[c] = variance;
     }
     // K = 1 clean-up: keep distributions with exactly one vote (codebook.cpp:201-224); otherwise every activated codeword stays
-    const bool clean_up = (k == 1);
+    const bool clean_up = is_knn && k == 1;
     CodebookData out; out.dim = D; out.class_sigma = sigma; out.vote_offsets.assign(1, 0u);
     std::vector<uint32_t> kept;
     for (uint32_t w = 0; w < n; ++w) {
@@ -468,14 +477,12 @@ void Codebook::castVotes(DeviceSession& s, const DeviceFeatures& f, int metric, 
     if (m_use_partial_shot) throw RuntimeException("UsePartialShot is not built on the MI355X path");
     upload(s);
     m_activationStrategy->setIsDetection();
-    const ActivationStrategyKNN* knn = dynamic_cast<const ActivationStrategyKNN*>(m_activationStrategy.get());
-    if (!knn) throw RuntimeException("activation strategy \"" + m_activationStrategy->getType() + "\" is not built (only \"KNN\")");
-    int k = knn->getK();
-    if (k > 4) throw RuntimeException("KNN activation with K > 4 is not built");
+    const ActivationStrategy* knn = m_activationStrategy.get();
+    if (knn->getK() > 4) throw RuntimeException("KNN activation with K > 4 is not built");
     const uint32_t n = f.n;
     if (n == 0) return;
-    s.idx.reserve((size_t)n * k * 4); s.dist.reserve((size_t)n * k * 4);
-    knn->activateKNN(s, m_dev, f, metric, s.idx.as<int32_t>(), s.dist.as<float>());
+    s.idx.reserve((size_t)n * 4 * 4); s.dist.reserve((size_t)n * 4 * 4);
+    const int k = knn->activateKNN(s, m_dev, f, metric, s.idx.as<int32_t>(), s.dist.as<float>());
     const int maxv = ismhip_codebook_max_votes_per_word(m_dev);
     const size_t ns = (size_t)n * k * maxv;
     s.v_pos.reserve(ns * 12); s.v_w.reserve(ns * 4); s.v_cls.reserve(ns * 4); s.v_inst.reserve(ns * 4); s.v_cw.reserve(ns * 4); s.v_bs.reserve(ns * 12);
@@ -595,7 +602,8 @@ template <> Keypoints* Factory<Keypoints>::createByType(const std::string& type)
 }
 template <> ActivationStrategy* Factory<ActivationStrategy>::createByType(const std::string& type) {
     if (type == ActivationStrategyKNN::getTypeStatic()) return new ActivationStrategyKNN();
-    throw RuntimeException("activation strategy \"" + type + "\" is not built (built: KNN)");
+    if (type == ActivationStrategyKnnRule::getTypeStatic()) return new ActivationStrategyKnnRule();
+    throw RuntimeException("activation strategy \"" + type + "\" is not built (built: KNN, KNNRule)");
 }
 template <> Voting* Factory<Voting>::createByType(const std::string& type) {
     if (type == VotingMeanShift::getTypeStatic()) return new VotingMeanShift();

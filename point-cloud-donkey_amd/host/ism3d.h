@@ -212,6 +212,9 @@ public:
     void setIsDetection() { m_is_detection = true; }
     bool useDistanceRatio() const { return m_use_distance_ratio; }
     float distanceRatioThreshold() const { return m_distance_ratio_threshold; }
+    virtual int getK() const = 0;
+    // activates every feature of the batch; writes idx/dist [n x columns] on the device and returns the column count
+    virtual int activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric, int32_t* idx_out, float* dist_out) const = 0;
 protected:
     bool m_use_distance_ratio; float m_distance_ratio_threshold; bool m_is_detection = false;
 };
@@ -220,11 +223,22 @@ public:
     ActivationStrategyKNN();
     static std::string getTypeStatic() { return "KNN"; }
     std::string getType() const override { return getTypeStatic(); }
-    int getK() const { return m_k; }
+    int getK() const override { return m_k; }
     // activateKNN for a whole feature batch (activation_strategy_knn.h:41-126): idx/dist [n x K] on the device, exact search
     // (FLANNExactMatch semantics). With UseDistanceRatio at detection time and K == 1 the 2-NN ratio test discards matches
     // (idx -1). Returns K.
-    int activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric, int32_t* idx_out, float* dist_out) const;
+    int activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric, int32_t* idx_out, float* dist_out) const override;
+private:
+    int m_k;
+};
+class ActivationStrategyKnnRule : public ActivationStrategy {      // activation_strategy/activation_strategy_knn_rule.h:41-152
+public:
+    ActivationStrategyKnnRule();
+    static std::string getTypeStatic() { return "KNNRule"; }
+    std::string getType() const override { return getTypeStatic(); }
+    int getK() const override { return m_k; }
+    // training: plain 1-NN; detection: 3-NN + class-consistency rules. One column.
+    int activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric, int32_t* idx_out, float* dist_out) const override;
 private:
     int m_k;
 };

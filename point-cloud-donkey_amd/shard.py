@@ -50,7 +50,7 @@ def all_gather_records(rec, world_size):
     """one all-gather of the per-object records; returns [world_size * pad_to, 2 + C] on every rank"""
     import torch
     import torch.distributed as dist
-    if world_size == 1 or not dist.is_initialized():
+    if not dist.is_initialized():
         return rec
     out = torch.empty((world_size * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec.contiguous())

@@ -115,9 +115,13 @@ class Dataset:
     """A split of a synthetic dataset, generated object by object (nothing large is stored on disk)."""
 
     def __init__(self, n_classes, n_objects, split, n_points=16384, n_keypoints=1024, dataset_seed=0, with_color=False,
-                 leaf=None):
+                 leaf=None, scale=1.0, partial_view=False):
+        """scale: metric size of the bounding-sphere radius (1 = ModelNet-like, ~350 = the quick-start "model units",
+        ~0.15 = Kinect-like metres). partial_view: keep only the points whose normal faces a per-object viewpoint (single-view
+        partial surfaces of BASELINE configs[3]); leaf: fixed VoxelGrid LeafSize instead of a fixed keypoint count."""
         self.n_classes, self.n_objects, self.split = n_classes, n_objects, split
         self.n_points, self.n_keypoints, self.dataset_seed, self.with_color, self.leaf = n_points, n_keypoints, dataset_seed, with_color, leaf
+        self.scale, self.partial_view = float(scale), partial_view
 
     def label(self, i):
         return i % self.n_classes
@@ -127,6 +131,14 @@ class Dataset:
         o = make_object(c, self.split, i, self.n_points, self.dataset_seed, self.with_color)
         xyz, nrm = o[0], o[1]
         rgba = o[2] if self.with_color else None
+        if self.partial_view:
+            view = np.random.default_rng([BASE_SEED, self.dataset_seed, 31337, self.split, i]).normal(size=3)
+            view /= np.linalg.norm(view)
+            keep = (nrm @ view) > 0.0                       # points with n.view < 0 are culled
+            xyz, nrm = xyz[keep], nrm[keep]
+            rgba = rgba[keep] if rgba is not None else None
+        if self.scale != 1.0:
+            xyz = (xyz * np.float32(self.scale)).astype(np.float32)
         if self.leaf is not None:
             kp = voxel_grid(xyz, self.leaf, rgba)
         else:

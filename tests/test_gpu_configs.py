@@ -1,0 +1,106 @@
+"""GPU parity on reduced-size versions of every BASELINE.json configuration (configs[0], [2], [3], [4]; configs[1] is the
+bench workload and is covered at full size in test_gpu_parity.py): the HIP pipeline and the oracle pipeline run on the same
+synthetic objects and must agree on the kept features, kNN matches, vote classes, predicted labels and class scores."""
+import numpy as np
+import pytest
+
+import oracle_pipeline
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(pkg, gpu, ora, cfg, train, test, n_train, n_test, desc_tol=1e-4):
+    ctx, dev = gpu
+    pipeline = pkg.pipeline
+    rec = pipeline.Recognizer(ctx, cfg)
+    order = sorted(range(n_train), key=lambda i: (train.label(i), i))
+    cb = rec.train([pipeline.DeviceBatch(train.batch(order), dev)])
+    nb = test.batch(range(n_test))
+    got = rec.detect(pipeline.DeviceBatch(nb, dev), keep_intermediates=True)
+    want = oracle_pipeline.detect(ora, cfg, cb, nb, cfg.n_classes)
+    f = got["features"]
+    assert np.array_equal(f["off"], want["off"]), "kept feature counts differ"
+    assert np.array_equal(f["src"].cpu().numpy(), np.nonzero(want["keep"])[0])
+    scale = 100.0 if cfg.feature == "FPFH" else 1.0
+    assert np.abs(f["desc"].cpu().numpy() - want["desc"]).max() <= desc_tol * scale
+    gi, wi = got["idx"].cpu().numpy(), want["idx"]
+    same = (gi == wi).all(1)
+    assert same.mean() > 0.995, same.mean()              # a different winner needs a near tie of the two best distances
+    if not same.all():
+        _, d2 = ora.knn(cfg.metric, cb["words"], want["desc"][~same], 2)
+        assert ((d2[:, 1] - d2[:, 0]) <= 1e-5 * np.maximum(1.0, d2[:, 1])).all()
+    assert (got["cls"][:, 0].cpu().numpy() == want["cls"][:, 0]).all()
+    np.testing.assert_allclose(got["class_score"].cpu().numpy(), want["class_score"], atol=2e-3)
+    return got, want, nb
+
+
+def test_cfg0_quickstart_chi2_model_units(pkg, gpu, ora):
+    """configs[0]: the quick-start value set (config/qs_chi2_shot.ism): SHOT, Radius 60, LRF 50, LeafSize 50, Bandwidth 50,
+    ChiSquared, K = 1, objects of extent ~350 model units, 5 classes x 1 object."""
+    cfg = pkg.pipeline.IsmConfig(feature="SHOT", radius=60.0, lrf_radius=50.0, distance="ChiSquared", k=1, bandwidth=50.0, n_classes=5)
+    syn = pkg.synthetic
+    train = syn.Dataset(5, 5, split=0, n_points=8192, leaf=50.0, scale=350.0)
+    test = syn.Dataset(5, 5, split=1, n_points=8192, leaf=50.0, scale=350.0)
+    got, want, nb = _run(pkg, gpu, ora, cfg, train, test, 5, 5)
+    assert (got["cls"][:, 0].cpu().numpy() == nb["labels"]).all()
+
+
+def test_cfg2_random_codebook_2048_keypoints(pkg, gpu, ora):
+    """configs[2]: 2048 keypoints/object and a fixed-size codebook = seeded random subset of the training features
+    (the reference's UseRandomCodebook mechanism, codebook/codebook.cpp:821-829)."""
+    cfg = pkg.pipeline.IsmConfig(feature="SHOT", n_classes=4, use_random_codebook=True, random_codebook_size=3000)
+    syn = pkg.synthetic
+    train = syn.Dataset(4, 8, split=0, n_points=16384, n_keypoints=2048)
+    test = syn.Dataset(4, 3, split=1, n_points=16384, n_keypoints=2048)
+    got, want, nb = _run(pkg, gpu, ora, cfg, train, test, 8, 3)
+    assert got["features"]["off"][-1] > 3 * 1900
+
+
+def test_cfg3_cshot_chi2_partial_views(pkg, gpu, ora):
+    """configs[3]: Kinect-like coloured partial views, CSHOT-1344, Radius/LRF 0.05, LeafSize 0.02, Bandwidth 0.045, ChiSquared
+    (value set of config/kinect_cshot.ism)."""
+    cfg = pkg.pipeline.IsmConfig(feature="CSHOT", radius=0.05, lrf_radius=0.05, distance="ChiSquared", bandwidth=0.045, n_classes=3)
+    syn = pkg.synthetic
+    kw = dict(n_points=8192, leaf=0.02, scale=0.15, with_color=True, partial_view=True)
+    train = syn.Dataset(3, 6, split=0, **kw)
+    test = syn.Dataset(3, 3, split=1, **kw)
+    _run(pkg, gpu, ora, cfg, train, test, 6, 3)
+
+
+def test_cfg4_dual_fpfh_shot(pkg, gpu, ora):
+    """configs[4]: FPFH-33 and SHOT-352 as two models whose normalised class scores are summed by the harness."""
+    syn = pkg.synthetic
+    train = syn.Dataset(3, 6, split=0, n_points=8192, n_keypoints=512)
+    test = syn.Dataset(3, 3, split=1, n_points=8192, n_keypoints=512)
+    scores = []
+    for feat in ("FPFH", "SHOT"):
+        cfg = pkg.pipeline.IsmConfig(feature=feat, radius=0.3 if feat == "FPFH" else 0.4, n_classes=3)
+        got, want, nb = _run(pkg, gpu, ora, cfg, train, test, 6, 3)
+        scores.append((got["class_score"].cpu().numpy(), want["class_score"]))
+    fused_gpu = scores[0][0] + scores[1][0]
+    fused_ora = scores[0][1] + scores[1][1]
+    assert (fused_gpu.argmax(1) == fused_ora.argmax(1)).all()
+    assert (fused_gpu.argmax(1) == nb["labels"]).all()
+
+
+def test_knn_rule_matches_oracle(pkg, gpu, ora):
+    import torch
+    ctx, dev = gpu
+    rng = np.random.default_rng(77)
+    words = rng.random((600, 48)).astype(np.float32)
+    wcls = rng.integers(0, 3, 600).astype(np.uint32)
+    n = len(words)
+    cb = pkg.capi.Codebook(ctx, words, np.arange(n + 1, dtype=np.uint32), np.zeros((n, 3), np.float32), wcls, np.zeros(n, np.uint32), 3,
+                           np.ones(3, np.float32))
+    q = (words[rng.integers(0, n, 400)] + 0.15 * rng.random((400, 48))).astype(np.float32)
+    for metric in (0, 1):
+        for thr in (0.8, 0.95):
+            gi, gd = pkg.capi.knn_rule(ctx, cb, metric, torch.as_tensor(q).to(dev), thr)
+            wi, wd = ora.knn_rule(metric, words, wcls, q, thr)
+            assert np.array_equal(gi.cpu().numpy(), wi)
+            g, w = gd.cpu().numpy(), wd
+            assert np.array_equal(np.isnan(g), np.isnan(w)) and np.array_equal(g[~np.isnan(g)], w[~np.isnan(w)])
+    assert (wi == -1).any() and (wi >= 0).any()
+    cb.set_word_class(np.zeros(n, np.uint32))            # one class everywhere -> the rule always accepts k1
+    gi, _ = pkg.capi.knn_rule(ctx, cb, 0, torch.as_tensor(q).to(dev), 0.8)
+    assert np.array_equal(gi.cpu().numpy(), ora.knn(0, words, q, 1)[0])
