@@ -58,14 +58,17 @@ template <bool COLOR>
 __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hist, bool act, uint32_t gi,
                                                float dx, float dy, float dz, float d2,
                                                const float fx[3], const float fy[3], const float fz[3],
-                                               float r12, float r14, float r34, float inv_r12,
+                                               float r12, float r14, float r34, float inv_r12, double r12sq,
                                                float LRef, float aRef, float bRef) {
     if (!act) return;
     const float nxv = a.snx[gi], nyv = a.sny[gi], nzv = a.snz[gi];
     if (!(isfinite(nxv) && isfinite(nyv) && isfinite(nzv))) return;              // createBinDistanceShape: NaN normal -> skipped
     float cosd = (nxv * fz[0] + nyv * fz[1]) + nzv * fz[2];
     cosd = fminf(1.0f, fmaxf(-1.0f, cosd));
-    float bd = ((1.0f + cosd) * 10.0f) * 0.5f;
+    // PCL's interpolation is only partly soft: the whole accumulated weight lands in the HARD-assigned (sector, step) bin, so
+    // every hard decision must be taken exactly as the reference takes it. The cosine bin is computed in double from the float
+    // cosine (createBinDistanceShape), and the radial shell test compares in double.
+    const double bd_d = ((1.0 + (double)cosd) * 10.0) / 2.0;
     const float dist = sqrtf(d2);
     if (dist < 1e-15f) return;                                                    // areEquals(distance, 0)
     float xl = (dx * fx[0] + dy * fx[1]) + dz * fx[2];
@@ -81,12 +84,13 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
     if (same_sign || xl == 0.f) di += (fabsf(xl) >= fabsf(yl)) ? 0 : 4;
     else di += (fabsf(xl) > fabsf(yl)) ? 4 : 0;
     di += zl > 0.f ? 1 : 0;
-    const bool outer = dist > r12;
+    const bool outer = (double)d2 > r12sq;                                        // distance > radius1_2, decided on the squares in double
     di += outer ? 2 : 0;
 
-    const int step = (int)floorf(bd + 0.5f);
+    const double step_d = floor(bd_d + 0.5);
+    const int step = (int)step_d;
     const int vol = di * 11;
-    bd -= (float)step;
+    float bd = (float)(bd_d - step_d);
     float w_shape = 1.f - fabsf(bd);
     if (bd > 0.f) shot_dep(hist, vol + ((step + 1) % 10), bd);
     else shot_dep(hist, vol + ((step - 1 + 10) % 10), -bd);
@@ -96,10 +100,11 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
         const float L = a.sL[gi], A = a.sa[gi], B = a.sb[gi];
         float cd = (fabsf(LRef - L) + ((fabsf(aRef - A) + fabsf(bRef - B)) * 0.5f)) / 3.0f;
         cd = fminf(1.0f, fmaxf(0.0f, cd));
-        float bc = cd * 30.0f;
-        step_c = (int)floorf(bc + 0.5f);
+        const double bc_d = (double)cd * 30.0;                                    // colorDistance (float) * nr_color_bins_ in double
+        const double step_cd = floor(bc_d + 0.5);
+        step_c = (int)step_cd;
         vol_c = 352 + di * 31;
-        bc -= (float)step_c;
+        float bc = (float)(bc_d - step_cd);
         w_col = 1.f - fabsf(bc);
         if (bc > 0.f) shot_dep(hist, vol_c + ((step_c + 1) % 30), bc);
         else shot_dep(hist, vol_c + ((step_c - 1 + 30) % 30), -bc);
@@ -124,7 +129,7 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
     float ic = zl / dist;
     ic = fminf(1.0f, fmaxf(-1.0f, ic));
     const float inc = acosf(ic);
-    if (inc > PST_RAD_90f || (fabsf(inc - PST_RAD_90f) < 1e-30f && zl <= 0.f)) {
+    if (!(zl > 0.f)) {        // inclination > 90 deg, or exactly 90 deg with z <= 0: the same test that picked the sector's elevation bit
         const float id = (inc - PST_RAD_135f) / PST_RAD_90f;
         if (inc > PST_RAD_135f) winc += 1.f - id;
         else { winc += 1.f + id; SHOT_DEP(di + 1, -id); }
@@ -188,6 +193,7 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
     float LRef = 0.f, aRef = 0.f, bRef = 0.f;
     if (COLOR) rgb2lab_norm(a.lut_srgb, a.lut_sxyz, a.kp_rgba[k], LRef, aRef, bRef);
     const float r12 = a.radius * 0.5f, r14 = a.radius * 0.25f, r34 = (a.radius * 3.0f) * 0.25f, inv_r12 = 1.0f / r12;
+    const double r12sq = 0.25 * (double)a.radius * (double)a.radius;
     const uint32_t* cs = a.cell_start + (size_t)o * ISM_GRID_STRIDE;
     const uint32_t base = a.pt_off[o];
     uint32_t qn = 0, total = 0;
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
                 if (qn >= 64) {
                     // a full wave of neighbours (LDS traffic of one wave is ordered; no barrier needed)
                     const float4 e = sm.qd[wv][lane];
-                    shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][lane], e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, LRef, aRef, bRef);
+                    shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][lane], e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq, LRef, aRef, bRef);
                     const uint32_t rem = qn - 64;
                     float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f); uint32_t t0i = 0;
                     if ((uint32_t)lane < rem) { t4 = sm.qd[wv][64 + lane]; t0i = sm.qi[wv][64 + lane]; }
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
     if (qn > 0) {
         const bool act = (uint32_t)lane < qn;
         const float4 e = sm.qd[wv][lane];
-        shot_neighbour<COLOR>(a, hist, act, act ? sm.qi[wv][lane] : 0u, e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, LRef, aRef, bRef);
+        shot_neighbour<COLOR>(a, hist, act, act ? sm.qi[wv][lane] : 0u, e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq, LRef, aRef, bRef);
     }
     if (a.count && lane == 0) a.count[k] = total;
     if (total < 5) {                                    // computePointSHOT: fewer than 5 neighbours -> NaN descriptor
