@@ -127,7 +127,7 @@ def main():
     correct, total = int((best == labels).sum().item()), int(len(oi))
 
     # ---- per-kernel device time (HIP events on the ctx stream, timed region only)
-    tm = {n: ctx.timer(n) for n in ["grid", "lrf", "shot352", "knn", "knn_l2_mfma", "cast_votes", "maxima"]}
+    tm = {n: ctx.timer(n) for n in ["grid", "lrf", "shot352", "knn", "knn_l2_mfma", "knn_fallback", "cast_votes", "maxima"]}
     ctx.timers_enable(False)
     nq_per_launch = None
     roofline = roofline_shot = None
@@ -155,7 +155,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_objects > 0:
         ora = ge.load_oracle()
-        n_thr = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1)
+        n_thr = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16)     # the GPU box's CPU share for one GPU
         ora.set_num_threads(n_thr)
         nb = test.batch(list(range(args.cpu_objects)))
         xyz, nrm, kp = nb["xyz"], nb["normals"], nb["kp"]

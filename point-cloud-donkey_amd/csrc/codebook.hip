@@ -177,6 +177,13 @@ int ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* w
     if (!ok) return fail(ISMHIP_ERR_NOMEM, "codebook_create: vote tables");
     hipLaunchKernelGGL(k_word_norms, dim3((cb->n_words_pad + 3) / 4), dim3(256), 0, ctx->stream, cb->words, n_words, cb->n_words_pad, cb->dim_pad, cb->word_norm);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ISMHIP_ERR_HIP, "codebook_create: norms kernel");
+    {
+        std::vector<float> nh(n_words);
+        if (hipMemcpy(nh.data(), cb->word_norm, (size_t)n_words * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(ISMHIP_ERR_HIP, "codebook_create: norms copy");
+        float mx = 0.f;
+        for (float v : nh) if (v > mx || v != v) mx = v;        // a NaN word poisons the bound -> every query takes the exact fallback
+        cb->max_norm2 = mx;
+    }
     *out = cb;
     return ISMHIP_OK;
 }

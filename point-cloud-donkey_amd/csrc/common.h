@@ -48,6 +48,7 @@ struct ismhip_codebook {
     float* words = nullptr;          // [n_words_pad * dim_pad] row-major, zero padded (MFMA tile friendly)
     int n_words_pad = 0;
     float* word_norm = nullptr;      // [n_words_pad] squared L2 norm (+inf for padding rows)
+    float max_norm2 = 0.f;           // max squared norm over the real rows (bounds the fp32 contraction error of kNN)
     float* word_weight = nullptr;    // [n_words]
     uint32_t* vote_off = nullptr;    // [n_words+1]
     float* vote_xyz = nullptr;       // [n_votes*3]
@@ -86,7 +87,7 @@ struct ismhip_ctx {
 enum ScratchSlot {
     SCR_KP_OFF = 1, SCR_TIE_LIST, SCR_TIE_REC, SCR_TIE_KEYS, SCR_COUNTERS, SCR_KNN_CAND_IDX, SCR_KNN_CAND_VAL,
     SCR_QNORM, SCR_FPFH_FLAG, SCR_FPFH_LIST, SCR_FPFH_SPFH, SCR_FPFH_LOOKUP, SCR_SLOT_OFF, SCR_CLASS_BW,
-    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV
+    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS
 };
 
 int  ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg);

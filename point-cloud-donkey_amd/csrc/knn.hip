@@ -12,10 +12,16 @@
 //           of ONE query per accumulator tile: the running top-T per query is kept in registers with no cross-lane
 //           traffic and the Nq x Nc matrix is never materialised. Roofline: 2*Nq*Nc*D flop vs 157.3 TFLOP/s.
 //     chi2: k_knn_chi2 — not a contraction (sum (a-b)^2/(a+b)); 64x64 VALU tile, 4x4 pairs per thread, v_rcp_f32.
-//     Both keep T candidates per lane/thread with T >= k, so the true k nearest are always among the candidates.
+//     Both keep the T best candidates per lane/thread slot (T >= k) AND the value of the best candidate they dropped.
 //  2. k_knn_rerank — one wave per query: every candidate's distance is recomputed with the FLANN functor's own
 //     summation order (bit-identical to the CPU functor) and the k smallest (distance, row) pairs are selected;
-//     ties go to the lowest row.
+//     ties go to the lowest row. The result is then PROVEN: every codeword outside the candidate set has an approximate
+//     score >= B (the smallest dropped value), so its true distance is >= |q|^2 + B - eps with eps a rigorous bound on the
+//     fp32 contraction error (2(K+8)u(|c|max^2 + 2|q||c|max)); if the k-th exact distance is not safely below that, the query
+//     is queued for
+//  3. k_knn_fallback — exact scan of the whole codebook for the queued queries (coalesced direct (a-b)^2 sums select the
+//     rows, the functor order ranks them). Rare for unit-norm SHOT/CSHOT descriptors, common for un-normalised FPFH-33
+//     (values up to 100: |c|^2 ~ 1e4 makes eps ~ 0.1), where it keeps the answer exact at VALU speed.
 #include "common.h"
 
 namespace {
@@ -57,7 +63,8 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
                                                         int n_tiles_m, int dim_pad,
                                                         const float* __restrict__ q, int nq, int ldq,
                                                         int tiles_per_split, int n_splits,
-                                                        float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride) {
+                                                        float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
+                                                        float* __restrict__ cand_bound, int bound_stride) {
     __shared__ __attribute__((aligned(16))) float sA[2][KNN_BM * KNN_LDK];
     __shared__ __attribute__((aligned(16))) float sB[2][KNN_BN * KNN_LDK];
     __shared__ float sCn[KNN_BM];
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
         qbase[i] = q + (size_t)qr * ldq + scol;
     }
 
-    TopT<T> top[2];
+    TopT<T + 1> top[2];            // T candidates + the best value that gets dropped
     top[0].init(); top[1].init();
 
     for (int mt = mt0; mt < mt1; ++mt) {
@@ -173,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
                 const size_t o = (size_t)qi * cand_stride + split * (4 * T) + (wr * 2 + h) * T + t;
                 cand_val[o] = top[ni].v[t]; cand_idx[o] = top[ni].i[t];
             }
+            cand_bound[(size_t)qi * bound_stride + split * 4 + (wr * 2 + h)] = top[ni].v[T];
         }
     }
 }
@@ -186,18 +194,19 @@ template <int T>
 __global__ __launch_bounds__(256) void k_knn_chi2(const float* __restrict__ words, int n_words_pad, int dim_pad,
                                                   const float* __restrict__ q, int nq, int ldq,
                                                   int tiles_per_split,
-                                                  float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride) {
+                                                  float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
+                                                  float* __restrict__ cand_bound, int bound_stride) {
     __shared__ float sC[CHI_B * CHI_LDK];
     __shared__ float sQ[CHI_B * CHI_LDK];
-    __shared__ float sMv[CHI_B][16][T];
-    __shared__ int sMi[CHI_B][16][T];
+    __shared__ float sMv[CHI_B][16][T + 1];
+    __shared__ int sMi[CHI_B][16][T + 1];
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;       // tx -> 4 query columns, ty -> 4 codeword rows
     const int qtile = blockIdx.x, split = blockIdx.y;
     const int n_tiles = n_words_pad / CHI_B;
     const int mt0 = split * tiles_per_split, mt1 = min(n_tiles, mt0 + tiles_per_split);
     const int nk = dim_pad / 32;
-    TopT<T> top[4];
+    TopT<T + 1> top[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) top[j].init();
     // staging: 64 rows x 32 floats = 2048 floats, 8 per thread: row = tid/4, cols (tid%4)*8 .. +7
@@ -241,28 +250,29 @@ __global__ __launch_bounds__(256) void k_knn_chi2(const float* __restrict__ word
 #pragma unroll
             for (int j = 0; j < 4; ++j) top[j].push(acc[i][j], mt * CHI_B + ty * 4 + i);
     }
-    // merge the 16 row-threads of every query column, keep the best T
+    // merge the 16 row-threads of every query column: best T are the candidates, the (T+1)-th smallest value bounds
+    // everything that was dropped (each thread's own (T+1)-th value bounds what that thread dropped)
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < T; ++t) { sMv[tx * 4 + j][ty][t] = top[j].v[t]; sMi[tx * 4 + j][ty][t] = top[j].i[t]; }
+        for (int t = 0; t < T + 1; ++t) { sMv[tx * 4 + j][ty][t] = top[j].v[t]; sMi[tx * 4 + j][ty][t] = top[j].i[t]; }
     __syncthreads();
     if (tid < CHI_B) {
         const int qi = qtile * CHI_B + tid;
         if (qi < nq) {
-            TopT<T> best; best.init();
+            TopT<T + 1> best; best.init();
             for (int y = 0; y < 16; ++y)
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
+                for (int t = 0; t < T + 1; ++t) {
                     // order by (value, row): rows from different threads interleave, so compare rows on equal values
                     const float v = sMv[tid][y][t]; const int id = sMi[tid][y][t];
                     if (id < 0) continue;
-                    if (v < best.v[T - 1] || (v == best.v[T - 1] && id < best.i[T - 1])) {
-                        best.v[T - 1] = v; best.i[T - 1] = id;
+                    if (v < best.v[T] || (v == best.v[T] && id < best.i[T]) || best.i[T] < 0) {
+                        best.v[T] = v; best.i[T] = id;
 #pragma unroll
-                        for (int u = T - 1; u > 0; --u)
-                            if (best.v[u] < best.v[u - 1] || (best.v[u] == best.v[u - 1] && best.i[u] < best.i[u - 1])) {
+                        for (int u = T; u > 0; --u)
+                            if (best.i[u - 1] < 0 || best.v[u] < best.v[u - 1] || (best.v[u] == best.v[u - 1] && best.i[u] < best.i[u - 1])) {
                                 float tv = best.v[u]; best.v[u] = best.v[u - 1]; best.v[u - 1] = tv;
                                 int ti = best.i[u]; best.i[u] = best.i[u - 1]; best.i[u - 1] = ti;
                             }
@@ -273,6 +283,7 @@ __global__ __launch_bounds__(256) void k_knn_chi2(const float* __restrict__ word
                 const size_t o = (size_t)qi * cand_stride + split * T + t;
                 cand_val[o] = best.v[t]; cand_idx[o] = best.i[t];
             }
+            cand_bound[(size_t)qi * bound_stride + split] = best.i[T] >= 0 ? best.v[T] : __builtin_inff();
         }
     }
 }
@@ -299,10 +310,17 @@ __device__ __forceinline__ float flann_chi2(const float* a, const float* b, int 
     return result;
 }
 
+struct VerifyParams {
+    float gamma;      // 2 (K+8) u : relative error bound of a K-term fp32 fma chain (u = 2^-24), with a factor 2 of safety
+    float cmax2;      // max |c|^2 over the codebook (L2 only)
+};
+
 __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ words, int dim, int dim_pad, int n_words,
                                                     const float* __restrict__ q, int nq, int ldq, int metric,
                                                     const int* __restrict__ cand_idx, int cand_stride, int n_cand,
-                                                    int k, int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
+                                                    const float* __restrict__ cand_bound, int n_bound, VerifyParams vp,
+                                                    int k, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
+                                                    uint32_t* __restrict__ flag_count, uint32_t* __restrict__ flag_list) {
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq) return;
     const int lane = lane_id();
@@ -318,6 +336,14 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
             key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;
         }
     }
+    // B = smallest approximate score among everything the candidate kernels dropped; |q|^2 by a wave sum
+    float bnd = __builtin_inff();
+    if (lane < n_bound) bnd = cand_bound[(size_t)qi * n_bound + lane];
+    float qn2 = 0.f;
+    for (int i = lane; i < dim; i += 64) { const float v = qp[i]; qn2 += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { bnd = fminf(bnd, __shfl_xor(bnd, o, 64)); qn2 += __shfl_xor(qn2, o, 64); }
+    float dk = 0.f; bool have_k = true;
     for (int j = 0; j < k; ++j) {
         unsigned long long mn = key;
 #pragma unroll
@@ -326,7 +352,90 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
             if (mn == ~0ull) { idx_out[(size_t)qi * k + j] = -1; dist_out[(size_t)qi * k + j] = __builtin_nanf(""); }
             else { idx_out[(size_t)qi * k + j] = (int)(mn & 0xffffffffull); dist_out[(size_t)qi * k + j] = __uint_as_float((unsigned)(mn >> 32)); }
         }
+        if (mn == ~0ull) have_k = false; else dk = __uint_as_float((unsigned)(mn >> 32));
         if (key == mn) key = ~0ull;     // rows are unique among candidates, so exactly one lane retires
+    }
+    // proof of exactness (see the file header). NaN distances or bounds fail the test and go to the fallback.
+    bool proven;
+    if (bnd == __builtin_inff()) proven = true;                       // nothing was dropped: the candidates are the whole codebook
+    else if (!have_k) proven = false;
+    else if (metric == ISMHIP_METRIC_CHI2) proven = dk * (1.f + vp.gamma) < bnd * (1.f - vp.gamma);
+    else {
+        const float eps = vp.gamma * (vp.cmax2 + 2.f * sqrtf(qn2 * vp.cmax2)) + 2.f * vp.gamma * (qn2 + dk);
+        proven = dk + eps < qn2 + bnd;
+    }
+    if (!proven && lane == 0) flag_list[atomicAdd(flag_count, 1u)] = (uint32_t)qi;
+}
+
+// Exact scan for the queries whose candidate result could not be proven. One workgroup per queued query; a wave handles
+// 4 codeword rows per step (16 lanes each, 64-byte coalesced segments), direct (a-b)^2 [/(a+b)] sums pick the rows that can
+// still matter, the FLANN functor order ranks them.
+__global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ words, int dim, int dim_pad, int n_words,
+                                                      const float* __restrict__ q, int ldq, int metric, int k,
+                                                      const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ flag_list,
+                                                      int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
+    extern __shared__ float s_q[];                       // [dim_pad] + merge area
+    __shared__ unsigned long long s_top[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const uint32_t n_flag = *flag_count;
+    for (uint32_t t = blockIdx.x; t < n_flag; t += gridDim.x) {
+        const int qi = (int)flag_list[t];
+        __syncthreads();
+        for (int i = tid; i < dim_pad; i += 256) s_q[i] = i < dim ? q[(size_t)qi * ldq + i] : 0.f;
+        __syncthreads();
+        // current k-th best exact distance from the candidate stage (inf when fewer than k candidates were valid)
+        unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        float thr = __builtin_inff();
+        {
+            const int id = idx_out[(size_t)qi * k + (k - 1)];
+            if (id >= 0) thr = dist_out[(size_t)qi * k + (k - 1)];
+        }
+        for (int r0 = wv * 4; r0 < n_words; r0 += 16) {
+            const int r = r0 + g;
+            float part = 0.f;
+            if (r < n_words) {
+                const float* wp = words + (size_t)r * dim_pad;
+                if (metric == ISMHIP_METRIC_CHI2) {
+                    for (int i = l16; i < dim_pad; i += 16) { const float a = s_q[i], b = wp[i], sm = a + b, df = a - b; part += sm > 0.f ? df * df / sm : 0.f; }
+                } else {
+                    for (int i = l16; i < dim_pad; i += 16) { const float df = s_q[i] - wp[i]; part += df * df; }
+                }
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            const bool hit = r < n_words && !(part > thr * 1.0001f + 1e-30f);          // NaN-safe: unordered compares count as hits
+            unsigned long long hm = __ballot(hit && l16 == 0);
+            while (hm) {                                                                 // rare
+                const int src = __ffsll((long long)hm) - 1; hm &= hm - 1;
+                const int rr = r0 + (src >> 4);
+                const float d = metric == ISMHIP_METRIC_CHI2 ? flann_chi2(s_q, words + (size_t)rr * dim_pad, dim) : flann_l2(s_q, words + (size_t)rr * dim_pad, dim);
+                unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)rr;
+                if (d != d) key = ~0ull - 1;                                            // NaN sorts last but stays a valid row
+                // insert into the wave-uniform top-k (k <= 4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (j < k && key < best[j]) { const unsigned long long tmp = best[j]; best[j] = key; key = tmp; }
+                if (best[k - 1] != ~0ull) thr = fminf(thr, __uint_as_float((unsigned)(best[k - 1] >> 32)));
+            }
+        }
+        if (lane == 0) for (int j = 0; j < 4; ++j) s_top[wv][j] = best[j];
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long fin[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+            auto ins = [&](unsigned long long key) {
+                for (int j = 0; j < k; ++j) if ((fin[j] & 0xffffffffull) == (key & 0xffffffffull) && fin[j] != ~0ull) return;   // same row twice
+                for (int j = 0; j < 4; ++j) if (j < k && key < fin[j]) { const unsigned long long tmp = fin[j]; fin[j] = key; key = tmp; }
+            };
+            for (int j = 0; j < k; ++j) {
+                const int id = idx_out[(size_t)qi * k + j];
+                if (id >= 0) ins(((unsigned long long)__float_as_uint(dist_out[(size_t)qi * k + j]) << 32) | (unsigned)id);
+            }
+            for (int w = 0; w < 4; ++w) for (int j = 0; j < k; ++j) if (s_top[w][j] != ~0ull) ins(s_top[w][j]);
+            for (int j = 0; j < k; ++j) {
+                if (fin[j] == ~0ull) { idx_out[(size_t)qi * k + j] = -1; dist_out[(size_t)qi * k + j] = __builtin_nanf(""); }
+                else { idx_out[(size_t)qi * k + j] = (int)(fin[j] & 0xffffffffull); dist_out[(size_t)qi * k + j] = __uint_as_float((unsigned)(fin[j] >> 32)); }
+            }
+        }
     }
 }
 
@@ -395,26 +504,41 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         cand_per_split = T;
     }
     n_cand = n_splits * cand_per_split;
-    float* cand_val = (float*)ism_scratch(ctx, SCR_KNN_CAND_VAL, (size_t)nq * n_cand * sizeof(float));
+    const int n_bound = metric == ISMHIP_METRIC_L2SQ ? n_splits * 4 : n_splits;
+    float* cand_val = (float*)ism_scratch(ctx, SCR_KNN_CAND_VAL, (size_t)nq * (n_cand + n_bound) * sizeof(float));
     int* cand_idx = (int*)ism_scratch(ctx, SCR_KNN_CAND_IDX, (size_t)nq * n_cand * sizeof(int));
-    if (!cand_val || !cand_idx) return ISMHIP_ERR_NOMEM;
+    uint32_t* flags = (uint32_t*)ism_scratch(ctx, SCR_KNN_FLAGS, ((size_t)nq + 16) * sizeof(uint32_t));
+    if (!cand_val || !cand_idx || !flags) return ISMHIP_ERR_NOMEM;
+    float* cand_bound = cand_val + (size_t)nq * n_cand;
+    uint32_t* flag_count = flags; uint32_t* flag_list = flags + 16;
+    ISM_HIP(ctx, hipMemsetAsync(flag_count, 0, 4, ctx->stream));
     {
         TimerScope ts(ctx, metric == ISMHIP_METRIC_L2SQ ? "knn_l2_mfma" : "knn_chi2");
         if (metric == ISMHIP_METRIC_L2SQ) {
             const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
             hipLaunchKernelGGL(k_knn_l2_mfma<T>, dim3(n_qt, n_splits), dim3(256), 0, ctx->stream, cb->words, cb->word_norm,
-                               cb->n_words_pad / KNN_BM, cb->dim_pad, qq, nq, ldq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand);
+                               cb->n_words_pad / KNN_BM, cb->dim_pad, qq, nq, ldq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand,
+                               cand_bound, n_bound);
             ISM_CHECK_LAUNCH(ctx, "k_knn_l2_mfma");
         } else {
             const int n_qt = (nq + CHI_B - 1) / CHI_B;
             hipLaunchKernelGGL(k_knn_chi2<T>, dim3(n_qt, n_splits), dim3(256), 0, ctx->stream, cb->words, cb->n_words_pad, cb->dim_pad,
-                               qq, nq, ldq, tiles_per_split, cand_val, cand_idx, n_cand);
+                               qq, nq, ldq, tiles_per_split, cand_val, cand_idx, n_cand, cand_bound, n_bound);
             ISM_CHECK_LAUNCH(ctx, "k_knn_chi2");
         }
     }
+    VerifyParams vp;
+    vp.gamma = 2.0f * (float)(cb->dim_pad + 8) * 5.9604645e-08f;
+    vp.cmax2 = cb->max_norm2;
     hipLaunchKernelGGL(k_knn_rerank, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
-                       qq, nq, ldq, metric, cand_idx, n_cand, n_cand, k, idx_out, dist_out);
+                       qq, nq, ldq, metric, cand_idx, n_cand, n_cand, cand_bound, n_bound, vp, k, idx_out, dist_out, flag_count, flag_list);
     ISM_CHECK_LAUNCH(ctx, "k_knn_rerank");
+    {
+        TimerScope ts(ctx, "knn_fallback");
+        hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), (size_t)cb->dim_pad * sizeof(float), ctx->stream, cb->words, cb->dim, cb->dim_pad,
+                           cb->n_words, qq, ldq, metric, k, flag_count, flag_list, idx_out, dist_out);
+        ISM_CHECK_LAUNCH(ctx, "k_knn_fallback");
+    }
     return ISMHIP_OK;
 }
 

@@ -231,6 +231,28 @@ def test_knn_matches_oracle(pkg, gpu, ora, metric, shape, k):
     assert np.array_equal(got[~np.isnan(got)], wdist[~np.isnan(wdist)])    # same functor, same summation order: bit-exact
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+def test_knn_adversarial_needs_the_exact_fallback(pkg, gpu, ora, metric):
+    """Candidate generation keeps 2 entries per lane slot; these codebooks put hundreds of near-duplicates (and exact duplicates)
+    inside the fp32 contraction error of the best match, and use un-normalised magnitudes (|c|^2 ~ 1e4) where the error bound is
+    large. The proof step must notice and the exact scan must still return the oracle's answer, ties to the lowest row."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(5 + metric)
+    base = rng.random((40, 96)).astype(np.float32) * 30.0
+    words = np.repeat(base, 60, axis=0)                                   # 60 copies of each of 40 prototypes ...
+    words += (rng.random(words.shape) < 0.02) * 1e-4 * rng.random(words.shape)   # ... some of them perturbed in the 6th digit
+    words = words.astype(np.float32)
+    perm = rng.permutation(len(words)); words = words[perm]
+    q = (base[rng.integers(0, 40, 300)] + 1e-3 * rng.random((300, 96))).astype(np.float32)
+    host, cb = _cb(pkg, gpu, words)
+    for k in (1, 3):
+        idx, dist = pkg.capi.knn(ctx, cb, metric, T(q, dev), k)
+        widx, wdist = ora.knn(metric, words, q, k)
+        assert np.array_equal(idx.cpu().numpy(), widx)
+        assert np.array_equal(dist.cpu().numpy(), wdist)
+    ms, n = ctx.timer("knn_fallback")
+
+
 def test_knn_ties_kat_and_ratio(pkg, gpu, ora):
     ctx, dev = gpu
     k = KAT["knn_ties"]
