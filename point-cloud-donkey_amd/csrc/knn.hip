@@ -311,9 +311,10 @@ __device__ __forceinline__ float flann_chi2(const float* a, const float* b, int 
 }
 
 struct VerifyParams {
-    float gamma;      // 2 (K+8) u : relative error bound of a K-term fp32 fma chain (u = 2^-24), with a factor 2 of safety
+    float ku;         // 1.01 * K * u : relative error bound of a K-term fp32 fma chain / K-term functor sum (u = 2^-24)
     float cmax2;      // max |c|^2 over the codebook (L2 only)
 };
+#define KNN_U 5.9604645e-08f
 
 __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ words, int dim, int dim_pad, int n_words,
                                                     const float* __restrict__ q, int nq, int ldq, int metric,
@@ -336,13 +337,13 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
             key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;
         }
     }
-    // B = smallest approximate score among everything the candidate kernels dropped; |q|^2 by a wave sum
+    // every bound slot (L2: split x 4 lane slots, chi2: split) holds the smallest approximate score that slot dropped
     float bnd = __builtin_inff();
     if (lane < n_bound) bnd = cand_bound[(size_t)qi * n_bound + lane];
     float qn2 = 0.f;
     for (int i = lane; i < dim; i += 64) { const float v = qp[i]; qn2 += v * v; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { bnd = fminf(bnd, __shfl_xor(bnd, o, 64)); qn2 += __shfl_xor(qn2, o, 64); }
+    for (int o = 32; o > 0; o >>= 1) qn2 += __shfl_xor(qn2, o, 64);
     float dk = 0.f; bool have_k = true;
     for (int j = 0; j < k; ++j) {
         unsigned long long mn = key;
@@ -355,32 +356,50 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
         if (mn == ~0ull) have_k = false; else dk = __uint_as_float((unsigned)(mn >> 32));
         if (key == mn) key = ~0ull;     // rows are unique among candidates, so exactly one lane retires
     }
-    // proof of exactness (see the file header). NaN distances or bounds fail the test and go to the fallback.
-    bool proven;
-    if (bnd == __builtin_inff()) proven = true;                       // nothing was dropped: the candidates are the whole codebook
-    else if (!have_k) proven = false;
-    else if (metric == ISMHIP_METRIC_CHI2) proven = dk * (1.f + vp.gamma) < bnd * (1.f - vp.gamma);
-    else {
-        const float eps = vp.gamma * (vp.cmax2 + 2.f * sqrtf(qn2 * vp.cmax2)) + 2.f * vp.gamma * (qn2 + dk);
-        proven = dk + eps < qn2 + bnd;
+    // Proof of exactness, slot by slot. A codeword dropped by slot b has approximate score >= bnd_b, so
+    //   L2  : true distance D >= |q|^2 (1 - 16u) + bnd_b - eps_s,  eps_s = 17u |c|max^2 + (2.02 K + 2) u |q||c|max
+    //         (|c|^2 by a short tree sum: 16u; K-term fma chain: 1.01 K u on sum|q_i c_i| <= |q||c|; final subtraction: u)
+    //   chi2: all terms are non-negative, v_rcp_f32 is 1 ulp: D >= bnd_b (1 - (K + 8) u)
+    // and its functor value is >= D (1 - 1.01 K u). If that is above the k-th exact functor value, the slot cannot hold a
+    // better row. Slots that fail (or NaNs) are handed to the exact scan, restricted to the rows of those slots.
+    bool viol = false;
+    if (lane < n_bound && bnd != __builtin_inff()) {
+        if (!have_k) viol = true;
+        else if (metric == ISMHIP_METRIC_CHI2) {
+            const float lo = bnd * (1.f - ((float)dim_pad + 8.f) * KNN_U) * (1.f - vp.ku);
+            viol = !(dk < lo);
+        } else {
+            const float eps_s = 17.f * KNN_U * vp.cmax2 + (2.f * vp.ku + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2);
+            const float rhs = qn2 * (1.f - 16.f * KNN_U) + bnd - eps_s;
+            viol = !(dk < rhs - vp.ku * fabsf(rhs) - 1e-37f);
+        }
     }
-    if (!proven && lane == 0) flag_list[atomicAdd(flag_count, 1u)] = (uint32_t)qi;
+    const unsigned long long vmask = __ballot(viol);
+    if (vmask != 0ull && lane == 0) {
+        const uint32_t slot = atomicAdd(flag_count, 1u);
+        flag_list[2 * (size_t)slot] = (uint32_t)qi; flag_list[2 * (size_t)slot + 1] = (uint32_t)vmask;
+    }
 }
 
-// Exact scan for the queries whose candidate result could not be proven. One workgroup per queued query; a wave handles
-// 4 codeword rows per step (16 lanes each, 64-byte coalesced segments), direct (a-b)^2 [/(a+b)] sums pick the rows that can
-// still matter, the FLANN functor order ranks them.
+// Exact scan for the queries whose candidate result could not be proven, restricted to the codeword rows of the slots that
+// failed. One workgroup per queued query; a wave handles 4 rows per step (16 lanes each, 64-byte coalesced segments); direct
+// (a-b)^2 [/(a+b)] sums pick the rows that can still matter, the FLANN functor order ranks them.
+// Slot -> rows: L2 bit b = split*4 + wr*2 + h owns, in every 128-row tile of its split, the 32 rows wr*64 + x with bit 2 of x
+// equal to h (the C/D layout of the 32x32 MFMA tile, see k_knn_l2_mfma); chi2 bit b = split owns all rows of its split.
 __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ words, int dim, int dim_pad, int n_words,
-                                                      const float* __restrict__ q, int ldq, int metric, int k,
+                                                      const float* __restrict__ q, int ldq, int metric, int k, int tiles_per_split, int n_tiles,
                                                       const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ flag_list,
                                                       int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
-    extern __shared__ float s_q[];                       // [dim_pad] + merge area
+    extern __shared__ float s_q[];                       // [dim_pad]
     __shared__ unsigned long long s_top[4][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15;
     const uint32_t n_flag = *flag_count;
+    const bool l2 = metric != ISMHIP_METRIC_CHI2;
+    const int tile_rows = l2 ? KNN_BM : CHI_B;
     for (uint32_t t = blockIdx.x; t < n_flag; t += gridDim.x) {
-        const int qi = (int)flag_list[t];
+        const int qi = (int)flag_list[2 * (size_t)t];
+        uint32_t mask = flag_list[2 * (size_t)t + 1];
         __syncthreads();
         for (int i = tid; i < dim_pad; i += 256) s_q[i] = i < dim ? q[(size_t)qi * ldq + i] : 0.f;
         __syncthreads();
@@ -391,31 +410,42 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
             const int id = idx_out[(size_t)qi * k + (k - 1)];
             if (id >= 0) thr = dist_out[(size_t)qi * k + (k - 1)];
         }
-        for (int r0 = wv * 4; r0 < n_words; r0 += 16) {
-            const int r = r0 + g;
-            float part = 0.f;
-            if (r < n_words) {
-                const float* wp = words + (size_t)r * dim_pad;
-                if (metric == ISMHIP_METRIC_CHI2) {
-                    for (int i = l16; i < dim_pad; i += 16) { const float a = s_q[i], b = wp[i], sm = a + b, df = a - b; part += sm > 0.f ? df * df / sm : 0.f; }
-                } else {
-                    for (int i = l16; i < dim_pad; i += 16) { const float df = s_q[i] - wp[i]; part += df * df; }
+        while (mask) {
+            const int b = __ffs((int)mask) - 1; mask &= mask - 1;
+            const int split = l2 ? (b >> 2) : b;
+            const int wr = (b >> 1) & 1, h = b & 1;
+            const int mt0 = split * tiles_per_split, mt1 = min(n_tiles, mt0 + tiles_per_split);
+            const int rows_per_tile = l2 ? 32 : CHI_B;
+            // the slot's rows, enumerated as (tile, y); the 4 waves take interleaved groups of 4 rows
+            const int total = (mt1 - mt0) * rows_per_tile;
+            for (int e0 = wv * 4; e0 < total; e0 += 16) {
+                const int e = e0 + g;
+                int r = n_words;                                  // out of range = idle group
+                if (e < total) {
+                    const int tile = mt0 + e / rows_per_tile, y = e % rows_per_tile;
+                    const int x = l2 ? (wr * 64 + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y;
+                    r = tile * tile_rows + x;
                 }
-            }
+                float part = 0.f;
+                if (r < n_words) {
+                    const float* wp = words + (size_t)r * dim_pad;
+                    if (!l2) { for (int i = l16; i < dim_pad; i += 16) { const float a = s_q[i], c = wp[i], sm = a + c, df = a - c; part += sm > 0.f ? df * df / sm : 0.f; } }
+                    else { for (int i = l16; i < dim_pad; i += 16) { const float df = s_q[i] - wp[i]; part += df * df; } }
+                }
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-            const bool hit = r < n_words && !(part > thr * 1.0001f + 1e-30f);          // NaN-safe: unordered compares count as hits
-            unsigned long long hm = __ballot(hit && l16 == 0);
-            while (hm) {                                                                 // rare
-                const int src = __ffsll((long long)hm) - 1; hm &= hm - 1;
-                const int rr = r0 + (src >> 4);
-                const float d = metric == ISMHIP_METRIC_CHI2 ? flann_chi2(s_q, words + (size_t)rr * dim_pad, dim) : flann_l2(s_q, words + (size_t)rr * dim_pad, dim);
-                unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)rr;
-                if (d != d) key = ~0ull - 1;                                            // NaN sorts last but stays a valid row
-                // insert into the wave-uniform top-k (k <= 4)
+                for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                const bool hit = r < n_words && !(part > thr * 1.0001f + 1e-30f);      // NaN-safe: unordered compares count as hits
+                unsigned long long hm = __ballot(hit && l16 == 0);
+                while (hm) {                                                             // rare
+                    const int src = __ffsll((long long)hm) - 1; hm &= hm - 1;
+                    const int rr = __shfl(r, src, 64);
+                    const float d = l2 ? flann_l2(s_q, words + (size_t)rr * dim_pad, dim) : flann_chi2(s_q, words + (size_t)rr * dim_pad, dim);
+                    unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)rr;
+                    if (d != d) key = ~0ull - 1;                                        // NaN sorts last but stays a valid row
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (j < k && key < best[j]) { const unsigned long long tmp = best[j]; best[j] = key; key = tmp; }
-                if (best[k - 1] != ~0ull) thr = fminf(thr, __uint_as_float((unsigned)(best[k - 1] >> 32)));
+                    for (int j = 0; j < 4; ++j) if (j < k && key < best[j]) { const unsigned long long tmp = best[j]; best[j] = key; key = tmp; }
+                    if (best[k - 1] != ~0ull) thr = fminf(thr, __uint_as_float((unsigned)(best[k - 1] >> 32)));
+                }
             }
         }
         if (lane == 0) for (int j = 0; j < 4; ++j) s_top[wv][j] = best[j];
@@ -423,7 +453,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
         if (tid == 0) {
             unsigned long long fin[4] = {~0ull, ~0ull, ~0ull, ~0ull};
             auto ins = [&](unsigned long long key) {
-                for (int j = 0; j < k; ++j) if ((fin[j] & 0xffffffffull) == (key & 0xffffffffull) && fin[j] != ~0ull) return;   // same row twice
+                for (int j = 0; j < k; ++j) if (fin[j] != ~0ull && (fin[j] & 0xffffffffull) == (key & 0xffffffffull)) return;   // same row twice
                 for (int j = 0; j < 4; ++j) if (j < k && key < fin[j]) { const unsigned long long tmp = fin[j]; fin[j] = key; key = tmp; }
             };
             for (int j = 0; j < k; ++j) {
@@ -507,7 +537,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     const int n_bound = metric == ISMHIP_METRIC_L2SQ ? n_splits * 4 : n_splits;
     float* cand_val = (float*)ism_scratch(ctx, SCR_KNN_CAND_VAL, (size_t)nq * (n_cand + n_bound) * sizeof(float));
     int* cand_idx = (int*)ism_scratch(ctx, SCR_KNN_CAND_IDX, (size_t)nq * n_cand * sizeof(int));
-    uint32_t* flags = (uint32_t*)ism_scratch(ctx, SCR_KNN_FLAGS, ((size_t)nq + 16) * sizeof(uint32_t));
+    uint32_t* flags = (uint32_t*)ism_scratch(ctx, SCR_KNN_FLAGS, (2 * (size_t)nq + 16) * sizeof(uint32_t));
     if (!cand_val || !cand_idx || !flags) return ISMHIP_ERR_NOMEM;
     float* cand_bound = cand_val + (size_t)nq * n_cand;
     uint32_t* flag_count = flags; uint32_t* flag_list = flags + 16;
@@ -528,7 +558,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         }
     }
     VerifyParams vp;
-    vp.gamma = 2.0f * (float)(cb->dim_pad + 8) * 5.9604645e-08f;
+    vp.ku = 1.01f * (float)cb->dim_pad * KNN_U;
     vp.cmax2 = cb->max_norm2;
     hipLaunchKernelGGL(k_knn_rerank, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
                        qq, nq, ldq, metric, cand_idx, n_cand, n_cand, cand_bound, n_bound, vp, k, idx_out, dist_out, flag_count, flag_list);
@@ -536,7 +566,8 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     {
         TimerScope ts(ctx, "knn_fallback");
         hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), (size_t)cb->dim_pad * sizeof(float), ctx->stream, cb->words, cb->dim, cb->dim_pad,
-                           cb->n_words, qq, ldq, metric, k, flag_count, flag_list, idx_out, dist_out);
+                           cb->n_words, qq, ldq, metric, k, tiles_per_split, cb->n_words_pad / (metric == ISMHIP_METRIC_L2SQ ? KNN_BM : CHI_B),
+                           flag_count, flag_list, idx_out, dist_out);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback");
     }
     return ISMHIP_OK;
