@@ -41,6 +41,8 @@ struct ismhip_cloud {
     GridMeta* meta = nullptr;             // [n_obj]
     uint32_t* cell_start = nullptr;       // [n_obj * ISM_GRID_STRIDE]
     float requested_cell = 0.f;
+    // capacities of the owned allocations (clouds are recycled through ismhip_ctx::cloud_pool)
+    size_t cap_pts = 0; int cap_obj = 0; bool cap_color = false;
 };
 
 struct ismhip_codebook {
@@ -82,6 +84,8 @@ struct ismhip_ctx {
     // LUTs for RGB->Lab (device)
     float* lut_srgb = nullptr;   // [256]
     float* lut_sxyz = nullptr;   // [4000]
+    // destroyed clouds keep their device allocations here for the next ismhip_cloud_create (no hipMalloc/hipFree per batch)
+    std::vector<ismhip_cloud*> cloud_pool;
 };
 
 enum ScratchSlot {

@@ -3,6 +3,8 @@
 #include <cmath>
 #include <cstring>
 
+extern "C" void ism_cloud_pool_release(ismhip_ctx* ctx);
+
 int ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;
@@ -86,6 +88,7 @@ int ismhip_ctx_destroy(ismhip_ctx* ctx) {
     if (!ctx) return ISMHIP_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ism_cloud_pool_release(ctx);
     for (auto& kv : ctx->scratch) if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto& kv : ctx->timers) for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);

@@ -215,25 +215,38 @@ int ismhip_cloud_create(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_h
         if (pt_offsets_h[o + 1] < pt_offsets_h[o]) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "cloud_create: offsets not monotone");
     if (pt_offsets_h[0] != 0) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "cloud_create: offsets must start at 0");
     ISM_HIP(ctx, hipSetDevice(ctx->device));
-    ismhip_cloud* c = new ismhip_cloud();
+    const uint32_t n_pts_new = pt_offsets_h[n_obj];
+    const size_t np = n_pts_new ? n_pts_new : 1;
+    // recycle a destroyed cloud whose allocations are large enough (steady-state batches never touch hipMalloc)
+    ismhip_cloud* c = nullptr;
+    for (size_t i = 0; i < ctx->cloud_pool.size(); ++i) {
+        ismhip_cloud* p = ctx->cloud_pool[i];
+        if (p->cap_pts >= np && p->cap_obj >= n_obj && (p->cap_color || !rgba)) { c = p; ctx->cloud_pool.erase(ctx->cloud_pool.begin() + i); break; }
+    }
+    const bool fresh = c == nullptr;
+    if (fresh) c = new ismhip_cloud();
     c->n_obj = n_obj;
     c->pt_off_h.assign(pt_offsets_h, pt_offsets_h + n_obj + 1);
-    c->n_pts = pt_offsets_h[n_obj];
+    c->n_pts = n_pts_new;
+    c->max_pts = 0;
     for (int o = 0; o < n_obj; ++o) c->max_pts = std::max(c->max_pts, pt_offsets_h[o + 1] - pt_offsets_h[o]);
     c->x = x; c->y = y; c->z = z; c->nx = nx; c->ny = ny; c->nz = nz; c->rgba = rgba;
     c->requested_cell = cell_size;
-    const size_t np = c->n_pts ? c->n_pts : 1;
-    const int n_arr = rgba ? 9 : 6;
-    float* block = nullptr;
-    auto fail = [&](int code, const char* msg) { ismhip_cloud_destroy(ctx, c); return ism_set_err(ctx, code, msg); };
-    if (hipMalloc((void**)&block, np * sizeof(float) * n_arr) != hipSuccess) return fail(ISMHIP_ERR_NOMEM, "cloud_create: hipMalloc sorted arrays");
-    c->sx = block; c->sy = block + np; c->sz = block + 2 * np; c->snx = block + 3 * np; c->sny = block + 4 * np; c->snz = block + 5 * np;
-    if (rgba) { c->sL = block + 6 * np; c->sa = block + 7 * np; c->sb = block + 8 * np; }
-    if (hipMalloc((void**)&c->sorig, np * 4) != hipSuccess || hipMalloc((void**)&c->cell_of_pt, np * 4) != hipSuccess ||
-        hipMalloc((void**)&c->rank_of_pt, np * 4) != hipSuccess || hipMalloc((void**)&c->pt_off, (size_t)(n_obj + 1) * 4) != hipSuccess ||
-        hipMalloc((void**)&c->meta, (size_t)n_obj * sizeof(GridMeta)) != hipSuccess ||
-        hipMalloc((void**)&c->cell_start, (size_t)n_obj * ISM_GRID_STRIDE * 4) != hipSuccess)
-        return fail(ISMHIP_ERR_NOMEM, "cloud_create: hipMalloc grid");
+    auto fail = [&](int code, const char* msg) { c->cap_pts = 0; ismhip_cloud_destroy(ctx, c); return ism_set_err(ctx, code, msg); };
+    if (fresh) {
+        const size_t capp = np + np / 8;
+        const int n_arr = rgba ? 9 : 6;
+        float* block = nullptr;
+        if (hipMalloc((void**)&block, capp * sizeof(float) * n_arr) != hipSuccess) return fail(ISMHIP_ERR_NOMEM, "cloud_create: hipMalloc sorted arrays");
+        c->sx = block; c->sy = block + capp; c->sz = block + 2 * capp; c->snx = block + 3 * capp; c->sny = block + 4 * capp; c->snz = block + 5 * capp;
+        if (rgba) { c->sL = block + 6 * capp; c->sa = block + 7 * capp; c->sb = block + 8 * capp; }
+        if (hipMalloc((void**)&c->sorig, capp * 4) != hipSuccess || hipMalloc((void**)&c->cell_of_pt, capp * 4) != hipSuccess ||
+            hipMalloc((void**)&c->rank_of_pt, capp * 4) != hipSuccess || hipMalloc((void**)&c->pt_off, (size_t)(n_obj + 1) * 4) != hipSuccess ||
+            hipMalloc((void**)&c->meta, (size_t)n_obj * sizeof(GridMeta)) != hipSuccess ||
+            hipMalloc((void**)&c->cell_start, (size_t)n_obj * ISM_GRID_STRIDE * 4) != hipSuccess)
+            return fail(ISMHIP_ERR_NOMEM, "cloud_create: hipMalloc grid");
+        c->cap_pts = capp; c->cap_obj = n_obj; c->cap_color = rgba != nullptr;
+    }
     if (hipMemcpyAsync(c->pt_off, c->pt_off_h.data(), (size_t)(n_obj + 1) * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail(ISMHIP_ERR_HIP, "cloud_create: offsets copy");
     {
@@ -256,9 +269,7 @@ int ismhip_cloud_create(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_h
     return ISMHIP_OK;
 }
 
-int ismhip_cloud_destroy(ismhip_ctx* ctx, ismhip_cloud* c) {
-    if (!c) return ISMHIP_ERR_INVALID;
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+static void cloud_free(ismhip_cloud* c) {
     if (c->sx) (void)hipFree(c->sx);
     if (c->sorig) (void)hipFree(c->sorig);
     if (c->cell_of_pt) (void)hipFree(c->cell_of_pt);
@@ -267,7 +278,20 @@ int ismhip_cloud_destroy(ismhip_ctx* ctx, ismhip_cloud* c) {
     if (c->meta) (void)hipFree(c->meta);
     if (c->cell_start) (void)hipFree(c->cell_start);
     delete c;
+}
+
+int ismhip_cloud_destroy(ismhip_ctx* ctx, ismhip_cloud* c) {
+    if (!c) return ISMHIP_ERR_INVALID;
+    // stream order protects the buffers: a recycled cloud is only rewritten by later work on the same stream
+    if (ctx && c->cap_pts > 0 && ctx->cloud_pool.size() < 4) { ctx->cloud_pool.push_back(c); return ISMHIP_OK; }
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    cloud_free(c);
     return ISMHIP_OK;
+}
+
+void ism_cloud_pool_release(ismhip_ctx* ctx) {
+    for (ismhip_cloud* c : ctx->cloud_pool) cloud_free(c);
+    ctx->cloud_pool.clear();
 }
 
 int ismhip_cloud_centroids(ismhip_ctx* ctx, const ismhip_cloud* cloud, float* centroid_out) {
