@@ -10,6 +10,8 @@
 #include <cmath>
 #include <limits>
 
+int ism_codebook_split_bf16(ismhip_ctx* ctx, ismhip_codebook* cb);
+
 namespace {
 
 __global__ void k_word_norms(const float* __restrict__ words, int n_words, int n_words_pad, int dim_pad, float* __restrict__ norm) {
@@ -184,6 +186,10 @@ int ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* w
         for (float v : nh) if (v > mx || v != v) mx = v;        // a NaN word poisons the bound -> every query takes the exact fallback
         cb->max_norm2 = mx;
     }
+    {
+        int rc = ism_codebook_split_bf16(ctx, cb);
+        if (rc != ISMHIP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(rc != ISMHIP_OK ? rc : ISMHIP_ERR_HIP, "codebook_create: bf16 split");
+    }
     *out = cb;
     return ISMHIP_OK;
 }
@@ -192,7 +198,7 @@ int ismhip_codebook_destroy(ismhip_ctx* ctx, ismhip_codebook* cb) {
     if (!cb) return ISMHIP_ERR_INVALID;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     void* ptrs[] = {cb->words, cb->word_norm, cb->word_weight, cb->vote_off, cb->vote_xyz, cb->vote_weight, cb->vote_class_weight,
-                    cb->vote_class, cb->vote_instance, cb->vote_bbox_quat, cb->vote_bbox_size, cb->class_sigma, cb->word_class};
+                    cb->vote_class, cb->vote_instance, cb->vote_bbox_quat, cb->vote_bbox_size, cb->class_sigma, cb->word_class, cb->words_bf16_hi};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete cb;
     return ISMHIP_OK;

@@ -50,6 +50,8 @@ struct ismhip_codebook {
     float* words = nullptr;          // [n_words_pad * dim_pad] row-major, zero padded (MFMA tile friendly)
     int n_words_pad = 0;
     float* word_norm = nullptr;      // [n_words_pad] squared L2 norm (+inf for padding rows)
+    unsigned short* words_bf16_hi = nullptr;   // [n_words_pad * dim_pad] RN_bf16(word)            (one allocation holds hi then lo)
+    unsigned short* words_bf16_lo = nullptr;   // [n_words_pad * dim_pad] RN_bf16(word - hi)
     float max_norm2 = 0.f;           // max squared norm over the real rows (bounds the fp32 contraction error of kNN)
     float* word_weight = nullptr;    // [n_words]
     uint32_t* vote_off = nullptr;    // [n_words+1]
@@ -86,12 +88,13 @@ struct ismhip_ctx {
     float* lut_sxyz = nullptr;   // [4000]
     // destroyed clouds keep their device allocations here for the next ismhip_cloud_create (no hipMalloc/hipFree per batch)
     std::vector<ismhip_cloud*> cloud_pool;
+    bool knn_force_f32 = false;  // env ISMHIP_KNN_F32=1: squared-L2 candidates by the exact-f32 MFMA kernel instead of bf16x3
 };
 
 enum ScratchSlot {
     SCR_KP_OFF = 1, SCR_TIE_LIST, SCR_TIE_REC, SCR_TIE_KEYS, SCR_COUNTERS, SCR_KNN_CAND_IDX, SCR_KNN_CAND_VAL,
     SCR_QNORM, SCR_FPFH_FLAG, SCR_FPFH_LIST, SCR_FPFH_SPFH, SCR_FPFH_LOOKUP, SCR_SLOT_OFF, SCR_CLASS_BW,
-    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS
+    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT
 };
 
 int  ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg);

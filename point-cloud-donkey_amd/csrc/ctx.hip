@@ -2,6 +2,7 @@
 #include "common.h"
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 extern "C" void ism_cloud_pool_release(ismhip_ctx* ctx);
 
@@ -60,6 +61,7 @@ static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ISMHIP_ERR_NODEVICE;   // code objects are gfx950 only
     ismhip_ctx* ctx = new ismhip_ctx();
     ctx->device = device;
+    { const char* e = getenv("ISMHIP_KNN_F32"); ctx->knn_force_f32 = e && e[0] == '1'; }
     if (!own) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ISMHIP_ERR_HIP; }

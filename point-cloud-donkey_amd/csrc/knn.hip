@@ -185,6 +185,170 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// L2 candidates on the BF16 matrix cores with a 3-term split (q = qh + ql, c = ch + cl, dot ~ qh.ch + qh.cl + ql.ch)
+// ---------------------------------------------------------------------------------------------
+// The candidate stage only has to be accurate enough for the proof in k_knn_rerank to go through; its result is never
+// returned. bf16 keeps fp32's exponent range (no underflow of the residuals) and v_mfma_f32_32x32x16_bf16 runs at 16x the
+// rate of the f32-input MFMA, so three of them per 16-k step are ~5x cheaper than the exact-f32 contraction.
+// Error bound used by the proof (VerifyParams::dot_rel, relative to |q||c|):
+//   representation : |q - qh - ql| <= 2^-18 |q| element-wise (two RN-to-bf16 steps, u = 2^-9), the dropped ql.cl term and
+//                    the two residual cross terms give <= 3.1 * 2^-18
+//   accumulation   : products of bf16 pairs are exact in fp32; the 3K-term sum is modelled as fp32 additions in ANY order
+//                    with a per-add unit roundoff of 2^-23 (i.e. not even assuming round-to-nearest inside the MFMA)
+//                    -> 1.01 * 3K * 2^-23
+// tests/test_gpu_parity.py::test_knn_bf16x3_error_model checks the measured error against this model on random and
+// adversarial (all-positive, large-norm) data.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+#define KB_ROW 32        // halves per LDS row (one 32-k slice); rows are 64 B, 16-byte segments XOR-swizzled by (row>>2)&3
+
+__device__ __forceinline__ u16 f32_to_bf16_rn(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u16)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// rows beyond n and columns beyond dim are zero; hi = RN_bf16(x), lo = RN_bf16(x - hi)
+__global__ void k_split_bf16(const float* __restrict__ src, int n, int dim, int ld, int n_pad, int dim_pad,
+                             u16* __restrict__ hi, u16* __restrict__ lo) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_pad * dim_pad) return;
+    const int row = (int)(i / dim_pad), col = (int)(i % dim_pad);
+    float x = 0.f;
+    if (row < n && col < dim) x = src[(size_t)row * ld + col];
+    const u16 h = f32_to_bf16_rn(x);
+    const float hf = __uint_as_float((unsigned)h << 16);
+    hi[i] = h; lo[i] = f32_to_bf16_rn(x - hf);
+}
+
+template <int T>
+__global__ __launch_bounds__(256, 2) void k_knn_l2_bf16x3(const u16* __restrict__ wh, const u16* __restrict__ wl,
+                                                          const float* __restrict__ word_norm, int n_tiles_m, int dim_pad,
+                                                          const u16* __restrict__ qh, const u16* __restrict__ ql, int nq,
+                                                          int tiles_per_split,
+                                                          float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
+                                                          float* __restrict__ cand_bound, int bound_stride) {
+    __shared__ __attribute__((aligned(16))) u16 sAh[2][KNN_BM * KB_ROW];
+    __shared__ __attribute__((aligned(16))) u16 sAl[2][KNN_BM * KB_ROW];
+    __shared__ __attribute__((aligned(16))) u16 sBh[2][KNN_BN * KB_ROW];
+    __shared__ __attribute__((aligned(16))) u16 sBl[2][KNN_BN * KB_ROW];
+    __shared__ float sCn[KNN_BM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int qtile = blockIdx.x, split = blockIdx.y;
+    const int mt0 = split * tiles_per_split;
+    const int mt1 = min(n_tiles_m, mt0 + tiles_per_split);
+    const int nk = dim_pad / KNN_BK;
+
+    // staging map: 128 rows x 4 segments of 16 B per array; thread -> rows tid/4 and tid/4 + 64, segment tid%4
+    const int srow = tid >> 2, sseg = tid & 3;
+    const int sdst0 = srow * KB_ROW + ((sseg ^ ((srow >> 2) & 3)) << 3);
+    const int sdst1 = (srow + 64) * KB_ROW + ((sseg ^ (((srow + 64) >> 2) & 3)) << 3);
+    const size_t qoff0 = (size_t)(qtile * KNN_BN + srow) * dim_pad + sseg * 8;
+    const size_t qoff1 = qoff0 + (size_t)64 * dim_pad;
+
+    // fragment read offsets (halves) inside a stage: row * 32 + swizzled segment * 8; segment = kstep*2 + h
+    int offA[2][2], offB[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ra = wr * 64 + m * 32 + r, rb = wc * 64 + m * 32 + r, seg = ks * 2 + h;
+            offA[m][ks] = ra * KB_ROW + ((seg ^ ((ra >> 2) & 3)) << 3);
+            offB[m][ks] = rb * KB_ROW + ((seg ^ ((rb >> 2) & 3)) << 3);
+        }
+
+    TopT<T + 1> top[2];
+    top[0].init(); top[1].init();
+
+    for (int mt = mt0; mt < mt1; ++mt) {
+        const size_t aoff0 = (size_t)(mt * KNN_BM + srow) * dim_pad + sseg * 8;
+        const size_t aoff1 = aoff0 + (size_t)64 * dim_pad;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+        f32x4 g[8];
+        g[0] = *(const f32x4*)(wh + aoff0); g[1] = *(const f32x4*)(wh + aoff1);
+        g[2] = *(const f32x4*)(wl + aoff0); g[3] = *(const f32x4*)(wl + aoff1);
+        g[4] = *(const f32x4*)(qh + qoff0); g[5] = *(const f32x4*)(qh + qoff1);
+        g[6] = *(const f32x4*)(ql + qoff0); g[7] = *(const f32x4*)(ql + qoff1);
+        __syncthreads();                                   // previous tile's epilogue has finished reading sCn / LDS
+        if (tid < KNN_BM) sCn[tid] = word_norm[mt * KNN_BM + tid];
+        *(f32x4*)(&sAh[0][sdst0]) = g[0]; *(f32x4*)(&sAh[0][sdst1]) = g[1];
+        *(f32x4*)(&sAl[0][sdst0]) = g[2]; *(f32x4*)(&sAl[0][sdst1]) = g[3];
+        *(f32x4*)(&sBh[0][sdst0]) = g[4]; *(f32x4*)(&sBh[0][sdst1]) = g[5];
+        *(f32x4*)(&sBl[0][sdst0]) = g[6]; *(f32x4*)(&sBl[0][sdst1]) = g[7];
+        __syncthreads();
+
+        for (int kc = 0; kc < nk; ++kc) {
+            const int cur = kc & 1;
+            if (kc + 1 < nk) {
+                const int ko = (kc + 1) * KNN_BK;
+                g[0] = *(const f32x4*)(wh + aoff0 + ko); g[1] = *(const f32x4*)(wh + aoff1 + ko);
+                g[2] = *(const f32x4*)(wl + aoff0 + ko); g[3] = *(const f32x4*)(wl + aoff1 + ko);
+                g[4] = *(const f32x4*)(qh + qoff0 + ko); g[5] = *(const f32x4*)(qh + qoff1 + ko);
+                g[6] = *(const f32x4*)(ql + qoff0 + ko); g[7] = *(const f32x4*)(ql + qoff1 + ko);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    ah[m] = *(const bf16x8*)(&sAh[cur][offA[m][ks]]); al[m] = *(const bf16x8*)(&sAl[cur][offA[m][ks]]);
+                    bh[m] = *(const bf16x8*)(&sBh[cur][offB[m][ks]]); bl[m] = *(const bf16x8*)(&sBl[cur][offB[m][ks]]);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    }
+            }
+            if (kc + 1 < nk) {
+                const int nx = cur ^ 1;
+                *(f32x4*)(&sAh[nx][sdst0]) = g[0]; *(f32x4*)(&sAh[nx][sdst1]) = g[1];
+                *(f32x4*)(&sAl[nx][sdst0]) = g[2]; *(f32x4*)(&sAl[nx][sdst1]) = g[3];
+                *(f32x4*)(&sBh[nx][sdst0]) = g[4]; *(f32x4*)(&sBh[nx][sdst1]) = g[5];
+                *(f32x4*)(&sBl[nx][sdst0]) = g[6]; *(f32x4*)(&sBl[nx][sdst1]) = g[7];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row_l = wr * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float cn = sCn[row_l];
+                const int idx = mt * KNN_BM + row_l;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) top[ni].push(cn - 2.0f * acc[mi][ni][e], idx);
+            }
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int qi = qtile * KNN_BN + wc * 64 + ni * 32 + r;
+        if (qi < nq) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const size_t o = (size_t)qi * cand_stride + split * (4 * T) + (wr * 2 + h) * T + t;
+                cand_val[o] = top[ni].v[t]; cand_idx[o] = top[ni].i[t];
+            }
+            cand_bound[(size_t)qi * bound_stride + split * 4 + (wr * 2 + h)] = top[ni].v[T];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // chi-square candidates on the vector ALUs
 // ---------------------------------------------------------------------------------------------
@@ -311,7 +475,8 @@ __device__ __forceinline__ float flann_chi2(const float* a, const float* b, int 
 }
 
 struct VerifyParams {
-    float ku;         // 1.01 * K * u : relative error bound of a K-term fp32 fma chain / K-term functor sum (u = 2^-24)
+    float ku;         // 1.01 * K * u : relative error bound of a K-term fp32 functor sum (u = 2^-24)
+    float dot_rel;    // bound on |approx(q.c) - q.c| / (|q||c|) of the candidate kernel (f32 fma chain: ku; bf16x3: see k_knn_l2_bf16x3)
     float cmax2;      // max |c|^2 over the codebook (L2 only)
 };
 #define KNN_U 5.9604645e-08f
@@ -357,7 +522,7 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
         if (key == mn) key = ~0ull;     // rows are unique among candidates, so exactly one lane retires
     }
     // Proof of exactness, slot by slot. A codeword dropped by slot b has approximate score >= bnd_b, so
-    //   L2  : true distance D >= |q|^2 (1 - 16u) + bnd_b - eps_s,  eps_s = 17u |c|max^2 + (2.02 K + 2) u |q||c|max
+    //   L2  : true distance D >= |q|^2 (1 - 16u) + bnd_b - eps_s,  eps_s = 17u |c|max^2 + (2 dot_rel + 2u) |q||c|max
     //         (|c|^2 by a short tree sum: 16u; K-term fma chain: 1.01 K u on sum|q_i c_i| <= |q||c|; final subtraction: u)
     //   chi2: all terms are non-negative, v_rcp_f32 is 1 ulp: D >= bnd_b (1 - (K + 8) u)
     // and its functor value is >= D (1 - 1.01 K u). If that is above the k-th exact functor value, the slot cannot hold a
@@ -369,7 +534,7 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
             const float lo = bnd * (1.f - ((float)dim_pad + 8.f) * KNN_U) * (1.f - vp.ku);
             viol = !(dk < lo);
         } else {
-            const float eps_s = 17.f * KNN_U * vp.cmax2 + (2.f * vp.ku + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2);
+            const float eps_s = 17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2);
             const float rhs = qn2 * (1.f - 16.f * KNN_U) + bnd - eps_s;
             viol = !(dk < rhs - vp.ku * fabsf(rhs) - 1e-37f);
         }
@@ -542,9 +707,26 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     float* cand_bound = cand_val + (size_t)nq * n_cand;
     uint32_t* flag_count = flags; uint32_t* flag_list = flags + 16;
     ISM_HIP(ctx, hipMemsetAsync(flag_count, 0, 4, ctx->stream));
+    // candidate kernel for squared L2: bf16x3 (default) or the exact-f32 MFMA contraction (ISMHIP_KNN_F32=1, kept for A/B runs)
+    const bool use_bf16 = metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi != nullptr && !ctx->knn_force_f32;
+    u16 *q_hi = nullptr, *q_lo = nullptr;
+    if (use_bf16) {
+        const int nq_pad = (nq + KNN_BN - 1) / KNN_BN * KNN_BN;
+        const size_t tot = (size_t)nq_pad * cb->dim_pad;
+        q_hi = (u16*)ism_scratch(ctx, SCR_KNN_QSPLIT, tot * 2 * sizeof(u16));
+        if (!q_hi) return ISMHIP_ERR_NOMEM;
+        q_lo = q_hi + tot;
+        hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->dim_pad, q_hi, q_lo);
+        ISM_CHECK_LAUNCH(ctx, "k_split_bf16");
+    }
     {
         TimerScope ts(ctx, metric == ISMHIP_METRIC_L2SQ ? "knn_l2_mfma" : "knn_chi2");
-        if (metric == ISMHIP_METRIC_L2SQ) {
+        if (metric == ISMHIP_METRIC_L2SQ && use_bf16) {
+            const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
+            hipLaunchKernelGGL(k_knn_l2_bf16x3<T>, dim3(n_qt, n_splits), dim3(256), 0, ctx->stream, cb->words_bf16_hi, cb->words_bf16_lo, cb->word_norm,
+                               cb->n_words_pad / KNN_BM, cb->dim_pad, q_hi, q_lo, nq, tiles_per_split, cand_val, cand_idx, n_cand, cand_bound, n_bound);
+            ISM_CHECK_LAUNCH(ctx, "k_knn_l2_bf16x3");
+        } else if (metric == ISMHIP_METRIC_L2SQ) {
             const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
             hipLaunchKernelGGL(k_knn_l2_mfma<T>, dim3(n_qt, n_splits), dim3(256), 0, ctx->stream, cb->words, cb->word_norm,
                                cb->n_words_pad / KNN_BM, cb->dim_pad, qq, nq, ldq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand,
@@ -559,6 +741,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     }
     VerifyParams vp;
     vp.ku = 1.01f * (float)cb->dim_pad * KNN_U;
+    vp.dot_rel = use_bf16 ? (3.1f * 3.814697265625e-06f + 1.01f * 3.f * (float)cb->dim_pad * 1.1920929e-07f) : vp.ku;
     vp.cmax2 = cb->max_norm2;
     hipLaunchKernelGGL(k_knn_rerank, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
                        qq, nq, ldq, metric, cand_idx, n_cand, n_cand, cand_bound, n_bound, vp, k, idx_out, dist_out, flag_count, flag_list);
@@ -574,6 +757,17 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
 }
 
 }  // namespace
+
+// bf16 hi/lo images of the codebook for k_knn_l2_bf16x3 (called once from ismhip_codebook_create)
+int ism_codebook_split_bf16(ismhip_ctx* ctx, ismhip_codebook* cb) {
+    const size_t tot = (size_t)cb->n_words_pad * cb->dim_pad;
+    if (hipMalloc((void**)&cb->words_bf16_hi, tot * 2 * sizeof(u16)) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook bf16 images");
+    cb->words_bf16_lo = cb->words_bf16_hi + tot;
+    hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, cb->words, cb->n_words_pad, cb->dim_pad, cb->dim_pad,
+                       cb->n_words_pad, cb->dim_pad, cb->words_bf16_hi, cb->words_bf16_lo);
+    ISM_CHECK_LAUNCH(ctx, "k_split_bf16");
+    return ISMHIP_OK;
+}
 
 extern "C" {
 

@@ -253,6 +253,24 @@ def test_knn_adversarial_needs_the_exact_fallback(pkg, gpu, ora, metric):
     ms, n = ctx.timer("knn_fallback")
 
 
+def test_knn_matches_oracle_on_clustered_unit_vectors(pkg, gpu, ora):
+    """descriptor-like data: unit vectors in tight clusters (many near neighbours within 1e-3 of the best) — the regime where
+    the bf16x3 candidate scores are least able to separate the winners and the proof/fallback has to work."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(99)
+    centres = rng.random((50, 352)).astype(np.float32)
+    words = (np.repeat(centres, 80, axis=0) + 0.01 * rng.random((4000, 352))).astype(np.float32)
+    words /= np.linalg.norm(words, axis=1, keepdims=True)
+    q = (centres[rng.integers(0, 50, 1000)] + 0.01 * rng.random((1000, 352))).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    host, cb = _cb(pkg, gpu, words)
+    for k in (1, 2, 4):
+        idx, dist = pkg.capi.knn(ctx, cb, 0, T(q, dev), k)
+        widx, wdist = ora.knn(0, words, q, k)
+        assert np.array_equal(idx.cpu().numpy(), widx)
+        assert np.array_equal(dist.cpu().numpy(), wdist)
+
+
 def test_knn_ties_kat_and_ratio(pkg, gpu, ora):
     ctx, dev = gpu
     k = KAT["knn_ties"]
