@@ -128,6 +128,7 @@ def main():
 
     # ---- per-kernel device time (HIP events on the ctx stream, timed region only)
     tm = {n: ctx.timer(n) for n in ["grid", "lrf", "shot352", "knn", "knn_l2_mfma", "knn_fallback", "cast_votes", "maxima"]}
+    knn_fb = {"queries": int(ctx.timer("knn_flagged_queries")[0]), "slot_items": int(ctx.timer("knn_flagged_items")[0])}
     ctx.timers_enable(False)
     nq_per_launch = None
     roofline = roofline_shot = None
@@ -185,7 +186,7 @@ def main():
                        "classes": C, "codebook_words": int(n_words), "descriptor_dim": cfg.dim, "parallelism": f"objects sharded over {world} GPU(s), codebook replicated, 1 all-gather/step"},
             "roofline": roofline, "roofline_shot": roofline_shot, "cpu_baseline": cpu,
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in tm.items()},
-            "accuracy_last_step": round(correct / max(1, total), 4), "train_seconds": round(t_train, 1),
+            "knn_exact_fallback_last_step": knn_fb, "accuracy_last_step": round(correct / max(1, total), 4), "train_seconds": round(t_train, 1),
         }
         print(json.dumps(line))
     if distributed:

@@ -137,6 +137,11 @@ int ismhip_timers_reset(ismhip_ctx* ctx) {
 int ismhip_timer_get(ismhip_ctx* ctx, const char* name, double* ms_out, int64_t* launches_out) {
     if (!ctx || !name) return ISMHIP_ERR_INVALID;
     resolve_timers(ctx);
+    if (std::strcmp(name, "knn_flagged_queries") == 0 || std::strcmp(name, "knn_flagged_items") == 0) {     // counters, not times
+        if (ms_out) *ms_out = (double)ctx->knn_stats[name[12] == 'q' ? 0 : 1];
+        if (launches_out) *launches_out = 1;
+        return ISMHIP_OK;
+    }
     auto it = ctx->timers.find(name);
     if (ms_out) *ms_out = it == ctx->timers.end() ? 0.0 : it->second.ms;
     if (launches_out) *launches_out = it == ctx->timers.end() ? 0 : it->second.launches;

@@ -483,32 +483,49 @@ struct VerifyParams {
 
 __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ words, int dim, int dim_pad, int n_words,
                                                     const float* __restrict__ q, int nq, int ldq, int metric,
-                                                    const int* __restrict__ cand_idx, int cand_stride, int n_cand,
+                                                    const int* __restrict__ cand_idx, const float* __restrict__ cand_val, int cand_stride, int n_cand,
                                                     const float* __restrict__ cand_bound, int n_bound, VerifyParams vp,
                                                     int k, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
-                                                    uint32_t* __restrict__ flag_count, uint32_t* __restrict__ flag_list) {
+                                                    uint32_t* __restrict__ flag_count, uint32_t* __restrict__ qrec, uint32_t* __restrict__ items) {
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq) return;
     const int lane = lane_id();
     const float* qp = q + (size_t)qi * ldq;
-    // n_cand <= 64 by construction (host): one candidate per lane
-    unsigned long long key = ~0ull;
-    if (lane < n_cand) {
-        const int id = cand_idx[(size_t)qi * cand_stride + lane];
-        if (id >= 0 && id < n_words) {
-            const float* wp = words + (size_t)id * dim_pad;
-            const float d = metric == ISMHIP_METRIC_CHI2 ? flann_chi2(qp, wp, dim) : flann_l2(qp, wp, dim);
-            // distances are >= 0 (or NaN); positive float bit patterns order like unsigned integers
-            key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;
-        }
-    }
-    // every bound slot (L2: split x 4 lane slots, chi2: split) holds the smallest approximate score that slot dropped
-    float bnd = __builtin_inff();
-    if (lane < n_bound) bnd = cand_bound[(size_t)qi * n_bound + lane];
+    // |q|^2 by a wave sum (needed by the error bounds below)
     float qn2 = 0.f;
     for (int i = lane; i < dim; i += 64) { const float v = qp[i]; qn2 += v * v; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qn2 += __shfl_xor(qn2, o, 64);
+    // n_cand <= 64 by construction (host): one candidate per lane. Only candidates whose approximate score is within twice the
+    // error bound of the k-th best approximate score can be among the exact k best; the others skip the functor.
+    int id = -1; float av = __builtin_inff();
+    if (lane < n_cand) { id = cand_idx[(size_t)qi * cand_stride + lane]; av = cand_val[(size_t)qi * cand_stride + lane]; }
+    if (!(id >= 0 && id < n_words)) { id = -1; av = __builtin_inff(); }
+    float kth = av;
+    {
+        float cur = av;                       // k-th smallest approximate score (k <= 4) by k rounds of wave-min
+        for (int j = 0; j < k; ++j) {
+            float mn = cur;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
+            kth = mn;
+            const unsigned long long eq = __ballot(cur == mn);
+            if (eq && lane == __ffsll((long long)eq) - 1) cur = __builtin_inff();      // retire one instance
+        }
+    }
+    float slack;
+    if (metric == ISMHIP_METRIC_CHI2) slack = 4.f * (((float)dim_pad + 8.f) * KNN_U + vp.ku) * fabsf(kth);
+    else slack = 2.f * (17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2)) + 4.f * vp.ku * (qn2 + fabsf(kth) + vp.cmax2);
+    unsigned long long key = ~0ull;
+    if (id >= 0 && !(av > kth + slack)) {     // NaN scores are never skipped
+        const float* wp = words + (size_t)id * dim_pad;
+        const float d = metric == ISMHIP_METRIC_CHI2 ? flann_chi2(qp, wp, dim) : flann_l2(qp, wp, dim);
+        // distances are >= 0 (or NaN); positive float bit patterns order like unsigned integers
+        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;
+    }
+    // every bound slot (L2: split x 4 lane slots, chi2: split) holds the smallest approximate score that slot dropped
+    float bnd = __builtin_inff();
+    if (lane < n_bound) bnd = cand_bound[(size_t)qi * n_bound + lane];
     float dk = 0.f; bool have_k = true;
     for (int j = 0; j < k; ++j) {
         unsigned long long mn = key;
@@ -539,97 +556,108 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
             viol = !(dk < rhs - vp.ku * fabsf(rhs) - 1e-37f);
         }
     }
+    // queue: one record per unproven query {query, first item, #items} and one work item {query, slot} per failing slot
     const unsigned long long vmask = __ballot(viol);
-    if (vmask != 0ull && lane == 0) {
-        const uint32_t slot = atomicAdd(flag_count, 1u);
-        flag_list[2 * (size_t)slot] = (uint32_t)qi; flag_list[2 * (size_t)slot + 1] = (uint32_t)vmask;
+    if (vmask != 0ull) {
+        const int nv = __popcll(vmask);
+        uint32_t ibase = 0;
+        if (lane == 0) {
+            const uint32_t qs = atomicAdd(&flag_count[0], 1u);
+            ibase = atomicAdd(&flag_count[1], (uint32_t)nv);
+            qrec[3 * (size_t)qs] = (uint32_t)qi; qrec[3 * (size_t)qs + 1] = ibase; qrec[3 * (size_t)qs + 2] = (uint32_t)nv;
+        }
+        ibase = __shfl(ibase, 0, 64);
+        if (viol) {
+            const uint32_t it = ibase + __popcll(vmask & ((1ull << lane) - 1ull));
+            items[2 * (size_t)it] = (uint32_t)qi; items[2 * (size_t)it + 1] = (uint32_t)lane;
+        }
     }
 }
 
-// Exact scan for the queries whose candidate result could not be proven, restricted to the codeword rows of the slots that
-// failed. One workgroup per queued query; a wave handles 4 rows per step (16 lanes each, 64-byte coalesced segments); direct
-// (a-b)^2 [/(a+b)] sums pick the rows that can still matter, the FLANN functor order ranks them.
+// Exact scan for the slots that could not be proven. One WAVE per (query, slot) work item; the wave handles 4 codeword rows
+// per step (16 lanes each, 64-byte coalesced segments) with the query held in registers; direct (a-b)^2 [/(a+b)] sums pick
+// the rows that can still matter, the FLANN functor order ranks them. Each item leaves its k best (distance,row) keys in
+// item_out; k_knn_fallback_merge folds them into the query's result.
 // Slot -> rows: L2 bit b = split*4 + wr*2 + h owns, in every 128-row tile of its split, the 32 rows wr*64 + x with bit 2 of x
 // equal to h (the C/D layout of the 32x32 MFMA tile, see k_knn_l2_mfma); chi2 bit b = split owns all rows of its split.
+#define KNN_FB_MAXJ 84          // dim_pad <= 1344 -> at most 84 elements per lane of a 16-lane row group
 __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ words, int dim, int dim_pad, int n_words,
                                                       const float* __restrict__ q, int ldq, int metric, int k, int tiles_per_split, int n_tiles,
-                                                      const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ flag_list,
-                                                      int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
-    extern __shared__ float s_q[];                       // [dim_pad]
-    __shared__ unsigned long long s_top[4][4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+                                                      const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ items,
+                                                      const int32_t* __restrict__ idx_in, const float* __restrict__ dist_in,
+                                                      unsigned long long* __restrict__ item_out) {
+    const int lane = threadIdx.x & 63;
     const int g = lane >> 4, l16 = lane & 15;
-    const uint32_t n_flag = *flag_count;
+    const uint32_t n_items = flag_count[1];
     const bool l2 = metric != ISMHIP_METRIC_CHI2;
     const int tile_rows = l2 ? KNN_BM : CHI_B;
-    for (uint32_t t = blockIdx.x; t < n_flag; t += gridDim.x) {
-        const int qi = (int)flag_list[2 * (size_t)t];
-        uint32_t mask = flag_list[2 * (size_t)t + 1];
-        __syncthreads();
-        for (int i = tid; i < dim_pad; i += 256) s_q[i] = i < dim ? q[(size_t)qi * ldq + i] : 0.f;
-        __syncthreads();
-        // current k-th best exact distance from the candidate stage (inf when fewer than k candidates were valid)
+    const int rows_per_tile = l2 ? 32 : CHI_B;
+    const int nj = dim_pad / 16;
+    const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    for (uint32_t it = gw; it < n_items; it += nw) {
+        const int qi = (int)items[2 * (size_t)it], b = (int)items[2 * (size_t)it + 1];
+        const float* qp = q + (size_t)qi * ldq;
+        const int split = l2 ? (b >> 2) : b;
+        const int wr = (b >> 1) & 1, h = b & 1;
+        const int mt0 = split * tiles_per_split, mt1 = min(n_tiles, mt0 + tiles_per_split);
+        const int total = (mt1 - mt0) * rows_per_tile;
         unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
         float thr = __builtin_inff();
         {
-            const int id = idx_out[(size_t)qi * k + (k - 1)];
-            if (id >= 0) thr = dist_out[(size_t)qi * k + (k - 1)];
+            const int id = idx_in[(size_t)qi * k + (k - 1)];
+            if (id >= 0) thr = dist_in[(size_t)qi * k + (k - 1)];
         }
-        while (mask) {
-            const int b = __ffs((int)mask) - 1; mask &= mask - 1;
-            const int split = l2 ? (b >> 2) : b;
-            const int wr = (b >> 1) & 1, h = b & 1;
-            const int mt0 = split * tiles_per_split, mt1 = min(n_tiles, mt0 + tiles_per_split);
-            const int rows_per_tile = l2 ? 32 : CHI_B;
-            // the slot's rows, enumerated as (tile, y); the 4 waves take interleaved groups of 4 rows
-            const int total = (mt1 - mt0) * rows_per_tile;
-            for (int e0 = wv * 4; e0 < total; e0 += 16) {
-                const int e = e0 + g;
-                int r = n_words;                                  // out of range = idle group
-                if (e < total) {
-                    const int tile = mt0 + e / rows_per_tile, y = e % rows_per_tile;
-                    const int x = l2 ? (wr * 64 + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y;
-                    r = tile * tile_rows + x;
-                }
-                float part = 0.f;
-                if (r < n_words) {
-                    const float* wp = words + (size_t)r * dim_pad;
-                    if (!l2) { for (int i = l16; i < dim_pad; i += 16) { const float a = s_q[i], c = wp[i], sm = a + c, df = a - c; part += sm > 0.f ? df * df / sm : 0.f; } }
-                    else { for (int i = l16; i < dim_pad; i += 16) { const float df = s_q[i] - wp[i]; part += df * df; } }
-                }
+        for (int e0 = 0; e0 < total; e0 += 4) {
+            const int e = e0 + g;
+            int r = n_words;                                  // out of range = idle group
+            if (e < total) {
+                const int tile = mt0 + e / rows_per_tile, y = e % rows_per_tile;
+                const int x = l2 ? (wr * 64 + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y;
+                r = tile * tile_rows + x;
+            }
+            float part = 0.f;
+            if (r < n_words) {
+                const float* wp = words + (size_t)r * dim_pad;
+                if (!l2) { for (int j = 0; j < nj; ++j) { const int i = l16 + 16 * j; const float a = i < dim ? qp[i] : 0.f, c = wp[i], sm = a + c, df = a - c; part += sm > 0.f ? df * df / sm : 0.f; } }
+                else { for (int j = 0; j < nj; ++j) { const int i = l16 + 16 * j; const float df = (i < dim ? qp[i] : 0.f) - wp[i]; part += df * df; } }
+            }
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-                const bool hit = r < n_words && !(part > thr * 1.0001f + 1e-30f);      // NaN-safe: unordered compares count as hits
-                unsigned long long hm = __ballot(hit && l16 == 0);
-                while (hm) {                                                             // rare
-                    const int src = __ffsll((long long)hm) - 1; hm &= hm - 1;
-                    const int rr = __shfl(r, src, 64);
-                    const float d = l2 ? flann_l2(s_q, words + (size_t)rr * dim_pad, dim) : flann_chi2(s_q, words + (size_t)rr * dim_pad, dim);
-                    unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)rr;
-                    if (d != d) key = ~0ull - 1;                                        // NaN sorts last but stays a valid row
+            for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            const bool hit = r < n_words && !(part > thr * 1.0001f + 1e-30f);      // NaN-safe: unordered compares count as hits
+            unsigned long long hm = __ballot(hit && l16 == 0);
+            while (hm) {                                                             // rare
+                const int src = __ffsll((long long)hm) - 1; hm &= hm - 1;
+                const int rr = __shfl(r, src, 64);
+                const float d = l2 ? flann_l2(qp, words + (size_t)rr * dim_pad, dim) : flann_chi2(qp, words + (size_t)rr * dim_pad, dim);
+                unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)rr;
+                if (d != d) key = ~0ull - 1;                                        // NaN sorts last but stays a valid row
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (j < k && key < best[j]) { const unsigned long long tmp = best[j]; best[j] = key; key = tmp; }
-                    if (best[k - 1] != ~0ull) thr = fminf(thr, __uint_as_float((unsigned)(best[k - 1] >> 32)));
-                }
+                for (int j = 0; j < 4; ++j) if (j < k && key < best[j]) { const unsigned long long tmp = best[j]; best[j] = key; key = tmp; }
+                if (best[k - 1] != ~0ull) thr = fminf(thr, __uint_as_float((unsigned)(best[k - 1] >> 32)));
             }
         }
-        if (lane == 0) for (int j = 0; j < 4; ++j) s_top[wv][j] = best[j];
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long fin[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-            auto ins = [&](unsigned long long key) {
-                for (int j = 0; j < k; ++j) if (fin[j] != ~0ull && (fin[j] & 0xffffffffull) == (key & 0xffffffffull)) return;   // same row twice
-                for (int j = 0; j < 4; ++j) if (j < k && key < fin[j]) { const unsigned long long tmp = fin[j]; fin[j] = key; key = tmp; }
-            };
-            for (int j = 0; j < k; ++j) {
-                const int id = idx_out[(size_t)qi * k + j];
-                if (id >= 0) ins(((unsigned long long)__float_as_uint(dist_out[(size_t)qi * k + j]) << 32) | (unsigned)id);
-            }
-            for (int w = 0; w < 4; ++w) for (int j = 0; j < k; ++j) if (s_top[w][j] != ~0ull) ins(s_top[w][j]);
-            for (int j = 0; j < k; ++j) {
-                if (fin[j] == ~0ull) { idx_out[(size_t)qi * k + j] = -1; dist_out[(size_t)qi * k + j] = __builtin_nanf(""); }
-                else { idx_out[(size_t)qi * k + j] = (int)(fin[j] & 0xffffffffull); dist_out[(size_t)qi * k + j] = __uint_as_float((unsigned)(fin[j] >> 32)); }
-            }
+        if (lane < 4) item_out[4 * (size_t)it + lane] = lane == 0 ? best[0] : (lane == 1 ? best[1] : (lane == 2 ? best[2] : best[3]));
+    }
+}
+
+__global__ void k_knn_fallback_merge(int k, const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ qrec,
+                                     const unsigned long long* __restrict__ item_out, int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
+    const uint32_t n_q = flag_count[0];
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_q; t += gridDim.x * blockDim.x) {
+        const int qi = (int)qrec[3 * (size_t)t]; const uint32_t ibase = qrec[3 * (size_t)t + 1], ni = qrec[3 * (size_t)t + 2];
+        unsigned long long fin[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        auto ins = [&](unsigned long long key) {
+            for (int j = 0; j < k; ++j) if (fin[j] != ~0ull && (fin[j] & 0xffffffffull) == (key & 0xffffffffull)) return;   // same row twice
+            for (int j = 0; j < 4; ++j) if (j < k && key < fin[j]) { const unsigned long long tmp = fin[j]; fin[j] = key; key = tmp; }
+        };
+        for (int j = 0; j < k; ++j) {
+            const int id = idx_out[(size_t)qi * k + j];
+            if (id >= 0) ins(((unsigned long long)__float_as_uint(dist_out[(size_t)qi * k + j]) << 32) | (unsigned)id);
+        }
+        for (uint32_t i = 0; i < ni; ++i) for (int j = 0; j < k; ++j) { const unsigned long long key = item_out[4 * (size_t)(ibase + i) + j]; if (key != ~0ull) ins(key); }
+        for (int j = 0; j < k; ++j) {
+            if (fin[j] == ~0ull) { idx_out[(size_t)qi * k + j] = -1; dist_out[(size_t)qi * k + j] = __builtin_nanf(""); }
+            else { idx_out[(size_t)qi * k + j] = (int)(fin[j] & 0xffffffffull); dist_out[(size_t)qi * k + j] = __uint_as_float((unsigned)(fin[j] >> 32)); }
         }
     }
 }
@@ -702,11 +730,14 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     const int n_bound = metric == ISMHIP_METRIC_L2SQ ? n_splits * 4 : n_splits;
     float* cand_val = (float*)ism_scratch(ctx, SCR_KNN_CAND_VAL, (size_t)nq * (n_cand + n_bound) * sizeof(float));
     int* cand_idx = (int*)ism_scratch(ctx, SCR_KNN_CAND_IDX, (size_t)nq * n_cand * sizeof(int));
-    uint32_t* flags = (uint32_t*)ism_scratch(ctx, SCR_KNN_FLAGS, (2 * (size_t)nq + 16) * sizeof(uint32_t));
+    // queue of unproven work: 16 counters | query records [nq*3] | items [nq*n_bound*2] | item results [nq*n_bound*4] u64
+    const size_t q_items = (size_t)nq * n_bound;
+    uint32_t* flags = (uint32_t*)ism_scratch(ctx, SCR_KNN_FLAGS, (16 + 3 * (size_t)nq + 2 * q_items) * sizeof(uint32_t) + 8 + q_items * 4 * sizeof(unsigned long long));
     if (!cand_val || !cand_idx || !flags) return ISMHIP_ERR_NOMEM;
     float* cand_bound = cand_val + (size_t)nq * n_cand;
-    uint32_t* flag_count = flags; uint32_t* flag_list = flags + 16;
-    ISM_HIP(ctx, hipMemsetAsync(flag_count, 0, 4, ctx->stream));
+    uint32_t* flag_count = flags; uint32_t* qrec = flags + 16; uint32_t* items = qrec + 3 * (size_t)nq;
+    unsigned long long* item_out = (unsigned long long*)(((uintptr_t)(items + 2 * q_items) + 7) & ~(uintptr_t)7);
+    ISM_HIP(ctx, hipMemsetAsync(flag_count, 0, 8, ctx->stream));
     // candidate kernel for squared L2: bf16x3 (default) or the exact-f32 MFMA contraction (ISMHIP_KNN_F32=1, kept for A/B runs)
     const bool use_bf16 = metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi != nullptr && !ctx->knn_force_f32;
     u16 *q_hi = nullptr, *q_lo = nullptr;
@@ -744,15 +775,19 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     vp.dot_rel = use_bf16 ? (3.1f * 3.814697265625e-06f + 1.01f * 3.f * (float)cb->dim_pad * 1.1920929e-07f) : vp.ku;
     vp.cmax2 = cb->max_norm2;
     hipLaunchKernelGGL(k_knn_rerank, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
-                       qq, nq, ldq, metric, cand_idx, n_cand, n_cand, cand_bound, n_bound, vp, k, idx_out, dist_out, flag_count, flag_list);
+                       qq, nq, ldq, metric, cand_idx, cand_val, n_cand, n_cand, cand_bound, n_bound, vp, k, idx_out, dist_out, flag_count, qrec, items);
     ISM_CHECK_LAUNCH(ctx, "k_knn_rerank");
     {
         TimerScope ts(ctx, "knn_fallback");
-        hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), (size_t)cb->dim_pad * sizeof(float), ctx->stream, cb->words, cb->dim, cb->dim_pad,
+        if (cb->dim_pad / 16 > KNN_FB_MAXJ) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: descriptor longer than 1344 not built");
+        hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad,
                            cb->n_words, qq, ldq, metric, k, tiles_per_split, cb->n_words_pad / (metric == ISMHIP_METRIC_L2SQ ? KNN_BM : CHI_B),
-                           flag_count, flag_list, idx_out, dist_out);
+                           flag_count, items, idx_out, dist_out, item_out);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback");
+        hipLaunchKernelGGL(k_knn_fallback_merge, dim3(64), dim3(256), 0, ctx->stream, k, flag_count, qrec, item_out, idx_out, dist_out);
+        ISM_CHECK_LAUNCH(ctx, "k_knn_fallback_merge");
     }
+    if (ctx->timers_on) ISM_HIP(ctx, hipMemcpyAsync(ctx->knn_stats, flag_count, 8, hipMemcpyDeviceToHost, ctx->stream));   // read back after a sync
     return ISMHIP_OK;
 }
 
@@ -778,7 +813,10 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
     if (k > 4) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: k > 4 not built");
     if (nq == 0) return ISMHIP_OK;
     TimerScope ts(ctx, "knn");
-    return k <= 2 ? run_knn<2>(ctx, cb, metric, nq, q, k, idx_out, dist_out) : run_knn<4>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
+    // T = candidates kept per slot. The bf16x3 candidate scores carry a larger error bound, so more are kept (T = 4): the proof
+    // then compares against the 5th best of every slot and almost never fails.
+    const bool wide = k > 2 || (metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi && !ctx->knn_force_f32);
+    return wide ? run_knn<4>(ctx, cb, metric, nq, q, k, idx_out, dist_out) : run_knn<2>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
 }
 
 int ismhip_knn_ratio(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q,
