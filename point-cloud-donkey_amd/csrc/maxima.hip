@@ -1,4 +1,5 @@
-// maxima.hip — continuous Hough space: mean-shift mode search + maxima post-processing, one workgroup per object.
+// maxima.hip — continuous Hough space: mean-shift mode search (one workgroup per (object, class)) + maxima post-processing
+// (one workgroup per object).
 // Reference seams: Voting::findMaxima (voting/voting.cpp:79-328, 436-462), VotingMeanShift::iFindMaxima and helpers
 // (voting/voting_mean_shift.cpp:33-37, 39-177, 201-481), MaximaHandler::averageNeighborMaxima / suppressNeighborMaxima
 // (voting/maxima_handler.cpp:51-157).
@@ -13,23 +14,28 @@
 namespace {
 
 #define MX_MAXC 256        // classes
-#define MX_MAXM 256        // maxima kept per object before sort/normalise
+#define MX_MAXM 1024       // maxima kept per object before sort/normalise
 #define MX_BIAS (1 << 20)
+#define MX_MAXM_C 128      // maxima kept per (object, class)
+#define MX_REC 12          // pos[3], weight, instance (bits), instance weight, bbox[3], n_votes (bits), 2 spare
 
 struct MaxArgs {
     const uint32_t* slot_off; const float* vpos; const float* vw; const int32_t* vcls; const int32_t* vinst; const float* vbs;
     int n_classes; const float* class_bw; float bandwidth, threshold; int max_iter, kernel, suppression, min_votes;
     float min_threshold; int best_k, max_maxima, cap;
     int32_t* n_max; float* mpos; float* mw; int32_t* mcls; int32_t* minst; float* miw; float* mbs; int32_t* mnv; float* class_score;
+    float* rec; int32_t* rec_count;      // per (object, class): up to MX_MAXM_C records of MX_REC floats
 };
 
 __device__ __forceinline__ float ms_kernel(int kernel, float u) {          // voting_mean_shift.cpp:378-417
-    if (kernel == ISMHIP_KERNEL_GAUSSIAN) return (float)exp(-0.5 * (double)u);
+    // the reference evaluates exp(-0.5 * x) in double and rounds to float; expf differs by <= 2 ulp (2e-7 relative), far inside
+    // the 1e-4 tolerance on vote weights, and is ~10x cheaper than the double-precision exp on the device
+    if (kernel == ISMHIP_KERNEL_GAUSSIAN) return expf(-0.5f * u);
     if (kernel == ISMHIP_KERNEL_UNIFORM) return 1.f;
     return 0.f;
 }
 __device__ __forceinline__ float ms_neg_kernel_derivative(int kernel, float u) {
-    if (kernel == ISMHIP_KERNEL_GAUSSIAN) { const float profile = (float)exp(-0.5 * (double)u); return -(-0.5f * profile); }
+    if (kernel == ISMHIP_KERNEL_GAUSSIAN) { const float profile = expf(-0.5f * u); return -(-0.5f * profile); }
     if (kernel == ISMHIP_KERNEL_UNIFORM) return -1.f;
     return 0.f;
 }
@@ -61,9 +67,6 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
     unsigned long long* keys = (unsigned long long*)(vslot + cap);
     float4* ctr = (float4*)(keys + cap);    float4* ctr2 = ctr + cap;
     unsigned char* member = (unsigned char*)(ctr2 + cap);
-    __shared__ int s_clscount[MX_MAXC];
-    __shared__ float s_mpos[MX_MAXM][3], s_mw[MX_MAXM], s_miw[MX_MAXM], s_mbs[MX_MAXM][3];
-    __shared__ int s_mcls[MX_MAXM], s_minst[MX_MAXM], s_mnv[MX_MAXM];
     __shared__ int s_nmax, s_n, s_ns, s_nc, s_np;
     __shared__ int s_wcnt[4];
     __shared__ float s_redf[4];
@@ -71,17 +74,14 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
     __shared__ float s_bv[4]; __shared__ int s_bi[4];
 
     const int o = blockIdx.x;
+    const int c = blockIdx.y;                                    // the reference visits the classes of m_votes one by one (voting.cpp:95)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t s0 = a.slot_off[o], s1 = a.slot_off[o + 1];
     const int C = a.n_classes;
-    for (int i = tid; i < C; i += 256) s_clscount[i] = 0;
-    if (tid == 0) s_nmax = 0;
+    float* rec = a.rec + ((size_t)o * C + c) * MX_MAXM_C * MX_REC;
+    if (tid == 0) { s_nmax = 0; a.rec_count[(size_t)o * C + c] = 0; }
     __syncthreads();
-    for (uint32_t s = s0 + tid; s < s1; s += 256) { const int c = a.vcls[s]; if (c >= 0 && c < C) atomicAdd(&s_clscount[c], 1); }
-    __syncthreads();
-
-    for (int c = 0; c < C; ++c) {
-        if (s_clscount[c] == 0) continue;                    // class absent from m_votes
+    {
         const float h = a.class_bw ? a.class_bw[c] : a.bandwidth;          // voting_mean_shift.cpp:48-49
         const float h2 = (float)((double)h * (double)h);
         const float hh = h * h;
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
             __syncthreads();
         }
         const int n = min(s_n, cap);
+        if (n == 0) return;                                       // class absent from m_votes (uniform across the block)
         // ---- seeds: unique cells of edge 2h/sqrt(2), key floor(x/edge + 0.5), (z,y,x) order (:431-481)
         const float bin = (h * 2.0f) / sqrtf(2.0f);
         int P = 1; while (P < n) P <<= 1;
@@ -284,11 +285,11 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
                 for (int k = 1; k < 4; ++k)
                     if (s_bv[k] > bestS || (s_bv[k] == bestS && bestS > 0.f && (unsigned)s_bi[k] < (unsigned)bestI)) { bestS = s_bv[k]; bestI = s_bi[k]; }
                 const int m = s_nmax;
-                if (m < MX_MAXM) {
-                    s_mpos[m][0] = p.x; s_mpos[m][1] = p.y; s_mpos[m][2] = p.z;
-                    s_mw[m] = sw; s_mcls[m] = c; s_mnv[m] = cnt;
-                    s_minst[m] = bestS > 0.f ? bestI : -1; s_miw[m] = bestS > 0.f ? bestS : 0.f;
-                    s_mbs[m][0] = b0 / sw; s_mbs[m][1] = b1 / sw; s_mbs[m][2] = b2 / sw;
+                if (m < MX_MAXM_C) {
+                    float* r = rec + (size_t)m * MX_REC;
+                    r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = sw;
+                    r[4] = __int_as_float(bestS > 0.f ? bestI : -1); r[5] = bestS > 0.f ? bestS : 0.f;
+                    r[6] = b0 / sw; r[7] = b1 / sw; r[8] = b2 / sw; r[9] = __int_as_float(cnt);
                     s_nmax = m + 1;
                 }
             }
@@ -296,42 +297,56 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
         }
         __syncthreads();
     }
-    // ---- sort (stable, descending weight), normalise, threshold, best-k (voting.cpp:272, 298-323, 441-462)
-    if (tid == 0) {
-        const int nm = s_nmax;
-        int* order = (int*)keys;
-        for (int i = 0; i < nm; ++i) order[i] = i;
-        for (int i = 1; i < nm; ++i) {
-            const int v = order[i]; int j = i - 1;
-            while (j >= 0 && s_mw[order[j]] < s_mw[v]) { order[j + 1] = order[j]; --j; }
-            order[j + 1] = v;
+    if (tid == 0) a.rec_count[(size_t)o * C + c] = s_nmax;
+}
+
+// Voting::findMaxima tail (voting.cpp:272, 298-323, 441-462): gather the maxima of all classes (class order, then the order
+// in which iFindMaxima produced them), stable sort by weight, normalise, MinThreshold, BestK, class scores.
+__global__ __launch_bounds__(64) void k_finalize_maxima(MaxArgs a) {
+    __shared__ float s_w[MX_MAXM], s_iw[MX_MAXM];
+    __shared__ int s_src[MX_MAXM], s_cls[MX_MAXM], s_order[MX_MAXM];
+    const int o = blockIdx.x;
+    const int C = a.n_classes;
+    if (threadIdx.x != 0) return;
+    int nm = 0;
+    for (int c = 0; c < C; ++c) {
+        const int cnt = a.rec_count[(size_t)o * C + c];
+        for (int m = 0; m < cnt && nm < MX_MAXM; ++m) {
+            const float* r = a.rec + (((size_t)o * C + c) * MX_MAXM_C + m) * MX_REC;
+            s_w[nm] = r[3]; s_iw[nm] = r[5]; s_src[nm] = c * MX_MAXM_C + m; s_cls[nm] = c; s_order[nm] = nm; ++nm;
         }
-        float sum = 0.f, sum_inst = 0.f;
-        for (int i = 0; i < nm; ++i) { sum += s_mw[order[i]]; sum_inst += s_miw[order[i]]; }
-        for (int i = 0; i < nm; ++i) {
-            s_mw[i] = sum != 0.f ? s_mw[i] / sum : 0.f;
-            s_miw[i] = sum_inst != 0.f ? s_miw[i] / sum_inst : 0.f;
-        }
-        float thr = a.min_threshold;
-        if (thr < 0.f) { const float mxw = nm > 0 ? s_mw[order[0]] : 0.0f; thr = -thr * mxw; }
-        int kept = 0;
-        for (int i = 0; i < nm; ++i) if (s_mw[order[i]] >= thr) order[kept++] = order[i];
-        if (a.best_k > 0 && kept >= a.best_k) kept = a.best_k;
-        for (int cc = 0; cc < C; ++cc) a.class_score[(size_t)o * C + cc] = 0.f;
-        for (int i = 0; i < kept; ++i) {
-            float* cs = &a.class_score[(size_t)o * C + s_mcls[order[i]]];
-            if (s_mw[order[i]] > *cs) *cs = s_mw[order[i]];
-        }
-        const int nout = min(kept, a.max_maxima);
-        a.n_max[o] = nout;
-        for (int i = 0; i < a.max_maxima; ++i) {
-            const size_t t = (size_t)o * a.max_maxima + i;
-            const bool ok = i < nout; const int m = ok ? order[i] : 0;
-            a.mpos[t * 3] = ok ? s_mpos[m][0] : 0.f; a.mpos[t * 3 + 1] = ok ? s_mpos[m][1] : 0.f; a.mpos[t * 3 + 2] = ok ? s_mpos[m][2] : 0.f;
-            a.mw[t] = ok ? s_mw[m] : 0.f; a.mcls[t] = ok ? s_mcls[m] : -1; a.minst[t] = ok ? s_minst[m] : -1;
-            a.miw[t] = ok ? s_miw[m] : 0.f; a.mnv[t] = ok ? s_mnv[m] : 0;
-            if (a.mbs) { a.mbs[t * 3] = ok ? s_mbs[m][0] : 0.f; a.mbs[t * 3 + 1] = ok ? s_mbs[m][1] : 0.f; a.mbs[t * 3 + 2] = ok ? s_mbs[m][2] : 0.f; }
-        }
+    }
+    for (int i = 1; i < nm; ++i) {
+        const int v = s_order[i]; int j = i - 1;
+        while (j >= 0 && s_w[s_order[j]] < s_w[v]) { s_order[j + 1] = s_order[j]; --j; }
+        s_order[j + 1] = v;
+    }
+    float sum = 0.f, sum_inst = 0.f;
+    for (int i = 0; i < nm; ++i) { sum += s_w[s_order[i]]; sum_inst += s_iw[s_order[i]]; }
+    for (int i = 0; i < nm; ++i) {
+        s_w[i] = sum != 0.f ? s_w[i] / sum : 0.f;
+        s_iw[i] = sum_inst != 0.f ? s_iw[i] / sum_inst : 0.f;
+    }
+    float thr = a.min_threshold;
+    if (thr < 0.f) { const float mxw = nm > 0 ? s_w[s_order[0]] : 0.0f; thr = -thr * mxw; }
+    int kept = 0;
+    for (int i = 0; i < nm; ++i) if (s_w[s_order[i]] >= thr) s_order[kept++] = s_order[i];
+    if (a.best_k > 0 && kept >= a.best_k) kept = a.best_k;
+    for (int cc = 0; cc < C; ++cc) a.class_score[(size_t)o * C + cc] = 0.f;
+    for (int i = 0; i < kept; ++i) {
+        float* cs = &a.class_score[(size_t)o * C + s_cls[s_order[i]]];
+        if (s_w[s_order[i]] > *cs) *cs = s_w[s_order[i]];
+    }
+    const int nout = min(kept, a.max_maxima);
+    a.n_max[o] = nout;
+    for (int i = 0; i < a.max_maxima; ++i) {
+        const size_t t = (size_t)o * a.max_maxima + i;
+        const bool ok = i < nout; const int m = ok ? s_order[i] : 0;
+        const float* r = a.rec + ((size_t)o * C * MX_MAXM_C + (ok ? s_src[m] : 0)) * MX_REC;
+        a.mpos[t * 3] = ok ? r[0] : 0.f; a.mpos[t * 3 + 1] = ok ? r[1] : 0.f; a.mpos[t * 3 + 2] = ok ? r[2] : 0.f;
+        a.mw[t] = ok ? s_w[m] : 0.f; a.mcls[t] = ok ? s_cls[m] : -1; a.minst[t] = ok ? __float_as_int(r[4]) : -1;
+        a.miw[t] = ok ? s_iw[m] : 0.f; a.mnv[t] = ok ? __float_as_int(r[9]) : 0;
+        if (a.mbs) { a.mbs[t * 3] = ok ? r[6] : 0.f; a.mbs[t * 3 + 1] = ok ? r[7] : 0.f; a.mbs[t * 3 + 2] = ok ? r[8] : 0.f; }
     }
 }
 
@@ -380,8 +395,14 @@ extern "C" int ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* sl
         ISM_HIP(ctx, hipFuncSetAttribute((const void*)k_find_maxima, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
         attr_set = true;
     }
+    const size_t n_oc = (size_t)n_obj * P->n_classes;
+    a.rec = (float*)ism_scratch(ctx, SCR_MAX_REC, n_oc * MX_MAXM_C * MX_REC * sizeof(float) + n_oc * sizeof(int32_t));
+    if (!a.rec) return ISMHIP_ERR_NOMEM;
+    a.rec_count = (int32_t*)(a.rec + n_oc * MX_MAXM_C * MX_REC);
     TimerScope ts(ctx, "maxima");
-    hipLaunchKernelGGL(k_find_maxima, dim3(n_obj), dim3(256), dyn, ctx->stream, a);
+    hipLaunchKernelGGL(k_find_maxima, dim3(n_obj, P->n_classes), dim3(256), dyn, ctx->stream, a);
     ISM_CHECK_LAUNCH(ctx, "k_find_maxima");
+    hipLaunchKernelGGL(k_finalize_maxima, dim3(n_obj), dim3(64), 0, ctx->stream, a);
+    ISM_CHECK_LAUNCH(ctx, "k_finalize_maxima");
     return ISMHIP_OK;
 }
