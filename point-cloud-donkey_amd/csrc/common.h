@@ -136,20 +136,47 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
     return r;
 }
 
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+// Wave-wide sums on the DPP data path. hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS-crossbar round trip of ~100+
+// cycles per step, 6 dependent steps per sum); the DPP sequence below is 6 register-to-register moves + 1 v_readlane.
+// All 64 lanes must be active at the call site (they are: every use is wave-uniform). Steps: quad_perm [1,0,3,2], quad_perm
+// [2,3,0,1], row_shr:4, row_shr:8, row_bcast:15, row_bcast:31 -> the total lands in lane 63 (lanes without a source add 0).
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __int_as_float(dpp_mov0<0xb1>(__float_as_int(v)));
+    v += __int_as_float(dpp_mov0<0x4e>(__float_as_int(v)));
+    v += __int_as_float(dpp_mov0<0x114>(__float_as_int(v)));
+    v += __int_as_float(dpp_mov0<0x118>(__float_as_int(v)));
+    v += __int_as_float(dpp_mov0<0x142>(__float_as_int(v)));
+    v += __int_as_float(dpp_mov0<0x143>(__float_as_int(v)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov0<0xb1>(v);
+    v += dpp_mov0<0x4e>(v);
+    v += dpp_mov0<0x114>(v);
+    v += dpp_mov0<0x118>(v);
+    v += dpp_mov0<0x142>(v);
+    v += dpp_mov0<0x143>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov0_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_mov0<CTRL>((int)(b & 0xffffffffll)), hi = dpp_mov0<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_mov0_d<0xb1>(v);
+    v += dpp_mov0_d<0x4e>(v);
+    v += dpp_mov0_d<0x114>(v);
+    v += dpp_mov0_d<0x118>(v);
+    v += dpp_mov0_d<0x142>(v);
+    v += dpp_mov0_d<0x143>(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 // cell coordinate of a value along one axis, clamped (monotone in v)

@@ -73,7 +73,13 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
     const int lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 1, wc = wv & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int qtile = blockIdx.x, split = blockIdx.y;
+    // XCD-aware block -> (query tile, codebook split) map. Blocks are dealt round-robin over the 8 XCDs, each with a private
+    // 4 MiB L2: block id = 8*j + x runs on XCD group x and takes query tile 8*(j / n_splits) + x, split j % n_splits, so the
+    // blocks co-resident on one XCD cover few query tiles (their hi/lo images stay in that L2 while every split's codeword
+    // slices stream through it) instead of 32 different ones that thrash it. Placement only affects speed, never results.
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = jx % n_splits, qtile = (jx / n_splits) * 8 + xcd;
+    if (qtile * KNN_BN >= nq) return;
     const int mt0 = split * tiles_per_split;
     const int mt1 = min(n_tiles_m, mt0 + tiles_per_split);
     const int nk = dim_pad / KNN_BK;
@@ -226,7 +232,7 @@ template <int T>
 __global__ __launch_bounds__(256, 2) void k_knn_l2_bf16x3(const u16* __restrict__ wh, const u16* __restrict__ wl,
                                                           const float* __restrict__ word_norm, int n_tiles_m, int dim_pad,
                                                           const u16* __restrict__ qh, const u16* __restrict__ ql, int nq,
-                                                          int tiles_per_split,
+                                                          int tiles_per_split, int n_splits,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
                                                           float* __restrict__ cand_bound, int bound_stride) {
     __shared__ __attribute__((aligned(16))) u16 sAh[2][KNN_BM * KB_ROW];
@@ -239,7 +245,13 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_bf16x3(const u16* __restrict_
     const int lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 1, wc = wv & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int qtile = blockIdx.x, split = blockIdx.y;
+    // XCD-aware block -> (query tile, codebook split) map. Blocks are dealt round-robin over the 8 XCDs, each with a private
+    // 4 MiB L2: block id = 8*j + x runs on XCD group x and takes query tile 8*(j / n_splits) + x, split j % n_splits, so the
+    // blocks co-resident on one XCD cover few query tiles (their hi/lo images stay in that L2 while every split's codeword
+    // slices stream through it) instead of 32 different ones that thrash it. Placement only affects speed, never results.
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = jx % n_splits, qtile = (jx / n_splits) * 8 + xcd;
+    if (qtile * KNN_BN >= nq) return;
     const int mt0 = split * tiles_per_split;
     const int mt1 = min(n_tiles_m, mt0 + tiles_per_split);
     const int nk = dim_pad / KNN_BK;
@@ -754,12 +766,12 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         TimerScope ts(ctx, metric == ISMHIP_METRIC_L2SQ ? "knn_l2_mfma" : "knn_chi2");
         if (metric == ISMHIP_METRIC_L2SQ && use_bf16) {
             const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
-            hipLaunchKernelGGL(k_knn_l2_bf16x3<T>, dim3(n_qt, n_splits), dim3(256), 0, ctx->stream, cb->words_bf16_hi, cb->words_bf16_lo, cb->word_norm,
-                               cb->n_words_pad / KNN_BM, cb->dim_pad, q_hi, q_lo, nq, tiles_per_split, cand_val, cand_idx, n_cand, cand_bound, n_bound);
+            hipLaunchKernelGGL(k_knn_l2_bf16x3<T>, dim3(8 * ((n_qt + 7) / 8) * n_splits), dim3(256), 0, ctx->stream, cb->words_bf16_hi, cb->words_bf16_lo, cb->word_norm,
+                               cb->n_words_pad / KNN_BM, cb->dim_pad, q_hi, q_lo, nq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand, cand_bound, n_bound);
             ISM_CHECK_LAUNCH(ctx, "k_knn_l2_bf16x3");
         } else if (metric == ISMHIP_METRIC_L2SQ) {
             const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
-            hipLaunchKernelGGL(k_knn_l2_mfma<T>, dim3(n_qt, n_splits), dim3(256), 0, ctx->stream, cb->words, cb->word_norm,
+            hipLaunchKernelGGL(k_knn_l2_mfma<T>, dim3(8 * ((n_qt + 7) / 8) * n_splits), dim3(256), 0, ctx->stream, cb->words, cb->word_norm,
                                cb->n_words_pad / KNN_BM, cb->dim_pad, qq, nq, ldq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand,
                                cand_bound, n_bound);
             ISM_CHECK_LAUNCH(ctx, "k_knn_l2_mfma");

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
     __shared__ int s_wcnt[4];
     __shared__ float s_redf[4];
     __shared__ int s_redi[4];
-    __shared__ float s_bv[4]; __shared__ int s_bi[4];
+    __shared__ int s_bi[4];
 
     const int o = blockIdx.x;
     const int c = blockIdx.y;                                    // the reference visits the classes of m_votes one by one (voting.cpp:95)
@@ -265,25 +265,48 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
             sw = block_sum_f(sw, s_redf);
             b0 = block_sum_f(b0, s_redf); b1 = block_sum_f(b1, s_redf); b2 = block_sum_f(b2, s_redf);
             __syncthreads();
-            // instance id with the largest summed weight; ties -> smallest id; weights <= 0 never win (voting.cpp:139-165)
-            float bestS = 0.f; int bestI = 0x7fffffff;
+            // instance id with the largest summed weight; ties -> smallest id; weights <= 0 never win (voting.cpp:139-165).
+            // Per-instance sums in an LDS hash table (open addressing, keys = instance ids, values = 2^-32 fixed point updated with
+            // ds_add_u64: O(n), order independent) instead of the O(n^2) pairwise tally.
+            int* hkey = (int*)ctr;                                   // ctr / keys are free once the final positions sit in ctr2
+            unsigned long long* hval = keys;
+            const int HEMPTY = (int)0x80000000;
+            for (int i = tid; i < cap; i += 256) { hkey[i] = HEMPTY; hval[i] = 0ull; }
+            __syncthreads();
             for (int i = tid; i < n; i += 256) {
                 if (!member[i]) continue;
                 const int id = vinst[i];
-                float S = 0.f;
-                for (int j = 0; j < n; ++j) if (member[j] && vinst[j] == id) S += vw[j];
-                if (S > bestS || (S == bestS && S > 0.f && (unsigned)id < (unsigned)bestI)) { bestS = S; bestI = id; }
+                const float wv_ = vw[i];
+                const unsigned long long fx = wv_ > 0.f ? (unsigned long long)((double)wv_ * 4294967296.0) : 0ull;
+                unsigned slot = ((unsigned)id * 2654435761u) & (unsigned)(cap - 1);
+                for (int probe = 0; probe < cap; ++probe) {
+                    const int old = atomicCAS(&hkey[slot], HEMPTY, id);
+                    if (old == HEMPTY || old == id) { atomicAdd(&hval[slot], fx); break; }
+                    slot = (slot + 1) & (unsigned)(cap - 1);
+                }
+            }
+            __syncthreads();
+            unsigned long long bS = 0ull; int bI = 0x7fffffff;
+            for (int i = tid; i < cap; i += 256) {
+                const int id = hkey[i];
+                if (id == HEMPTY) continue;
+                const unsigned long long S = hval[i];
+                if (S > bS || (S == bS && S > 0ull && (unsigned)id < (unsigned)bI)) { bS = S; bI = id; }
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
-                const float oS = __shfl_xor(bestS, off, 64); const int oI = __shfl_xor(bestI, off, 64);
-                if (oS > bestS || (oS == bestS && oS > 0.f && (unsigned)oI < (unsigned)bestI)) { bestS = oS; bestI = oI; }
+                const unsigned long long oS = __shfl_xor(bS, off, 64); const int oI = __shfl_xor(bI, off, 64);
+                if (oS > bS || (oS == bS && oS > 0ull && (unsigned)oI < (unsigned)bI)) { bS = oS; bI = oI; }
             }
-            if (lane == 0) { s_bv[wv] = bestS; s_bi[wv] = bestI; }
+            float bestS = (float)((double)bS * 2.3283064365386963e-10); int bestI = bI;
+            __shared__ unsigned long long s_bS[4];
+            if (lane == 0) { s_bS[wv] = bS; s_bi[wv] = bI; }
             __syncthreads();
             if (tid == 0) {
+                unsigned long long fS = s_bS[0]; bestI = s_bi[0];
                 for (int k = 1; k < 4; ++k)
-                    if (s_bv[k] > bestS || (s_bv[k] == bestS && bestS > 0.f && (unsigned)s_bi[k] < (unsigned)bestI)) { bestS = s_bv[k]; bestI = s_bi[k]; }
+                    if (s_bS[k] > fS || (s_bS[k] == fS && fS > 0ull && (unsigned)s_bi[k] < (unsigned)bestI)) { fS = s_bS[k]; bestI = s_bi[k]; }
+                bestS = (float)((double)fS * 2.3283064365386963e-10);
                 const int m = s_nmax;
                 if (m < MX_MAXM_C) {
                     float* r = rec + (size_t)m * MX_REC;
