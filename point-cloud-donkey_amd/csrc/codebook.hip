@@ -4,7 +4,7 @@
 // Codebook::castVotes), utils/utils.cpp:136-178, 342-394, 560-574 (LRF -> quaternion, rotateBack), voting/voting.cpp:58-77.
 //
 // HBM layout: words [n_words_pad x dim_pad] zero-padded so the kNN tiles never branch on bounds (n_words_pad multiple
-// of 128, dim_pad multiple of 32); votes as CSR over words with SoA payloads. Vote casting is HBM-bound
+// of 256, dim_pad multiple of 32); votes as CSR over words with SoA payloads. Vote casting is HBM-bound
 // (V*(12+4+4+4) read + V*32 written) and tiny next to kNN.
 #include "common.h"
 #include <cmath>
@@ -153,7 +153,7 @@ int ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* w
     ismhip_codebook* cb = new ismhip_codebook();
     cb->n_words = n_words; cb->dim = dim; cb->n_classes = n_classes;
     cb->dim_pad = (dim + 31) / 32 * 32;
-    cb->n_words_pad = (n_words + 127) / 128 * 128;
+    cb->n_words_pad = (n_words + 255) / 256 * 256;      // multiple of every kNN tile height (64, 128, 256)
     cb->n_votes = (int)vote_offsets_h[n_words]; cb->max_votes = maxv;
     auto fail = [&](int code, const char* msg) { ismhip_codebook_destroy(ctx, cb); return ism_set_err(ctx, code, msg); };
     const size_t wbytes = (size_t)cb->n_words_pad * cb->dim_pad * sizeof(float);

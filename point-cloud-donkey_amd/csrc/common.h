@@ -89,6 +89,7 @@ struct ismhip_ctx {
     // destroyed clouds keep their device allocations here for the next ismhip_cloud_create (no hipMalloc/hipFree per batch)
     std::vector<ismhip_cloud*> cloud_pool;
     uint32_t knn_stats[2] = {0, 0};   // last ismhip_knn: {queries, (query,slot) items} sent to the exact fallback (valid with timers on, after a sync)
+    bool knn_small_tile = false; // env ISMHIP_KNN_TILE128=1: keep the bf16x3 kernel on its 128x128 tile (A/B runs)
     bool knn_force_f32 = false;  // env ISMHIP_KNN_F32=1: squared-L2 candidates by the exact-f32 MFMA kernel instead of bf16x3
 };
 

@@ -62,6 +62,7 @@ static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out)
     ismhip_ctx* ctx = new ismhip_ctx();
     ctx->device = device;
     { const char* e = getenv("ISMHIP_KNN_F32"); ctx->knn_force_f32 = e && e[0] == '1'; }
+    { const char* e = getenv("ISMHIP_KNN_TILE128"); ctx->knn_small_tile = e && e[0] == '1'; }
     if (!own) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ISMHIP_ERR_HIP; }

@@ -166,15 +166,22 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
         }
         // epilogue: C/D layout of the 32x32 tile: col = lane&31 (query), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (codeword)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi) {
+            float cn[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row_l = wr * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float cn = sCn[row_l];
-                const int idx = mt * KNN_BM + row_l;
+            for (int e = 0; e < 16; ++e) cn[e] = sCn[wr * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) top[ni].push(cn - 2.0f * acc[mi][ni][e], idx);
+            for (int ni = 0; ni < 2; ++ni) {
+                const float tau = top[ni].v[T];
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc[mi][ni][e] = cn[e] - 2.0f * acc[mi][ni][e]; any |= acc[mi][ni][e] < tau; }
+                if (__any(any)) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) top[ni].push(acc[mi][ni][e], mt * KNN_BM + wr * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h);
+                }
             }
+        }
     }
     // candidates: slot = split*(4T) + (wr*2 + h)*T + t
 #pragma unroll
@@ -228,135 +235,154 @@ __global__ void k_split_bf16(const float* __restrict__ src, int n, int dim, int 
     hi[i] = h; lo[i] = f32_to_bf16_rn(x - hf);
 }
 
-template <int T>
-__global__ __launch_bounds__(256, 2) void k_knn_l2_bf16x3(const u16* __restrict__ wh, const u16* __restrict__ wl,
+// Tile geometry is a template: WR x WC waves, each MI x NI MFMA tiles of 32x32 -> BM = WR*MI*32 codeword rows by
+// BN = WC*NI*32 queries per workgroup. The CU's load path delivers ~30 B/clk from L2 (MI355X_MICROARCH 'Indexed rows'), a
+// 128x128 tile needs 32 KB per 32-k slice for 768 MFMA cycles per wave and is load-bound; the 256x256 tile (8 waves, 64 KB per
+// slice for 1536 MFMA cycles per wave, 128 KB of LDS, one workgroup per CU) is MFMA-bound.
+template <int T, int WR, int WC, int MI, int NI>
+__global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_bf16x3(const u16* __restrict__ wh, const u16* __restrict__ wl,
                                                           const float* __restrict__ word_norm, int n_tiles_m, int dim_pad,
                                                           const u16* __restrict__ qh, const u16* __restrict__ ql, int nq,
                                                           int tiles_per_split, int n_splits,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
                                                           float* __restrict__ cand_bound, int bound_stride) {
-    __shared__ __attribute__((aligned(16))) u16 sAh[2][KNN_BM * KB_ROW];
-    __shared__ __attribute__((aligned(16))) u16 sAl[2][KNN_BM * KB_ROW];
-    __shared__ __attribute__((aligned(16))) u16 sBh[2][KNN_BN * KB_ROW];
-    __shared__ __attribute__((aligned(16))) u16 sBl[2][KNN_BN * KB_ROW];
-    __shared__ float sCn[KNN_BM];
+    constexpr int BM = WR * MI * 32, BN = WC * NI * 32, NT = WR * WC * 64;
+    constexpr int RPP = NT / 4;                       // rows staged per pass (4 threads x 16 B per 64-B row)
+    constexpr int PA = BM / RPP, PB = BN / RPP;       // passes per array
+    extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
+    u16* sAh = (u16*)knn_smem;                        // [2][BM*32]
+    u16* sAl = sAh + 2 * BM * KB_ROW;
+    u16* sBh = sAl + 2 * BM * KB_ROW;                 // [2][BN*32]
+    u16* sBl = sBh + 2 * BN * KB_ROW;
+    float* sCn = (float*)(sBl + 2 * BN * KB_ROW);     // [BM]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int wr = wv >> 1, wc = wv & 1;
+    const int wr = wv / WC, wc = wv % WC;
     const int r = lane & 31, h = lane >> 5;
-    // XCD-aware block -> (query tile, codebook split) map. Blocks are dealt round-robin over the 8 XCDs, each with a private
-    // 4 MiB L2: block id = 8*j + x runs on XCD group x and takes query tile 8*(j / n_splits) + x, split j % n_splits, so the
-    // blocks co-resident on one XCD cover few query tiles (their hi/lo images stay in that L2 while every split's codeword
-    // slices stream through it) instead of 32 different ones that thrash it. Placement only affects speed, never results.
+    // XCD-aware block -> (query tile, codebook split) map, see k_knn_l2_mfma
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int split = jx % n_splits, qtile = (jx / n_splits) * 8 + xcd;
-    if (qtile * KNN_BN >= nq) return;
+    if (qtile * BN >= nq) return;
     const int mt0 = split * tiles_per_split;
     const int mt1 = min(n_tiles_m, mt0 + tiles_per_split);
     const int nk = dim_pad / KNN_BK;
 
-    // staging map: 128 rows x 4 segments of 16 B per array; thread -> rows tid/4 and tid/4 + 64, segment tid%4
     const int srow = tid >> 2, sseg = tid & 3;
-    const int sdst0 = srow * KB_ROW + ((sseg ^ ((srow >> 2) & 3)) << 3);
-    const int sdst1 = (srow + 64) * KB_ROW + ((sseg ^ (((srow + 64) >> 2) & 3)) << 3);
-    const size_t qoff0 = (size_t)(qtile * KNN_BN + srow) * dim_pad + sseg * 8;
-    const size_t qoff1 = qoff0 + (size_t)64 * dim_pad;
-
-    // fragment read offsets (halves) inside a stage: row * 32 + swizzled segment * 8; segment = kstep*2 + h
-    int offA[2][2], offB[2][2];
+    int sdst[(PA > PB ? PA : PB)];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ra = wr * 64 + m * 32 + r, rb = wc * 64 + m * 32 + r, seg = ks * 2 + h;
-            offA[m][ks] = ra * KB_ROW + ((seg ^ ((ra >> 2) & 3)) << 3);
-            offB[m][ks] = rb * KB_ROW + ((seg ^ ((rb >> 2) & 3)) << 3);
-        }
+    for (int p = 0; p < (PA > PB ? PA : PB); ++p) {
+        const int row = srow + p * RPP;
+        sdst[p] = row * KB_ROW + ((sseg ^ ((row >> 2) & 3)) << 3);
+    }
+    const size_t qoff = (size_t)(qtile * BN + srow) * dim_pad + sseg * 8;
 
-    TopT<T + 1> top[2];
-    top[0].init(); top[1].init();
+    int offA[MI][2], offB[NI][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int seg = ks * 2 + h;
+#pragma unroll
+        for (int m = 0; m < MI; ++m) { const int ra = wr * (MI * 32) + m * 32 + r; offA[m][ks] = ra * KB_ROW + ((seg ^ ((ra >> 2) & 3)) << 3); }
+#pragma unroll
+        for (int n = 0; n < NI; ++n) { const int rb = wc * (NI * 32) + n * 32 + r; offB[n][ks] = rb * KB_ROW + ((seg ^ ((rb >> 2) & 3)) << 3); }
+    }
+
+    TopT<T + 1> top[NI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n) top[n].init();
 
     for (int mt = mt0; mt < mt1; ++mt) {
-        const size_t aoff0 = (size_t)(mt * KNN_BM + srow) * dim_pad + sseg * 8;
-        const size_t aoff1 = aoff0 + (size_t)64 * dim_pad;
-        f32x16 acc[2][2];
+        const size_t aoff = (size_t)(mt * BM + srow) * dim_pad + sseg * 8;
+        f32x16 acc[MI][NI];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-        f32x4 g[8];
-        g[0] = *(const f32x4*)(wh + aoff0); g[1] = *(const f32x4*)(wh + aoff1);
-        g[2] = *(const f32x4*)(wl + aoff0); g[3] = *(const f32x4*)(wl + aoff1);
-        g[4] = *(const f32x4*)(qh + qoff0); g[5] = *(const f32x4*)(qh + qoff1);
-        g[6] = *(const f32x4*)(ql + qoff0); g[7] = *(const f32x4*)(ql + qoff1);
+        f32x4 gah[PA], gal[PA], gbh[PB], gbl[PB];
+#pragma unroll
+        for (int p = 0; p < PA; ++p) { gah[p] = *(const f32x4*)(wh + aoff + (size_t)p * RPP * dim_pad); gal[p] = *(const f32x4*)(wl + aoff + (size_t)p * RPP * dim_pad); }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) { gbh[p] = *(const f32x4*)(qh + qoff + (size_t)p * RPP * dim_pad); gbl[p] = *(const f32x4*)(ql + qoff + (size_t)p * RPP * dim_pad); }
         __syncthreads();                                   // previous tile's epilogue has finished reading sCn / LDS
-        if (tid < KNN_BM) sCn[tid] = word_norm[mt * KNN_BM + tid];
-        *(f32x4*)(&sAh[0][sdst0]) = g[0]; *(f32x4*)(&sAh[0][sdst1]) = g[1];
-        *(f32x4*)(&sAl[0][sdst0]) = g[2]; *(f32x4*)(&sAl[0][sdst1]) = g[3];
-        *(f32x4*)(&sBh[0][sdst0]) = g[4]; *(f32x4*)(&sBh[0][sdst1]) = g[5];
-        *(f32x4*)(&sBl[0][sdst0]) = g[6]; *(f32x4*)(&sBl[0][sdst1]) = g[7];
+        for (int i = tid; i < BM; i += NT) sCn[i] = word_norm[mt * BM + i];
+#pragma unroll
+        for (int p = 0; p < PA; ++p) { *(f32x4*)(&sAh[sdst[p]]) = gah[p]; *(f32x4*)(&sAl[sdst[p]]) = gal[p]; }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) { *(f32x4*)(&sBh[sdst[p]]) = gbh[p]; *(f32x4*)(&sBl[sdst[p]]) = gbl[p]; }
         __syncthreads();
 
         for (int kc = 0; kc < nk; ++kc) {
             const int cur = kc & 1;
             if (kc + 1 < nk) {
                 const int ko = (kc + 1) * KNN_BK;
-                g[0] = *(const f32x4*)(wh + aoff0 + ko); g[1] = *(const f32x4*)(wh + aoff1 + ko);
-                g[2] = *(const f32x4*)(wl + aoff0 + ko); g[3] = *(const f32x4*)(wl + aoff1 + ko);
-                g[4] = *(const f32x4*)(qh + qoff0 + ko); g[5] = *(const f32x4*)(qh + qoff1 + ko);
-                g[6] = *(const f32x4*)(ql + qoff0 + ko); g[7] = *(const f32x4*)(ql + qoff1 + ko);
+#pragma unroll
+                for (int p = 0; p < PA; ++p) { gah[p] = *(const f32x4*)(wh + aoff + (size_t)p * RPP * dim_pad + ko); gal[p] = *(const f32x4*)(wl + aoff + (size_t)p * RPP * dim_pad + ko); }
+#pragma unroll
+                for (int p = 0; p < PB; ++p) { gbh[p] = *(const f32x4*)(qh + qoff + (size_t)p * RPP * dim_pad + ko); gbl[p] = *(const f32x4*)(ql + qoff + (size_t)p * RPP * dim_pad + ko); }
             }
+            const u16* cAh = sAh + cur * BM * KB_ROW; const u16* cAl = sAl + cur * BM * KB_ROW;
+            const u16* cBh = sBh + cur * BN * KB_ROW; const u16* cBl = sBl + cur * BN * KB_ROW;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 ah[2], al[2], bh[2], bl[2];
+                bf16x8 bh[NI], bl[NI];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    ah[m] = *(const bf16x8*)(&sAh[cur][offA[m][ks]]); al[m] = *(const bf16x8*)(&sAl[cur][offA[m][ks]]);
-                    bh[m] = *(const bf16x8*)(&sBh[cur][offB[m][ks]]); bl[m] = *(const bf16x8*)(&sBl[cur][offB[m][ks]]);
-                }
+                for (int n = 0; n < NI; ++n) { bh[n] = *(const bf16x8*)(cBh + offB[n][ks]); bl[n] = *(const bf16x8*)(cBl + offB[n][ks]); }
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi) {
+                    const bf16x8 ah = *(const bf16x8*)(cAh + offA[mi][ks]);
+                    const bf16x8 al = *(const bf16x8*)(cAl + offA[mi][ks]);
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NI; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
                     }
+                }
             }
             if (kc + 1 < nk) {
                 const int nx = cur ^ 1;
-                *(f32x4*)(&sAh[nx][sdst0]) = g[0]; *(f32x4*)(&sAh[nx][sdst1]) = g[1];
-                *(f32x4*)(&sAl[nx][sdst0]) = g[2]; *(f32x4*)(&sAl[nx][sdst1]) = g[3];
-                *(f32x4*)(&sBh[nx][sdst0]) = g[4]; *(f32x4*)(&sBh[nx][sdst1]) = g[5];
-                *(f32x4*)(&sBl[nx][sdst0]) = g[6]; *(f32x4*)(&sBl[nx][sdst1]) = g[7];
+#pragma unroll
+                for (int p = 0; p < PA; ++p) { *(f32x4*)(&sAh[nx * BM * KB_ROW + sdst[p]]) = gah[p]; *(f32x4*)(&sAl[nx * BM * KB_ROW + sdst[p]]) = gal[p]; }
+#pragma unroll
+                for (int p = 0; p < PB; ++p) { *(f32x4*)(&sBh[nx * BN * KB_ROW + sdst[p]]) = gbh[p]; *(f32x4*)(&sBl[nx * BN * KB_ROW + sdst[p]]) = gbl[p]; }
             }
             __syncthreads();
         }
+        // epilogue: score = |c|^2 - 2 c.q. After the first tiles almost no score beats a lane's current T-th best, so the scores
+        // are first only compared (2 VALU per value); the insertion code runs for an accumulator tile only if some lane needs it.
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi) {
+            float cn[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row_l = wr * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float cn = sCn[row_l];
-                const int idx = mt * KNN_BM + row_l;
+            for (int e = 0; e < 16; ++e) cn[e] = sCn[wr * (MI * 32) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) top[ni].push(cn - 2.0f * acc[mi][ni][e], idx);
+            for (int ni = 0; ni < NI; ++ni) {
+                const float tau = top[ni].v[T];
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc[mi][ni][e] = cn[e] - 2.0f * acc[mi][ni][e]; any |= acc[mi][ni][e] < tau; }
+                if (__any(any)) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        top[ni].push(acc[mi][ni][e], mt * BM + wr * (MI * 32) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h);
+                }
             }
+        }
     }
+    // candidates: slot = split*(2*WR*T) + (wr*2 + h)*T + t; bound slot = split*(2*WR) + wr*2 + h
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int qi = qtile * KNN_BN + wc * 64 + ni * 32 + r;
+    for (int ni = 0; ni < NI; ++ni) {
+        const int qi = qtile * BN + wc * (NI * 32) + ni * 32 + r;
         if (qi < nq) {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                const size_t o = (size_t)qi * cand_stride + split * (4 * T) + (wr * 2 + h) * T + t;
+                const size_t o = (size_t)qi * cand_stride + split * (2 * WR * T) + (wr * 2 + h) * T + t;
                 cand_val[o] = top[ni].v[t]; cand_idx[o] = top[ni].i[t];
             }
-            cand_bound[(size_t)qi * bound_stride + split * 4 + (wr * 2 + h)] = top[ni].v[T];
+            cand_bound[(size_t)qi * bound_stride + split * (2 * WR) + (wr * 2 + h)] = top[ni].v[T];
         }
     }
 }
@@ -590,11 +616,12 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
 // per step (16 lanes each, 64-byte coalesced segments) with the query held in registers; direct (a-b)^2 [/(a+b)] sums pick
 // the rows that can still matter, the FLANN functor order ranks them. Each item leaves its k best (distance,row) keys in
 // item_out; k_knn_fallback_merge folds them into the query's result.
-// Slot -> rows: L2 bit b = split*4 + wr*2 + h owns, in every 128-row tile of its split, the 32 rows wr*64 + x with bit 2 of x
-// equal to h (the C/D layout of the 32x32 MFMA tile, see k_knn_l2_mfma); chi2 bit b = split owns all rows of its split.
+// Slot -> rows: L2 bit b = split*4 + wr*2 + h owns, in every tile of its split, the rows wr*wr_rows + x (x < wr_rows) with bit 2
+// of x equal to h (the C/D layout of the 32x32 MFMA tile, see the candidate kernels); chi2 bit b = split owns all rows of its split.
 #define KNN_FB_MAXJ 84          // dim_pad <= 1344 -> at most 84 elements per lane of a 16-lane row group
 __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ words, int dim, int dim_pad, int n_words,
                                                       const float* __restrict__ q, int ldq, int metric, int k, int tiles_per_split, int n_tiles,
+                                                      int tile_rows, int wr_rows /* rows per wave-row block = MI*32 (L2) */,
                                                       const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ items,
                                                       const int32_t* __restrict__ idx_in, const float* __restrict__ dist_in,
                                                       unsigned long long* __restrict__ item_out) {
@@ -602,8 +629,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
     const int g = lane >> 4, l16 = lane & 15;
     const uint32_t n_items = flag_count[1];
     const bool l2 = metric != ISMHIP_METRIC_CHI2;
-    const int tile_rows = l2 ? KNN_BM : CHI_B;
-    const int rows_per_tile = l2 ? 32 : CHI_B;
+    const int rows_per_tile = l2 ? wr_rows / 2 : tile_rows;       // a lane slot sees half of its wave-row block (bit 2 of the row == h)
     const int nj = dim_pad / 16;
     const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     for (uint32_t it = gw; it < n_items; it += nw) {
@@ -624,7 +650,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
             int r = n_words;                                  // out of range = idle group
             if (e < total) {
                 const int tile = mt0 + e / rows_per_tile, y = e % rows_per_tile;
-                const int x = l2 ? (wr * 64 + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y;
+                const int x = l2 ? (wr * wr_rows + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y;
                 r = tile * tile_rows + x;
             }
             float part = 0.f;
@@ -723,8 +749,14 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         qq = qpad; ldq = cb->dim_pad;
     }
     int n_splits, cand_per_split, n_cand, tiles_per_split;
+    // candidate kernel for squared L2: bf16x3 (default) or the exact-f32 MFMA contraction (ISMHIP_KNN_F32=1, kept for A/B runs)
+    const bool use_bf16 = metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi != nullptr && !ctx->knn_force_f32;
+    const bool big_tile = use_bf16 && nq >= 4096 && cb->n_words_pad >= 4096 && !ctx->knn_small_tile;      // 256x256 tile, 8 waves
+    const int BM = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BM) : CHI_B;
+    const int BNq = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BN) : CHI_B;
+    const int wr_rows = big_tile ? 128 : 64;
     if (metric == ISMHIP_METRIC_L2SQ) {
-        const int n_qt = (nq + KNN_BN - 1) / KNN_BN, n_mt = cb->n_words_pad / KNN_BM;
+        const int n_qt = (nq + BNq - 1) / BNq, n_mt = cb->n_words_pad / BM;
         const int max_s = 64 / (4 * T);
         n_splits = std::max(1, std::min(std::min(max_s, n_mt), (1024 + n_qt - 1) / n_qt));
         tiles_per_split = (n_mt + n_splits - 1) / n_splits;
@@ -750,11 +782,9 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     uint32_t* flag_count = flags; uint32_t* qrec = flags + 16; uint32_t* items = qrec + 3 * (size_t)nq;
     unsigned long long* item_out = (unsigned long long*)(((uintptr_t)(items + 2 * q_items) + 7) & ~(uintptr_t)7);
     ISM_HIP(ctx, hipMemsetAsync(flag_count, 0, 8, ctx->stream));
-    // candidate kernel for squared L2: bf16x3 (default) or the exact-f32 MFMA contraction (ISMHIP_KNN_F32=1, kept for A/B runs)
-    const bool use_bf16 = metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi != nullptr && !ctx->knn_force_f32;
     u16 *q_hi = nullptr, *q_lo = nullptr;
     if (use_bf16) {
-        const int nq_pad = (nq + KNN_BN - 1) / KNN_BN * KNN_BN;
+        const int nq_pad = (nq + BNq - 1) / BNq * BNq;
         const size_t tot = (size_t)nq_pad * cb->dim_pad;
         q_hi = (u16*)ism_scratch(ctx, SCR_KNN_QSPLIT, tot * 2 * sizeof(u16));
         if (!q_hi) return ISMHIP_ERR_NOMEM;
@@ -765,9 +795,23 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     {
         TimerScope ts(ctx, metric == ISMHIP_METRIC_L2SQ ? "knn_l2_mfma" : "knn_chi2");
         if (metric == ISMHIP_METRIC_L2SQ && use_bf16) {
-            const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
-            hipLaunchKernelGGL(k_knn_l2_bf16x3<T>, dim3(8 * ((n_qt + 7) / 8) * n_splits), dim3(256), 0, ctx->stream, cb->words_bf16_hi, cb->words_bf16_lo, cb->word_norm,
-                               cb->n_words_pad / KNN_BM, cb->dim_pad, q_hi, q_lo, nq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand, cand_bound, n_bound);
+            const int n_qt = (nq + BNq - 1) / BNq;
+            const dim3 grid(8 * ((n_qt + 7) / 8) * n_splits);
+            if (big_tile) {
+                auto kern = k_knn_l2_bf16x3<T, 2, 4, 4, 2>;
+                const size_t lds = (size_t)2 * (2 * 256 + 2 * 256) * KB_ROW * sizeof(u16) + 256 * sizeof(float);
+                static bool attr = false;
+                if (!attr) { ISM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+                hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, cb->words_bf16_hi, cb->words_bf16_lo, cb->word_norm,
+                                   cb->n_words_pad / BM, cb->dim_pad, q_hi, q_lo, nq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand, cand_bound, n_bound);
+            } else {
+                auto kern = k_knn_l2_bf16x3<T, 2, 2, 2, 2>;
+                const size_t lds = (size_t)2 * (2 * 128 + 2 * 128) * KB_ROW * sizeof(u16) + 128 * sizeof(float);
+                static bool attr = false;
+                if (!attr) { ISM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+                hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, cb->words_bf16_hi, cb->words_bf16_lo, cb->word_norm,
+                                   cb->n_words_pad / BM, cb->dim_pad, q_hi, q_lo, nq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand, cand_bound, n_bound);
+            }
             ISM_CHECK_LAUNCH(ctx, "k_knn_l2_bf16x3");
         } else if (metric == ISMHIP_METRIC_L2SQ) {
             const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
@@ -793,7 +837,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         TimerScope ts(ctx, "knn_fallback");
         if (cb->dim_pad / 16 > KNN_FB_MAXJ) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: descriptor longer than 1344 not built");
         hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad,
-                           cb->n_words, qq, ldq, metric, k, tiles_per_split, cb->n_words_pad / (metric == ISMHIP_METRIC_L2SQ ? KNN_BM : CHI_B),
+                           cb->n_words, qq, ldq, metric, k, tiles_per_split, cb->n_words_pad / BM, BM, wr_rows,
                            flag_count, items, idx_out, dist_out, item_out);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback");
         hipLaunchKernelGGL(k_knn_fallback_merge, dim3(64), dim3(256), 0, ctx->stream, k, flag_count, qrec, item_out, idx_out, dist_out);
