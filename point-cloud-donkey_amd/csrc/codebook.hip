@@ -7,10 +7,11 @@
 // of 256, dim_pad multiple of 32); votes as CSR over words with SoA payloads. Vote casting is HBM-bound
 // (V*(12+4+4+4) read + V*32 written) and tiny next to kNN.
 #include "common.h"
+#include <cstring>
 #include <cmath>
 #include <limits>
 
-int ism_codebook_split_bf16(ismhip_ctx* ctx, ismhip_codebook* cb);
+int ism_codebook_split_bf16(ismhip_ctx* ctx, ismhip_codebook* cb, uint32_t absmax_bits);
 
 namespace {
 
@@ -187,7 +188,9 @@ int ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* w
         cb->max_norm2 = mx;
     }
     {
-        int rc = ism_codebook_split_bf16(ctx, cb);
+        uint32_t amax = 0u;                                       // largest |element| as float bits (NaN/inf sort last)
+        for (size_t i = 0; i < (size_t)n_words * dim; ++i) { uint32_t b; memcpy(&b, &words_h[i], 4); b &= 0x7fffffffu; amax = b > amax ? b : amax; }
+        int rc = ism_codebook_split_bf16(ctx, cb, amax);
         if (rc != ISMHIP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(rc != ISMHIP_OK ? rc : ISMHIP_ERR_HIP, "codebook_create: bf16 split");
     }
     *out = cb;

@@ -52,6 +52,8 @@ struct ismhip_codebook {
     float* word_norm = nullptr;      // [n_words_pad] squared L2 norm (+inf for padding rows)
     unsigned short* words_bf16_hi = nullptr;   // [n_words_pad * dim_pad] RN_bf16(word)            (one allocation holds hi then lo)
     unsigned short* words_bf16_lo = nullptr;   // [n_words_pad * dim_pad] RN_bf16(word - hi)
+    unsigned short* words_f16 = nullptr;       // [n_words_pad * dim_pad] RN_f16(word * f16_scale)  (same allocation)
+    float f16_scale = 1.f;           // power of two: largest |element| * f16_scale in [2^13, 2^14)
     float max_norm2 = 0.f;           // max squared norm over the real rows (bounds the fp32 contraction error of kNN)
     float* word_weight = nullptr;    // [n_words]
     uint32_t* vote_off = nullptr;    // [n_words+1]
@@ -90,7 +92,7 @@ struct ismhip_ctx {
     std::vector<ismhip_cloud*> cloud_pool;
     uint32_t knn_stats[2] = {0, 0};   // last ismhip_knn: {queries, (query,slot) items} sent to the exact fallback (valid with timers on, after a sync)
     bool knn_small_tile = false; // env ISMHIP_KNN_TILE128=1: keep the bf16x3 kernel on its 128x128 tile (A/B runs)
-    bool knn_force_f32 = false;  // env ISMHIP_KNN_F32=1: squared-L2 candidates by the exact-f32 MFMA kernel instead of bf16x3
+    int knn_mode = 0;            // env ISMHIP_KNN_MODE = f16 (0, default) | bf16x3 (1) | f32 (2): squared-L2 candidate kernel (A/B runs, tests)
 };
 
 enum ScratchSlot {

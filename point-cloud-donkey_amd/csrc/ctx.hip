@@ -61,7 +61,7 @@ static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ISMHIP_ERR_NODEVICE;   // code objects are gfx950 only
     ismhip_ctx* ctx = new ismhip_ctx();
     ctx->device = device;
-    { const char* e = getenv("ISMHIP_KNN_F32"); ctx->knn_force_f32 = e && e[0] == '1'; }
+    { const char* e = getenv("ISMHIP_KNN_MODE"); ctx->knn_mode = !e ? 0 : (!strcmp(e, "bf16x3") ? 1 : (!strcmp(e, "f32") ? 2 : 0)); }
     { const char* e = getenv("ISMHIP_KNN_TILE128"); ctx->knn_small_tile = e && e[0] == '1'; }
     if (!own) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else {

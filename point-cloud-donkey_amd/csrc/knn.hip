@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
 // returned. bf16 keeps fp32's exponent range (no underflow of the residuals) and v_mfma_f32_32x32x16_bf16 runs at 16x the
 // rate of the f32-input MFMA, so three of them per 16-k step are ~5x cheaper than the exact-f32 contraction.
 // Error bound used by the proof (VerifyParams::dot_rel, relative to |q||c|):
-//   representation : |q - qh - ql| <= 2^-18 |q| element-wise (two RN-to-bf16 steps, u = 2^-9), the dropped ql.cl term and
-//                    the two residual cross terms give <= 3.1 * 2^-18
+//   representation : |q - qh - ql| <= 2^-16 |q| element-wise (two RN-to-bf16 steps, 8 significant bits: u = 2^-8), the dropped
+//                    ql.cl term and the two residual cross terms give <= 3.1 * 2^-16
 //   accumulation   : products of bf16 pairs are exact in fp32; the 3K-term sum is modelled as fp32 additions in ANY order
 //                    with a per-add unit roundoff of 2^-23 (i.e. not even assuming round-to-nearest inside the MFMA)
 //                    -> 1.01 * 3K * 2^-23
@@ -235,14 +235,65 @@ __global__ void k_split_bf16(const float* __restrict__ src, int n, int dim, int 
     hi[i] = h; lo[i] = f32_to_bf16_rn(x - hf);
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// ---- f16 image (NTERM = 1). x -> RN_f16(x * s), s a power of two that puts the largest |element| into [2^13, 2^14) (clamped to
+// 2^+-40), so neither overflow nor the fp16 subnormal range matters: element error <= 2^-11 |x| + 2^-14 / s, where the second
+// term assumes the worst (subnormal results flushed to zero). absmax is kept as float bits (non-negative floats order like uints;
+// NaN/inf sort last and select s = 1, the affected scores become NaN/inf and those queries take the exact path).
+__global__ void k_absmax(const float* __restrict__ src, int n, int dim, int ld, uint32_t* __restrict__ out_bits) {
+    uint32_t m = 0u;
+    const size_t tot = (size_t)n * dim;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / dim), col = (int)(i % dim);
+        const uint32_t b = __float_as_uint(src[(size_t)row * ld + col]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
+}
+__host__ __device__ inline float f16_scale_for(uint32_t absmax_bits) {
+    const int e = (int)(absmax_bits >> 23);          // biased exponent; 0 = zero/subnormal, 255 = inf/NaN
+    if (e == 0 || e == 255) return 1.0f;
+    int k = 13 - (e - 127);                          // absmax * 2^k in [2^13, 2^14)
+    k = k > 40 ? 40 : (k < -40 ? -40 : k);
+    union { uint32_t u; float f; } v; v.u = (uint32_t)(127 + k) << 23;
+    return v.f;
+}
+// sc[0] = absmax bits (in), sc[1] = -2 / (s * other_scale) (out), sc[2] = 2^-14 / s (out: worst-case absolute element error)
+__global__ void k_to_f16(const float* __restrict__ src, int n, int dim, int ld, int n_pad, int dim_pad,
+                         uint32_t* __restrict__ sc, float other_scale, u16* __restrict__ dst) {
+    const float s = f16_scale_for(sc[0]);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        ((float*)sc)[1] = -2.0f / (s * other_scale);
+        ((float*)sc)[2] = (sc[0] >> 23) == 255u ? __builtin_inff() : 6.103515625e-05f / s;     // inf/NaN in the batch: nothing is provable
+    }
+    if (i >= (size_t)n_pad * dim_pad) return;
+    const int row = (int)(i / dim_pad), col = (int)(i % dim_pad);
+    float x = 0.f;
+    if (row < n && col < dim) x = src[(size_t)row * ld + col];
+    const _Float16 hx = (_Float16)(x * s);            // v_cvt_f16_f32, round to nearest even
+    dst[i] = __builtin_bit_cast(u16, hx);
+}
+
 // Tile geometry is a template: WR x WC waves, each MI x NI MFMA tiles of 32x32 -> BM = WR*MI*32 codeword rows by
 // BN = WC*NI*32 queries per workgroup. The CU's load path delivers ~30 B/clk from L2 (MI355X_MICROARCH 'Indexed rows'), a
 // 128x128 tile needs 32 KB per 32-k slice for 768 MFMA cycles per wave and is load-bound; the 256x256 tile (8 waves, 64 KB per
 // slice for 1536 MFMA cycles per wave, 128 KB of LDS, one workgroup per CU) is MFMA-bound.
-template <int T, int WR, int WC, int MI, int NI>
+//
+// NTERM = 3: bf16x3 (hi/lo images, three MFMAs per product, |error| ~ 2^-16 |q||c|).
+// NTERM = 1: f16 (one fp16 image scaled by a power of two so that the largest element sits in [2^13, 2^14), ONE MFMA per
+//            product, |error| ~ 2^-11 |q||c|). The scores only have to RANK the codewords well enough for the top-T slots to
+//            hold the true neighbours; k_knn_rerank recomputes every surviving candidate with the exact functor and proves the
+//            result with the rigorous bound of this kernel's error, so the answer stays exact at a third of the MFMA work.
+//            out_scale = -2 / (codebook scale * query scale) is read from device memory (the query scale is found on device).
+template <int T, int WR, int WC, int MI, int NI, int NTERM>
 __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_bf16x3(const u16* __restrict__ wh, const u16* __restrict__ wl,
                                                           const float* __restrict__ word_norm, int n_tiles_m, int dim_pad,
                                                           const u16* __restrict__ qh, const u16* __restrict__ ql, int nq,
+                                                          const float* __restrict__ out_scale,
                                                           int tiles_per_split, int n_splits,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
                                                           float* __restrict__ cand_bound, int bound_stride) {
@@ -250,11 +301,13 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_bf16x3(const u16* __
     constexpr int RPP = NT / 4;                       // rows staged per pass (4 threads x 16 B per 64-B row)
     constexpr int PA = BM / RPP, PB = BN / RPP;       // passes per array
     extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
+    constexpr bool X3 = NTERM == 3;
     u16* sAh = (u16*)knn_smem;                        // [2][BM*32]
-    u16* sAl = sAh + 2 * BM * KB_ROW;
+    u16* sAl = sAh + (X3 ? 2 * BM * KB_ROW : 0);
     u16* sBh = sAl + 2 * BM * KB_ROW;                 // [2][BN*32]
-    u16* sBl = sBh + 2 * BN * KB_ROW;
+    u16* sBl = sBh + (X3 ? 2 * BN * KB_ROW : 0);
     float* sCn = (float*)(sBl + 2 * BN * KB_ROW);     // [BM]
+    const float oscale = NTERM == 1 ? out_scale[0] : -2.0f;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -303,15 +356,15 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_bf16x3(const u16* __
 
         f32x4 gah[PA], gal[PA], gbh[PB], gbl[PB];
 #pragma unroll
-        for (int p = 0; p < PA; ++p) { gah[p] = *(const f32x4*)(wh + aoff + (size_t)p * RPP * dim_pad); gal[p] = *(const f32x4*)(wl + aoff + (size_t)p * RPP * dim_pad); }
+        for (int p = 0; p < PA; ++p) { gah[p] = *(const f32x4*)(wh + aoff + (size_t)p * RPP * dim_pad); if constexpr (X3) gal[p] = *(const f32x4*)(wl + aoff + (size_t)p * RPP * dim_pad); }
 #pragma unroll
-        for (int p = 0; p < PB; ++p) { gbh[p] = *(const f32x4*)(qh + qoff + (size_t)p * RPP * dim_pad); gbl[p] = *(const f32x4*)(ql + qoff + (size_t)p * RPP * dim_pad); }
+        for (int p = 0; p < PB; ++p) { gbh[p] = *(const f32x4*)(qh + qoff + (size_t)p * RPP * dim_pad); if constexpr (X3) gbl[p] = *(const f32x4*)(ql + qoff + (size_t)p * RPP * dim_pad); }
         __syncthreads();                                   // previous tile's epilogue has finished reading sCn / LDS
         for (int i = tid; i < BM; i += NT) sCn[i] = word_norm[mt * BM + i];
 #pragma unroll
-        for (int p = 0; p < PA; ++p) { *(f32x4*)(&sAh[sdst[p]]) = gah[p]; *(f32x4*)(&sAl[sdst[p]]) = gal[p]; }
+        for (int p = 0; p < PA; ++p) { *(f32x4*)(&sAh[sdst[p]]) = gah[p]; if constexpr (X3) *(f32x4*)(&sAl[sdst[p]]) = gal[p]; }
 #pragma unroll
-        for (int p = 0; p < PB; ++p) { *(f32x4*)(&sBh[sdst[p]]) = gbh[p]; *(f32x4*)(&sBl[sdst[p]]) = gbl[p]; }
+        for (int p = 0; p < PB; ++p) { *(f32x4*)(&sBh[sdst[p]]) = gbh[p]; if constexpr (X3) *(f32x4*)(&sBl[sdst[p]]) = gbl[p]; }
         __syncthreads();
 
         for (int kc = 0; kc < nk; ++kc) {
@@ -319,35 +372,47 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_bf16x3(const u16* __
             if (kc + 1 < nk) {
                 const int ko = (kc + 1) * KNN_BK;
 #pragma unroll
-                for (int p = 0; p < PA; ++p) { gah[p] = *(const f32x4*)(wh + aoff + (size_t)p * RPP * dim_pad + ko); gal[p] = *(const f32x4*)(wl + aoff + (size_t)p * RPP * dim_pad + ko); }
+                for (int p = 0; p < PA; ++p) { gah[p] = *(const f32x4*)(wh + aoff + (size_t)p * RPP * dim_pad + ko); if constexpr (X3) gal[p] = *(const f32x4*)(wl + aoff + (size_t)p * RPP * dim_pad + ko); }
 #pragma unroll
-                for (int p = 0; p < PB; ++p) { gbh[p] = *(const f32x4*)(qh + qoff + (size_t)p * RPP * dim_pad + ko); gbl[p] = *(const f32x4*)(ql + qoff + (size_t)p * RPP * dim_pad + ko); }
+                for (int p = 0; p < PB; ++p) { gbh[p] = *(const f32x4*)(qh + qoff + (size_t)p * RPP * dim_pad + ko); if constexpr (X3) gbl[p] = *(const f32x4*)(ql + qoff + (size_t)p * RPP * dim_pad + ko); }
             }
             const u16* cAh = sAh + cur * BM * KB_ROW; const u16* cAl = sAl + cur * BM * KB_ROW;
             const u16* cBh = sBh + cur * BN * KB_ROW; const u16* cBl = sBl + cur * BN * KB_ROW;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 bh[NI], bl[NI];
+                if constexpr (X3) {
+                    bf16x8 bh[NI], bl[NI];
 #pragma unroll
-                for (int n = 0; n < NI; ++n) { bh[n] = *(const bf16x8*)(cBh + offB[n][ks]); bl[n] = *(const bf16x8*)(cBl + offB[n][ks]); }
+                    for (int n = 0; n < NI; ++n) { bh[n] = *(const bf16x8*)(cBh + offB[n][ks]); bl[n] = *(const bf16x8*)(cBl + offB[n][ks]); }
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const bf16x8 ah = *(const bf16x8*)(cAh + offA[mi][ks]);
-                    const bf16x8 al = *(const bf16x8*)(cAl + offA[mi][ks]);
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const bf16x8 ah = *(const bf16x8*)(cAh + offA[mi][ks]);
+                        const bf16x8 al = *(const bf16x8*)(cAl + offA[mi][ks]);
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+                        for (int ni = 0; ni < NI; ++ni) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    f16x8 bh[NI];
+#pragma unroll
+                    for (int n = 0; n < NI; ++n) bh[n] = *(const f16x8*)(cBh + offB[n][ks]);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const f16x8 ah = *(const f16x8*)(cAh + offA[mi][ks]);
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
                     }
                 }
             }
             if (kc + 1 < nk) {
                 const int nx = cur ^ 1;
 #pragma unroll
-                for (int p = 0; p < PA; ++p) { *(f32x4*)(&sAh[nx * BM * KB_ROW + sdst[p]]) = gah[p]; *(f32x4*)(&sAl[nx * BM * KB_ROW + sdst[p]]) = gal[p]; }
+                for (int p = 0; p < PA; ++p) { *(f32x4*)(&sAh[nx * BM * KB_ROW + sdst[p]]) = gah[p]; if constexpr (X3) *(f32x4*)(&sAl[nx * BM * KB_ROW + sdst[p]]) = gal[p]; }
 #pragma unroll
-                for (int p = 0; p < PB; ++p) { *(f32x4*)(&sBh[nx * BN * KB_ROW + sdst[p]]) = gbh[p]; *(f32x4*)(&sBl[nx * BN * KB_ROW + sdst[p]]) = gbl[p]; }
+                for (int p = 0; p < PB; ++p) { *(f32x4*)(&sBh[nx * BN * KB_ROW + sdst[p]]) = gbh[p]; if constexpr (X3) *(f32x4*)(&sBl[nx * BN * KB_ROW + sdst[p]]) = gbl[p]; }
             }
             __syncthreads();
         }
@@ -363,7 +428,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_bf16x3(const u16* __
                 const float tau = top[ni].v[T];
                 bool any = false;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { acc[mi][ni][e] = cn[e] - 2.0f * acc[mi][ni][e]; any |= acc[mi][ni][e] < tau; }
+                for (int e = 0; e < 16; ++e) { acc[mi][ni][e] = cn[e] + oscale * acc[mi][ni][e]; any |= acc[mi][ni][e] < tau; }
                 if (__any(any)) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
@@ -516,7 +581,16 @@ struct VerifyParams {
     float ku;         // 1.01 * K * u : relative error bound of a K-term fp32 functor sum (u = 2^-24)
     float dot_rel;    // bound on |approx(q.c) - q.c| / (|q||c|) of the candidate kernel (f32 fma chain: ku; bf16x3: see k_knn_l2_bf16x3)
     float cmax2;      // max |c|^2 over the codebook (L2 only)
+    float dabs_c;     // f16 candidates: worst-case absolute error of one codebook element (2^-14 / scale), else 0
+    const float* dabs_q;   // f16 candidates: the same for the query batch (device scalar), else nullptr
+    float sqrt_dim;   // sqrt(dim_pad)
 };
+// absolute part of the candidate kernel's dot-product error: sum |dq_i c_i| + |q_i dc_i| + |dq_i dc_i| with |dq_i| <= dq, |dc_i| <= dc
+__device__ __forceinline__ float knn_abs_err(const VerifyParams& vp, float qn2) {
+    if (!vp.dabs_q) return 0.f;
+    const float dq = vp.dabs_q[0], dc = vp.dabs_c;
+    return 1.01f * (vp.sqrt_dim * (dq * sqrtf(vp.cmax2) + dc * sqrtf(qn2)) + vp.sqrt_dim * vp.sqrt_dim * dq * dc);
+}
 #define KNN_U 5.9604645e-08f
 
 __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ words, int dim, int dim_pad, int n_words,
@@ -553,7 +627,7 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
     }
     float slack;
     if (metric == ISMHIP_METRIC_CHI2) slack = 4.f * (((float)dim_pad + 8.f) * KNN_U + vp.ku) * fabsf(kth);
-    else slack = 2.f * (17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2)) + 4.f * vp.ku * (qn2 + fabsf(kth) + vp.cmax2);
+    else slack = 2.f * (17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2)) + 4.f * vp.ku * (qn2 + fabsf(kth) + vp.cmax2);
     unsigned long long key = ~0ull;
     if (id >= 0 && !(av > kth + slack)) {     // NaN scores are never skipped
         const float* wp = words + (size_t)id * dim_pad;
@@ -582,14 +656,18 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
     //   chi2: all terms are non-negative, v_rcp_f32 is 1 ulp: D >= bnd_b (1 - (K + 8) u)
     // and its functor value is >= D (1 - 1.01 K u). If that is above the k-th exact functor value, the slot cannot hold a
     // better row. Slots that fail (or NaNs) are handed to the exact scan, restricted to the rows of those slots.
+    // A slot whose bound is still +inf dropped nothing -- unless scores overflowed (+inf / NaN scores are never kept): that needs
+    // an inf or NaN in |q|^2, |c|max^2 or their product (or in the f16 scales), all of which make the error bound below non-finite.
     bool viol = false;
-    if (lane < n_bound && bnd != __builtin_inff()) {
+    const float eps_chk = metric == ISMHIP_METRIC_CHI2 ? qn2 + vp.cmax2
+                        : 17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2) + qn2;
+    if (lane < n_bound && (bnd != __builtin_inff() || !(eps_chk < __builtin_inff()))) {
         if (!have_k) viol = true;
         else if (metric == ISMHIP_METRIC_CHI2) {
             const float lo = bnd * (1.f - ((float)dim_pad + 8.f) * KNN_U) * (1.f - vp.ku);
             viol = !(dk < lo);
         } else {
-            const float eps_s = 17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2);
+            const float eps_s = 17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2);
             const float rhs = qn2 * (1.f - 16.f * KNN_U) + bnd - eps_s;
             viol = !(dk < rhs - vp.ku * fabsf(rhs) - 1e-37f);
         }
@@ -618,13 +696,19 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
 // item_out; k_knn_fallback_merge folds them into the query's result.
 // Slot -> rows: L2 bit b = split*4 + wr*2 + h owns, in every tile of its split, the rows wr*wr_rows + x (x < wr_rows) with bit 2
 // of x equal to h (the C/D layout of the 32x32 MFMA tile, see the candidate kernels); chi2 bit b = split owns all rows of its split.
+#define KNN_FB_UNITS 8192u      // work units (item x row range) when items are few
+__host__ __device__ inline uint32_t knn_fb_parts(uint32_t n_items) {
+    if (n_items == 0 || n_items > KNN_FB_UNITS / 2) return 1u;
+    const uint32_t p = KNN_FB_UNITS / n_items;
+    return p > 64u ? 64u : p;
+}
 #define KNN_FB_MAXJ 84          // dim_pad <= 1344 -> at most 84 elements per lane of a 16-lane row group
 __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ words, int dim, int dim_pad, int n_words,
                                                       const float* __restrict__ q, int ldq, int metric, int k, int tiles_per_split, int n_tiles,
                                                       int tile_rows, int wr_rows /* rows per wave-row block = MI*32 (L2) */,
                                                       const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ items,
                                                       const int32_t* __restrict__ idx_in, const float* __restrict__ dist_in,
-                                                      unsigned long long* __restrict__ item_out) {
+                                                      unsigned long long* __restrict__ item_out, size_t part_base) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, l16 = lane & 15;
     const uint32_t n_items = flag_count[1];
@@ -632,7 +716,12 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
     const int rows_per_tile = l2 ? wr_rows / 2 : tile_rows;       // a lane slot sees half of its wave-row block (bit 2 of the row == h)
     const int nj = dim_pad / 16;
     const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-    for (uint32_t it = gw; it < n_items; it += nw) {
+    // With few items a wave per item would leave the chip idle behind a handful of long scans: every item is cut into P row
+    // ranges (P * n_items <= KNN_FB_UNITS), each range leaves its own k best in part_out and the merge kernel folds them.
+    const uint32_t P = knn_fb_parts(n_items);
+    unsigned long long* outp = P > 1 ? item_out + 4 * part_base : item_out;
+    for (uint32_t u = gw; u < n_items * P; u += nw) {
+        const uint32_t it = u / P, part_i = u % P;
         const int qi = (int)items[2 * (size_t)it], b = (int)items[2 * (size_t)it + 1];
         const float* qp = q + (size_t)qi * ldq;
         const int split = l2 ? (b >> 2) : b;
@@ -645,10 +734,12 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
             const int id = idx_in[(size_t)qi * k + (k - 1)];
             if (id >= 0) thr = dist_in[(size_t)qi * k + (k - 1)];
         }
-        for (int e0 = 0; e0 < total; e0 += 4) {
+        const int steps = (total + 3) / 4;
+        const int e_beg = 4 * (int)((long long)steps * part_i / P), e_end = min(total, 4 * (int)((long long)steps * (part_i + 1) / P));
+        for (int e0 = e_beg; e0 < e_end; e0 += 4) {
             const int e = e0 + g;
             int r = n_words;                                  // out of range = idle group
-            if (e < total) {
+            if (e < e_end) {
                 const int tile = mt0 + e / rows_per_tile, y = e % rows_per_tile;
                 const int x = l2 ? (wr * wr_rows + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y;
                 r = tile * tile_rows + x;
@@ -674,13 +765,15 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
                 if (best[k - 1] != ~0ull) thr = fminf(thr, __uint_as_float((unsigned)(best[k - 1] >> 32)));
             }
         }
-        if (lane < 4) item_out[4 * (size_t)it + lane] = lane == 0 ? best[0] : (lane == 1 ? best[1] : (lane == 2 ? best[2] : best[3]));
+        if (lane < 4) outp[4 * (size_t)u + lane] = lane == 0 ? best[0] : (lane == 1 ? best[1] : (lane == 2 ? best[2] : best[3]));
     }
 }
 
 __global__ void k_knn_fallback_merge(int k, const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ qrec,
-                                     const unsigned long long* __restrict__ item_out, int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
+                                     const unsigned long long* __restrict__ item_out, size_t part_base, int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
     const uint32_t n_q = flag_count[0];
+    const uint32_t P = knn_fb_parts(flag_count[1]);
+    const unsigned long long* outp = P > 1 ? item_out + 4 * part_base : item_out;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_q; t += gridDim.x * blockDim.x) {
         const int qi = (int)qrec[3 * (size_t)t]; const uint32_t ibase = qrec[3 * (size_t)t + 1], ni = qrec[3 * (size_t)t + 2];
         unsigned long long fin[4] = {~0ull, ~0ull, ~0ull, ~0ull};
@@ -692,7 +785,7 @@ __global__ void k_knn_fallback_merge(int k, const uint32_t* __restrict__ flag_co
             const int id = idx_out[(size_t)qi * k + j];
             if (id >= 0) ins(((unsigned long long)__float_as_uint(dist_out[(size_t)qi * k + j]) << 32) | (unsigned)id);
         }
-        for (uint32_t i = 0; i < ni; ++i) for (int j = 0; j < k; ++j) { const unsigned long long key = item_out[4 * (size_t)(ibase + i) + j]; if (key != ~0ull) ins(key); }
+        for (uint32_t i = 0; i < ni * P; ++i) for (int j = 0; j < k; ++j) { const unsigned long long key = outp[4 * ((size_t)ibase * P + i) + j]; if (key != ~0ull) ins(key); }
         for (int j = 0; j < k; ++j) {
             if (fin[j] == ~0ull) { idx_out[(size_t)qi * k + j] = -1; dist_out[(size_t)qi * k + j] = __builtin_nanf(""); }
             else { idx_out[(size_t)qi * k + j] = (int)(fin[j] & 0xffffffffull); dist_out[(size_t)qi * k + j] = __uint_as_float((unsigned)(fin[j] >> 32)); }
@@ -749,9 +842,11 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         qq = qpad; ldq = cb->dim_pad;
     }
     int n_splits, cand_per_split, n_cand, tiles_per_split;
-    // candidate kernel for squared L2: bf16x3 (default) or the exact-f32 MFMA contraction (ISMHIP_KNN_F32=1, kept for A/B runs)
-    const bool use_bf16 = metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi != nullptr && !ctx->knn_force_f32;
-    const bool big_tile = use_bf16 && nq >= 4096 && cb->n_words_pad >= 4096 && !ctx->knn_small_tile;      // 256x256 tile, 8 waves
+    // candidate kernel for squared L2: f16 (default), bf16x3 (ISMHIP_KNN_MODE=bf16x3) or the exact-f32 MFMA contraction
+    // (ISMHIP_KNN_MODE=f32); the last two are kept for A/B runs and as the reference points of the error model tests
+    const int mode = metric != ISMHIP_METRIC_L2SQ ? -1 : (ctx->knn_mode == 0 && cb->words_f16 ? 0 : (ctx->knn_mode <= 1 && cb->words_bf16_hi ? 1 : 2));
+    const bool use_lp = mode == 0 || mode == 1;
+    const bool big_tile = use_lp && nq >= 4096 && cb->n_words_pad >= 4096 && !ctx->knn_small_tile;      // 256x256 tile, 8 waves
     const int BM = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BM) : CHI_B;
     const int BNq = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BN) : CHI_B;
     const int wr_rows = big_tile ? 128 : 64;
@@ -776,42 +871,49 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     int* cand_idx = (int*)ism_scratch(ctx, SCR_KNN_CAND_IDX, (size_t)nq * n_cand * sizeof(int));
     // queue of unproven work: 16 counters | query records [nq*3] | items [nq*n_bound*2] | item results [nq*n_bound*4] u64
     const size_t q_items = (size_t)nq * n_bound;
-    uint32_t* flags = (uint32_t*)ism_scratch(ctx, SCR_KNN_FLAGS, (16 + 3 * (size_t)nq + 2 * q_items) * sizeof(uint32_t) + 8 + q_items * 4 * sizeof(unsigned long long));
+    uint32_t* flags = (uint32_t*)ism_scratch(ctx, SCR_KNN_FLAGS, (16 + 3 * (size_t)nq + 2 * q_items) * sizeof(uint32_t) + 8 + (q_items + KNN_FB_UNITS) * 4 * sizeof(unsigned long long));
     if (!cand_val || !cand_idx || !flags) return ISMHIP_ERR_NOMEM;
     float* cand_bound = cand_val + (size_t)nq * n_cand;
     uint32_t* flag_count = flags; uint32_t* qrec = flags + 16; uint32_t* items = qrec + 3 * (size_t)nq;
     unsigned long long* item_out = (unsigned long long*)(((uintptr_t)(items + 2 * q_items) + 7) & ~(uintptr_t)7);
-    ISM_HIP(ctx, hipMemsetAsync(flag_count, 0, 8, ctx->stream));
+    ISM_HIP(ctx, hipMemsetAsync(flag_count, 0, 32, ctx->stream));
+    uint32_t* qsc = flag_count + 4;      // f16 mode: [0] absmax bits of the query batch, [1] -2/(s_q s_c), [2] 2^-14/s_q
     u16 *q_hi = nullptr, *q_lo = nullptr;
-    if (use_bf16) {
+    if (use_lp) {
         const int nq_pad = (nq + BNq - 1) / BNq * BNq;
         const size_t tot = (size_t)nq_pad * cb->dim_pad;
         q_hi = (u16*)ism_scratch(ctx, SCR_KNN_QSPLIT, tot * 2 * sizeof(u16));
         if (!q_hi) return ISMHIP_ERR_NOMEM;
         q_lo = q_hi + tot;
-        hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->dim_pad, q_hi, q_lo);
-        ISM_CHECK_LAUNCH(ctx, "k_split_bf16");
+        if (mode == 0) {
+            hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, qsc);
+            ISM_CHECK_LAUNCH(ctx, "k_absmax");
+            hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->dim_pad, qsc, cb->f16_scale, q_hi);
+            ISM_CHECK_LAUNCH(ctx, "k_to_f16");
+        } else {
+            hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->dim_pad, q_hi, q_lo);
+            ISM_CHECK_LAUNCH(ctx, "k_split_bf16");
+        }
     }
     {
         TimerScope ts(ctx, metric == ISMHIP_METRIC_L2SQ ? "knn_l2_mfma" : "knn_chi2");
-        if (metric == ISMHIP_METRIC_L2SQ && use_bf16) {
+        if (use_lp) {
             const int n_qt = (nq + BNq - 1) / BNq;
             const dim3 grid(8 * ((n_qt + 7) / 8) * n_splits);
-            if (big_tile) {
-                auto kern = k_knn_l2_bf16x3<T, 2, 4, 4, 2>;
-                const size_t lds = (size_t)2 * (2 * 256 + 2 * 256) * KB_ROW * sizeof(u16) + 256 * sizeof(float);
-                static bool attr = false;
-                if (!attr) { ISM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-                hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, cb->words_bf16_hi, cb->words_bf16_lo, cb->word_norm,
-                                   cb->n_words_pad / BM, cb->dim_pad, q_hi, q_lo, nq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand, cand_bound, n_bound);
-            } else {
-                auto kern = k_knn_l2_bf16x3<T, 2, 2, 2, 2>;
-                const size_t lds = (size_t)2 * (2 * 128 + 2 * 128) * KB_ROW * sizeof(u16) + 128 * sizeof(float);
-                static bool attr = false;
-                if (!attr) { ISM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-                hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, cb->words_bf16_hi, cb->words_bf16_lo, cb->word_norm,
-                                   cb->n_words_pad / BM, cb->dim_pad, q_hi, q_lo, nq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand, cand_bound, n_bound);
-            }
+            const u16* wh = mode == 0 ? cb->words_f16 : cb->words_bf16_hi;
+            const u16* wl = mode == 0 ? nullptr : cb->words_bf16_lo;
+            const int nterm = mode == 0 ? 1 : 3;
+            const size_t lds = (size_t)2 * (BM + BNq) * KB_ROW * sizeof(u16) * (nterm == 3 ? 2 : 1) + BM * sizeof(float);
+            const void* kern = big_tile ? (nterm == 3 ? (const void*)k_knn_l2_bf16x3<T, 2, 4, 4, 2, 3> : (const void*)k_knn_l2_bf16x3<T, 2, 4, 4, 2, 1>)
+                                        : (nterm == 3 ? (const void*)k_knn_l2_bf16x3<T, 2, 2, 2, 2, 3> : (const void*)k_knn_l2_bf16x3<T, 2, 2, 2, 2, 1>);
+            static bool attr[4] = {false, false, false, false};
+            const int ai = (big_tile ? 2 : 0) + (nterm == 3 ? 1 : 0);
+            if (!attr[ai]) { ISM_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr[ai] = true; }
+            const float* word_norm = cb->word_norm; const float* osc = (const float*)(qsc + 1);
+            int n_tiles_m = cb->n_words_pad / BM, dim_pad = cb->dim_pad, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
+            const u16* qh_ = q_hi; const u16* ql_ = q_lo;
+            void* args[] = {&wh, &wl, &word_norm, &n_tiles_m, &dim_pad, &qh_, &ql_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb};
+            ISM_HIP(ctx, hipLaunchKernel(kern, grid, dim3(big_tile ? 512 : 256), args, lds, ctx->stream));
             ISM_CHECK_LAUNCH(ctx, "k_knn_l2_bf16x3");
         } else if (metric == ISMHIP_METRIC_L2SQ) {
             const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
@@ -828,8 +930,13 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     }
     VerifyParams vp;
     vp.ku = 1.01f * (float)cb->dim_pad * KNN_U;
-    vp.dot_rel = use_bf16 ? (3.1f * 3.814697265625e-06f + 1.01f * 3.f * (float)cb->dim_pad * 1.1920929e-07f) : vp.ku;
+    // relative part of the candidate kernel's dot error (see the kernels): representation + accumulation (<= 2^-23 per add, any order)
+    vp.dot_rel = mode == 0 ? (2.002f * 4.8828125e-04f + 1.01f * (float)cb->dim_pad * 1.1920929e-07f)
+               : mode == 1 ? (3.1f * 1.52587890625e-05f + 1.01f * 3.f * (float)cb->dim_pad * 1.1920929e-07f) : vp.ku;
     vp.cmax2 = cb->max_norm2;
+    vp.dabs_c = mode == 0 ? 6.103515625e-05f / cb->f16_scale : 0.f;
+    vp.dabs_q = mode == 0 ? (const float*)(qsc + 2) : nullptr;
+    vp.sqrt_dim = sqrtf((float)cb->dim_pad);
     hipLaunchKernelGGL(k_knn_rerank, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
                        qq, nq, ldq, metric, cand_idx, cand_val, n_cand, n_cand, cand_bound, n_bound, vp, k, idx_out, dist_out, flag_count, qrec, items);
     ISM_CHECK_LAUNCH(ctx, "k_knn_rerank");
@@ -838,9 +945,9 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         if (cb->dim_pad / 16 > KNN_FB_MAXJ) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: descriptor longer than 1344 not built");
         hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad,
                            cb->n_words, qq, ldq, metric, k, tiles_per_split, cb->n_words_pad / BM, BM, wr_rows,
-                           flag_count, items, idx_out, dist_out, item_out);
+                           flag_count, items, idx_out, dist_out, item_out, q_items);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback");
-        hipLaunchKernelGGL(k_knn_fallback_merge, dim3(64), dim3(256), 0, ctx->stream, k, flag_count, qrec, item_out, idx_out, dist_out);
+        hipLaunchKernelGGL(k_knn_fallback_merge, dim3(64), dim3(256), 0, ctx->stream, k, flag_count, qrec, item_out, q_items, idx_out, dist_out);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback_merge");
     }
     if (ctx->timers_on) ISM_HIP(ctx, hipMemcpyAsync(ctx->knn_stats, flag_count, 8, hipMemcpyDeviceToHost, ctx->stream));   // read back after a sync
@@ -849,14 +956,22 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
 
 }  // namespace
 
-// bf16 hi/lo images of the codebook for k_knn_l2_bf16x3 (called once from ismhip_codebook_create)
-int ism_codebook_split_bf16(ismhip_ctx* ctx, ismhip_codebook* cb) {
+// bf16 hi/lo and scaled-f16 images of the codebook for k_knn_l2_bf16x3 (called once from ismhip_codebook_create)
+int ism_codebook_split_bf16(ismhip_ctx* ctx, ismhip_codebook* cb, uint32_t absmax_bits) {
     const size_t tot = (size_t)cb->n_words_pad * cb->dim_pad;
-    if (hipMalloc((void**)&cb->words_bf16_hi, tot * 2 * sizeof(u16)) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook bf16 images");
+    if (hipMalloc((void**)&cb->words_bf16_hi, tot * 3 * sizeof(u16) + 16) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook bf16/f16 images");
     cb->words_bf16_lo = cb->words_bf16_hi + tot;
+    cb->words_f16 = cb->words_bf16_lo + tot;
+    uint32_t* sc = (uint32_t*)(cb->words_f16 + tot);
     hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, cb->words, cb->n_words_pad, cb->dim_pad, cb->dim_pad,
                        cb->n_words_pad, cb->dim_pad, cb->words_bf16_hi, cb->words_bf16_lo);
     ISM_CHECK_LAUNCH(ctx, "k_split_bf16");
+    cb->f16_scale = f16_scale_for(absmax_bits);
+    ISM_HIP(ctx, hipMemcpyAsync(sc, &absmax_bits, 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, cb->words, cb->n_words_pad, cb->dim_pad, cb->dim_pad,
+                       cb->n_words_pad, cb->dim_pad, sc, 1.0f, cb->words_f16);
+    ISM_CHECK_LAUNCH(ctx, "k_to_f16");
+    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));       // absmax_bits is a stack variable of the caller's frame
     return ISMHIP_OK;
 }
 
@@ -871,7 +986,7 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
     TimerScope ts(ctx, "knn");
     // T = candidates kept per slot. The bf16x3 candidate scores carry a larger error bound, so more are kept (T = 4): the proof
     // then compares against the 5th best of every slot and almost never fails.
-    const bool wide = k > 2 || (metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi && !ctx->knn_force_f32);
+    const bool wide = k > 2 || (metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi && ctx->knn_mode <= 1);
     return wide ? run_knn<4>(ctx, cb, metric, nq, q, k, idx_out, dist_out) : run_knn<2>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
 }
 

@@ -271,6 +271,85 @@ def test_knn_matches_oracle_on_clustered_unit_vectors(pkg, gpu, ora):
         assert np.array_equal(dist.cpu().numpy(), wdist)
 
 
+def _knn_flagged(ctx):
+    return int(ctx.timer("knn_flagged_queries")[0]), int(ctx.timer("knn_flagged_items")[0])
+
+
+def test_knn_few_unproven_slots_take_the_split_scan(pkg, gpu, ora):
+    """Six identical copies of one codeword inside ONE candidate slot (rows 0-3, 8, 9 of the first tile: same wave-row block, same
+    accumulator half) overflow the slot's top-4 with equal scores, so the proof fails for exactly that (query, slot) pair. With so
+    few unproven items the exact scan cuts every item into row ranges; results must still be the oracle's (lowest row on ties)."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(123)
+    words = rng.random((3000, 352)).astype(np.float32)
+    words /= np.linalg.norm(words, axis=1, keepdims=True)
+    for r in (1, 2, 3, 8, 9):
+        words[r] = words[0]
+    words[2500] = words[0]                                              # and one more copy far away (another slot)
+    q = rng.random((500, 352)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[7] = words[0] + 1e-4 * rng.random(352).astype(np.float32)
+    q[8] = words[0]
+    host, cb = _cb(pkg, gpu, words)
+    ctx.timers_enable(True)
+    try:
+        for k in (1, 2, 3, 4):
+            idx, dist = pkg.capi.knn(ctx, cb, 0, T(q, dev), k)
+            gi, gd = idx.cpu().numpy(), dist.cpu().numpy()
+            nfq, nfi = _knn_flagged(ctx)
+            widx, wdist = ora.knn(0, words, q, k)
+            assert np.array_equal(gi, widx) and np.array_equal(gd, wdist)
+            assert 1 <= nfq <= 8 and nfi >= 1, (nfq, nfi)              # the construction really exercised the few-items path
+    finally:
+        ctx.timers_enable(False)
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16x3", "f32"])
+@pytest.mark.parametrize("scale", [1.0, 1e-30, 3e-6, 250.0, 1e20])
+def test_knn_candidate_modes_and_magnitudes(pkg, gpu, ora, mode, scale, monkeypatch):
+    """All three squared-L2 candidate kernels (f16 default, bf16x3, exact f32) must return the oracle's answer for descriptors of any
+    magnitude: the f16 image is rescaled by a power of two, tiny and huge values may neither underflow nor overflow it silently."""
+    _, dev = gpu
+    monkeypatch.setenv("ISMHIP_KNN_MODE", mode)
+    ctx = pkg.capi.Ctx(0)                                               # the mode is read when a context is created
+    rng = np.random.default_rng(17)
+    words = (rng.random((2000, 100)) ** 4).astype(np.float32)           # wide dynamic range inside each descriptor
+    q = (words[rng.integers(0, 2000, 400)] + 0.02 * rng.random((400, 100))).astype(np.float32)
+    q[:50] = (rng.random((50, 100)) ** 4).astype(np.float32)
+    words = (words * np.float32(scale)).astype(np.float32); q = (q * np.float32(scale)).astype(np.float32)
+    off = np.arange(len(words) + 1, dtype=np.uint32)
+    cb = pkg.capi.Codebook(ctx, words, off, np.zeros((len(words), 3), np.float32), np.zeros(len(words), np.uint32),
+                           np.zeros(len(words), np.uint32), 1, np.ones(1, np.float32))
+    ctx.timers_enable(True)
+    for k in (1, 3):
+        idx, dist = pkg.capi.knn(ctx, cb, 0, T(q, dev), k)
+        gi, gd = idx.cpu().numpy(), dist.cpu().numpy()
+        widx, wdist = ora.knn(0, words, q, k)
+        assert np.array_equal(gi, widx)
+        assert np.array_equal(gd, wdist)
+    if scale in (1.0, 250.0):                                            # ordinary magnitudes must not lean on the exact scan
+        assert _knn_flagged(ctx)[0] <= 40, _knn_flagged(ctx)
+
+
+def test_knn_f16_query_with_outlier_magnitude(pkg, gpu, ora):
+    """One query 1e6 times larger than the rest sets the batch's f16 scale; the small queries lose precision in the f16 image
+    (absolute error term of the bound) and must be caught by the proof, a query with inf must not poison the others."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(3)
+    words = rng.random((1500, 64)).astype(np.float32)
+    q = (words[rng.integers(0, 1500, 200)] + 0.01 * rng.random((200, 64))).astype(np.float32)
+    q[5] *= 1e6
+    host, cb = _cb(pkg, gpu, words)
+    idx, dist = pkg.capi.knn(ctx, cb, 0, T(q, dev), 2)
+    widx, wdist = ora.knn(0, words, q, 2)
+    assert np.array_equal(idx.cpu().numpy(), widx) and np.array_equal(dist.cpu().numpy(), wdist)
+    q[9, 3] = np.inf
+    idx, dist = pkg.capi.knn(ctx, cb, 0, T(q, dev), 1)
+    widx, wdist = ora.knn(0, words, q, 1)
+    ok = np.arange(200) != 9
+    assert np.array_equal(idx.cpu().numpy()[ok], widx[ok]) and np.array_equal(dist.cpu().numpy()[ok], wdist[ok])
+
+
 def test_knn_ties_kat_and_ratio(pkg, gpu, ora):
     ctx, dev = gpu
     k = KAT["knn_ties"]

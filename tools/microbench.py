@@ -35,7 +35,7 @@ if "knn" in args.what:
     ctx.sync()
     name = "knn_l2_mfma" if args.metric == 0 else "knn_chi2"
     ms, cnt = ctx.timer(name); ms_all, _ = ctx.timer("knn"); ms_fb, _ = ctx.timer("knn_fallback")
-    print(f"knn_fallback {ms_fb/cnt:.3f} ms/launch")
+    print(f"knn_fallback {ms_fb/cnt:.3f} ms/launch; flagged queries {int(ctx.timer('knn_flagged_queries')[0])} slot items {int(ctx.timer('knn_flagged_items')[0])} (last launch)")
     flop = 2.0 * args.nq * n * args.dim
     print(f"knn metric={args.metric} nq={args.nq} words={n} dim={args.dim}: {name} {ms/cnt:.3f} ms/launch = {flop/(ms/cnt*1e-3)/1e12:.1f} TFLOP/s (2NqNcD); whole call {ms_all/cnt:.3f} ms")
 
