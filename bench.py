@@ -9,8 +9,9 @@ path's one exchange: an all-gather of the per-object class-score records (RCCL).
 value = objects processed by all ranks / max-over-ranks time of the K timed steps.
 
 The JSON line also carries
-  roofline      : the dominant kernel (k_knn_l2_mfma, MFMA-bound): algorithmic flop per launch / mean launch time, measured
-                  with HIP events on the stream the kernel runs on (ismhip timers), vs the dense FP32-MFMA peak
+  roofline      : the dominant kernel (k_knn_l2_ring, the f16-MFMA candidate stage of the exact kNN, MFMA-bound): algorithmic
+                  flop per launch (2 * queries * codewords * 352) / mean launch time, measured with HIP events on the stream
+                  the kernel runs on (ismhip timers), vs the dense F16/BF16 MFMA peak
   roofline_shot : descriptor extraction (k_shot<false>, HBM-bound, gather model bytes of SURVEY.md §8d)
   cpu_baseline  : the CPU oracle (kind "port": the reference itself cannot be built here) timed on this host's cores on a
                   bounded sample of the same workload; checker/baseline only, never on the measured path.
@@ -27,7 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (ISMHIP_KNN_MODE=f32)
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (v_mfma_f32_32x32x16_f16)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -142,9 +144,17 @@ def main():
         ms_knn = tm["knn_l2_mfma"][0] / tm["knn_l2_mfma"][1]
         flop = 2.0 * nq_per_launch * n_words * cfg.dim
         ach = flop / (ms_knn * 1e-3) / 1e12
-        roofline = {"kernel": "k_knn_l2_mfma", "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                    "flop_per_launch": flop, "ms_per_launch": round(ms_knn, 4)}
+        knn_mode = os.environ.get("ISMHIP_KNN_MODE", "f16")
+        # f16: one MFMA per product -> executed = algorithmic flop; bf16x3 executes 3x the algorithmic flop, priced as executed
+        kname, peak, mult = {"f16": ("k_knn_l2_ring", PEAK_F16_MFMA_TFLOPS, 1.0),
+                             "bf16x3": ("k_knn_l2_mfma16<bf16x3>", PEAK_F16_MFMA_TFLOPS, 3.0),
+                             "f32": ("k_knn_l2_mfma", PEAK_FP32_MFMA_TFLOPS, 1.0)}.get(knn_mode, ("k_knn_l2_ring", PEAK_F16_MFMA_TFLOPS, 1.0))
+        ach *= mult
+        roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 3), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "flop_per_launch": flop * mult, "ms_per_launch": round(ms_knn, 4),
+                    "note": "candidate stage of the exact kNN: 16-bit MFMA scores rank the codewords, every returned neighbour is "
+                            "re-ranked with the exact f32 FLANN functor and proven (see DESIGN.md)"}
         ms_shot = tm["shot352"][0] / max(1, tm["shot352"][1])
         bytes_shot = m_sum * 24.0 + nkp * (12 + 36 + 352 * 4)
         gbs = bytes_shot / (ms_shot * 1e-3) / 1e9
@@ -180,6 +190,7 @@ def main():
             "metric": "objects/sec classified (ModelNet10-like, SHOT-352)", "value": round(n_objects / dt, 3), "unit": "objects/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "results are the exact f32 values of the reference's functors; the kNN candidate filter runs on f16 MFMA",
             "config": {"workload": "configs[1]: ModelNet10-like test objects, 16384 pts, 1024 uniform keypoints/object, SHOT-352 "
                                    "(Radius 0.4, LRF 0.3), exact kNN K=1 squared-L2, mean-shift bandwidth 0.6",
                        "objects_per_step_per_gpu": B, "points_per_object": args.points, "keypoints_per_object": args.keypoints,

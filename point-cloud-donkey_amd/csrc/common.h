@@ -53,6 +53,7 @@ struct ismhip_codebook {
     unsigned short* words_bf16_hi = nullptr;   // [n_words_pad * dim_pad] RN_bf16(word)            (one allocation holds hi then lo)
     unsigned short* words_bf16_lo = nullptr;   // [n_words_pad * dim_pad] RN_bf16(word - hi)
     unsigned short* words_f16 = nullptr;       // [n_words_pad * dim_pad] RN_f16(word * f16_scale)  (same allocation)
+    int ld16 = 0;                    // row stride (halves) of the 16-bit images: dim rounded up to 64, zero padded
     float f16_scale = 1.f;           // power of two: largest |element| * f16_scale in [2^13, 2^14)
     float max_norm2 = 0.f;           // max squared norm over the real rows (bounds the fp32 contraction error of kNN)
     float* word_weight = nullptr;    // [n_words]
@@ -92,6 +93,9 @@ struct ismhip_ctx {
     std::vector<ismhip_cloud*> cloud_pool;
     uint32_t knn_stats[2] = {0, 0};   // last ismhip_knn: {queries, (query,slot) items} sent to the exact fallback (valid with timers on, after a sync)
     bool knn_small_tile = false; // env ISMHIP_KNN_TILE128=1: keep the bf16x3 kernel on its 128x128 tile (A/B runs)
+    int knn_dbg = 0;             // env ISMHIP_KNN_DBG: timing experiments on k_knn_l2_ring (1 no epilogue, 2 no MFMA, 3 no DMA); results invalid
+    bool knn_no_ring = false;    // env ISMHIP_KNN_NORING=1: f16 candidates by the register-staged kernel instead of the LDS-DMA ring (A/B runs)
+    bool knn_kb32 = false;       // env ISMHIP_KNN_KB32=1: f16 candidates with 32-deep LDS slices instead of 64 (A/B runs)
     int knn_mode = 0;            // env ISMHIP_KNN_MODE = f16 (0, default) | bf16x3 (1) | f32 (2): squared-L2 candidate kernel (A/B runs, tests)
 };
 

@@ -215,7 +215,6 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
 // adversarial (all-positive, large-norm) data.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
-#define KB_ROW 32        // halves per LDS row (one 32-k slice); rows are 64 B, 16-byte segments XOR-swizzled by (row>>2)&3
 
 __device__ __forceinline__ u16 f32_to_bf16_rn(float x) {
     const unsigned u = __float_as_uint(x);
@@ -289,24 +288,32 @@ __global__ void k_to_f16(const float* __restrict__ src, int n, int dim, int ld, 
 //            hold the true neighbours; k_knn_rerank recomputes every surviving candidate with the exact functor and proves the
 //            result with the rigorous bound of this kernel's error, so the answer stays exact at a third of the MFMA work.
 //            out_scale = -2 / (codebook scale * query scale) is read from device memory (the query scale is found on device).
-template <int T, int WR, int WC, int MI, int NI, int NTERM>
-__global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_bf16x3(const u16* __restrict__ wh, const u16* __restrict__ wl,
-                                                          const float* __restrict__ word_norm, int n_tiles_m, int dim_pad,
+// KB = halves per LDS row = k-depth of one staged slice (32 or 64). A 64-deep slice moves whole 128-byte lines per codeword /
+// query row: with 32-deep slices every line is fetched twice (the halves are used one slice apart and a slice's lines exceed L1).
+// 16-byte segments of a row are XOR-swizzled with row bits so that both the staging stores and the fragment reads (32 rows x one
+// segment per half-wave) are bank-conflict free: 64-B rows by (row>>2)&3, 128-B rows by (row>>1)&7.
+// ld = row stride (halves) of the 16-bit images, a multiple of 64 (zero padded); k_steps = ceil(dim / 16) MFMA k-steps carry data.
+template <int T, int WR, int WC, int MI, int NI, int NTERM, int KB>
+__global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_mfma16(const u16* __restrict__ wh, const u16* __restrict__ wl,
+                                                          const float* __restrict__ word_norm, int n_tiles_m, int ld, int k_steps,
                                                           const u16* __restrict__ qh, const u16* __restrict__ ql, int nq,
                                                           const float* __restrict__ out_scale,
                                                           int tiles_per_split, int n_splits,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
                                                           float* __restrict__ cand_bound, int bound_stride) {
     constexpr int BM = WR * MI * 32, BN = WC * NI * 32, NT = WR * WC * 64;
-    constexpr int RPP = NT / 4;                       // rows staged per pass (4 threads x 16 B per 64-B row)
+    constexpr int SEGS = KB / 8;                      // 16-byte segments per row
+    constexpr int KS = KB / 16;                       // MFMA k-steps per slice
+    constexpr int RPP = NT / SEGS;                    // rows staged per pass (SEGS threads x 16 B per row)
     constexpr int PA = BM / RPP, PB = BN / RPP;       // passes per array
+    constexpr int SW_SH = KB == 64 ? 1 : 2, SW_MASK = SEGS - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
     constexpr bool X3 = NTERM == 3;
-    u16* sAh = (u16*)knn_smem;                        // [2][BM*32]
-    u16* sAl = sAh + (X3 ? 2 * BM * KB_ROW : 0);
-    u16* sBh = sAl + 2 * BM * KB_ROW;                 // [2][BN*32]
-    u16* sBl = sBh + (X3 ? 2 * BN * KB_ROW : 0);
-    float* sCn = (float*)(sBl + 2 * BN * KB_ROW);     // [BM]
+    u16* sAh = (u16*)knn_smem;                        // [2][BM*KB]
+    u16* sAl = sAh + (X3 ? 2 * BM * KB : 0);
+    u16* sBh = sAl + 2 * BM * KB;                     // [2][BN*KB]
+    u16* sBl = sBh + (X3 ? 2 * BN * KB : 0);
+    float* sCn = (float*)(sBl + 2 * BN * KB);         // [BM]
     const float oscale = NTERM == 1 ? out_scale[0] : -2.0f;
 
     const int tid = threadIdx.x;
@@ -319,33 +326,22 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_bf16x3(const u16* __
     if (qtile * BN >= nq) return;
     const int mt0 = split * tiles_per_split;
     const int mt1 = min(n_tiles_m, mt0 + tiles_per_split);
-    const int nk = dim_pad / KNN_BK;
+    const int nk = (k_steps + KS - 1) / KS;
 
-    const int srow = tid >> 2, sseg = tid & 3;
-    int sdst[(PA > PB ? PA : PB)];
-#pragma unroll
-    for (int p = 0; p < (PA > PB ? PA : PB); ++p) {
-        const int row = srow + p * RPP;
-        sdst[p] = row * KB_ROW + ((sseg ^ ((row >> 2) & 3)) << 3);
-    }
-    const size_t qoff = (size_t)(qtile * BN + srow) * dim_pad + sseg * 8;
-
-    int offA[MI][2], offB[NI][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int seg = ks * 2 + h;
-#pragma unroll
-        for (int m = 0; m < MI; ++m) { const int ra = wr * (MI * 32) + m * 32 + r; offA[m][ks] = ra * KB_ROW + ((seg ^ ((ra >> 2) & 3)) << 3); }
-#pragma unroll
-        for (int n = 0; n < NI; ++n) { const int rb = wc * (NI * 32) + n * 32 + r; offB[n][ks] = rb * KB_ROW + ((seg ^ ((rb >> 2) & 3)) << 3); }
-    }
+    // staging: thread -> (row srow + p*RPP, segment sseg); RPP is a multiple of 16, so the swizzle term is the same for every pass
+    const int srow = tid / SEGS, sseg = tid % SEGS;
+    const int sdst0 = srow * KB + ((sseg ^ ((srow >> SW_SH) & SW_MASK)) << 3);
+    const size_t qoff = (size_t)(qtile * BN + srow) * ld + sseg * 8;
+    // fragment reads: lane -> row r of a 32-row MFMA tile, k-segment (ks*2 + h) of the slice; tile bases are compile-time offsets
+    const int fragA = (wr * (MI * 32) + r) * KB, fragB = (wc * (NI * 32) + r) * KB;
+    const int fsw = (r >> SW_SH) & SW_MASK;
 
     TopT<T + 1> top[NI];
 #pragma unroll
     for (int n = 0; n < NI; ++n) top[n].init();
 
     for (int mt = mt0; mt < mt1; ++mt) {
-        const size_t aoff = (size_t)(mt * BM + srow) * dim_pad + sseg * 8;
+        const size_t aoff = (size_t)(mt * BM + srow) * ld + sseg * 8;
         f32x16 acc[MI][NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -354,65 +350,69 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_bf16x3(const u16* __
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-        f32x4 gah[PA], gal[PA], gbh[PB], gbl[PB];
+        f32x4 gah[PA], gal[X3 ? PA : 1], gbh[PB], gbl[X3 ? PB : 1];
 #pragma unroll
-        for (int p = 0; p < PA; ++p) { gah[p] = *(const f32x4*)(wh + aoff + (size_t)p * RPP * dim_pad); if constexpr (X3) gal[p] = *(const f32x4*)(wl + aoff + (size_t)p * RPP * dim_pad); }
+        for (int p = 0; p < PA; ++p) { gah[p] = *(const f32x4*)(wh + aoff + (size_t)p * RPP * ld); if constexpr (X3) gal[p] = *(const f32x4*)(wl + aoff + (size_t)p * RPP * ld); }
 #pragma unroll
-        for (int p = 0; p < PB; ++p) { gbh[p] = *(const f32x4*)(qh + qoff + (size_t)p * RPP * dim_pad); if constexpr (X3) gbl[p] = *(const f32x4*)(ql + qoff + (size_t)p * RPP * dim_pad); }
+        for (int p = 0; p < PB; ++p) { gbh[p] = *(const f32x4*)(qh + qoff + (size_t)p * RPP * ld); if constexpr (X3) gbl[p] = *(const f32x4*)(ql + qoff + (size_t)p * RPP * ld); }
         __syncthreads();                                   // previous tile's epilogue has finished reading sCn / LDS
         for (int i = tid; i < BM; i += NT) sCn[i] = word_norm[mt * BM + i];
 #pragma unroll
-        for (int p = 0; p < PA; ++p) { *(f32x4*)(&sAh[sdst[p]]) = gah[p]; if constexpr (X3) *(f32x4*)(&sAl[sdst[p]]) = gal[p]; }
+        for (int p = 0; p < PA; ++p) { *(f32x4*)(&sAh[sdst0 + p * RPP * KB]) = gah[p]; if constexpr (X3) *(f32x4*)(&sAl[sdst0 + p * RPP * KB]) = gal[p]; }
 #pragma unroll
-        for (int p = 0; p < PB; ++p) { *(f32x4*)(&sBh[sdst[p]]) = gbh[p]; if constexpr (X3) *(f32x4*)(&sBl[sdst[p]]) = gbl[p]; }
+        for (int p = 0; p < PB; ++p) { *(f32x4*)(&sBh[sdst0 + p * RPP * KB]) = gbh[p]; if constexpr (X3) *(f32x4*)(&sBl[sdst0 + p * RPP * KB]) = gbl[p]; }
         __syncthreads();
 
         for (int kc = 0; kc < nk; ++kc) {
             const int cur = kc & 1;
             if (kc + 1 < nk) {
-                const int ko = (kc + 1) * KNN_BK;
+                const int ko = (kc + 1) * KB;
 #pragma unroll
-                for (int p = 0; p < PA; ++p) { gah[p] = *(const f32x4*)(wh + aoff + (size_t)p * RPP * dim_pad + ko); if constexpr (X3) gal[p] = *(const f32x4*)(wl + aoff + (size_t)p * RPP * dim_pad + ko); }
+                for (int p = 0; p < PA; ++p) { gah[p] = *(const f32x4*)(wh + aoff + (size_t)p * RPP * ld + ko); if constexpr (X3) gal[p] = *(const f32x4*)(wl + aoff + (size_t)p * RPP * ld + ko); }
 #pragma unroll
-                for (int p = 0; p < PB; ++p) { gbh[p] = *(const f32x4*)(qh + qoff + (size_t)p * RPP * dim_pad + ko); if constexpr (X3) gbl[p] = *(const f32x4*)(ql + qoff + (size_t)p * RPP * dim_pad + ko); }
+                for (int p = 0; p < PB; ++p) { gbh[p] = *(const f32x4*)(qh + qoff + (size_t)p * RPP * ld + ko); if constexpr (X3) gbl[p] = *(const f32x4*)(ql + qoff + (size_t)p * RPP * ld + ko); }
             }
-            const u16* cAh = sAh + cur * BM * KB_ROW; const u16* cAl = sAl + cur * BM * KB_ROW;
-            const u16* cBh = sBh + cur * BN * KB_ROW; const u16* cBl = sBl + cur * BN * KB_ROW;
+            const u16* cAh = sAh + cur * BM * KB + fragA; const u16* cAl = sAl + cur * BM * KB + fragA;
+            const u16* cBh = sBh + cur * BN * KB + fragB; const u16* cBl = sBl + cur * BN * KB + fragB;
+            const int ks_n = min(KS, k_steps - kc * KS);   // the last slice may be partly padding: skip its all-zero k-steps
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if constexpr (X3) {
-                    bf16x8 bh[NI], bl[NI];
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks < ks_n) {
+                    const int so = ((ks * 2 + h) ^ fsw) << 3;
+                    if constexpr (X3) {
+                        bf16x8 bh[NI], bl[NI];
 #pragma unroll
-                    for (int n = 0; n < NI; ++n) { bh[n] = *(const bf16x8*)(cBh + offB[n][ks]); bl[n] = *(const bf16x8*)(cBl + offB[n][ks]); }
+                        for (int n = 0; n < NI; ++n) { bh[n] = *(const bf16x8*)(cBh + n * 32 * KB + so); bl[n] = *(const bf16x8*)(cBl + n * 32 * KB + so); }
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const bf16x8 ah = *(const bf16x8*)(cAh + offA[mi][ks]);
-                        const bf16x8 al = *(const bf16x8*)(cAl + offA[mi][ks]);
+                        for (int mi = 0; mi < MI; ++mi) {
+                            const bf16x8 ah = *(const bf16x8*)(cAh + mi * 32 * KB + so);
+                            const bf16x8 al = *(const bf16x8*)(cAl + mi * 32 * KB + so);
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) {
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+                            for (int ni = 0; ni < NI; ++ni) {
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+                            }
                         }
-                    }
-                } else {
-                    f16x8 bh[NI];
+                    } else {
+                        f16x8 bh[NI];
 #pragma unroll
-                    for (int n = 0; n < NI; ++n) bh[n] = *(const f16x8*)(cBh + offB[n][ks]);
+                        for (int n = 0; n < NI; ++n) bh[n] = *(const f16x8*)(cBh + n * 32 * KB + so);
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const f16x8 ah = *(const f16x8*)(cAh + offA[mi][ks]);
+                        for (int mi = 0; mi < MI; ++mi) {
+                            const f16x8 ah = *(const f16x8*)(cAh + mi * 32 * KB + so);
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+                            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+                        }
                     }
                 }
             }
             if (kc + 1 < nk) {
                 const int nx = cur ^ 1;
 #pragma unroll
-                for (int p = 0; p < PA; ++p) { *(f32x4*)(&sAh[nx * BM * KB_ROW + sdst[p]]) = gah[p]; if constexpr (X3) *(f32x4*)(&sAl[nx * BM * KB_ROW + sdst[p]]) = gal[p]; }
+                for (int p = 0; p < PA; ++p) { *(f32x4*)(&sAh[nx * BM * KB + sdst0 + p * RPP * KB]) = gah[p]; if constexpr (X3) *(f32x4*)(&sAl[nx * BM * KB + sdst0 + p * RPP * KB]) = gal[p]; }
 #pragma unroll
-                for (int p = 0; p < PB; ++p) { *(f32x4*)(&sBh[nx * BN * KB_ROW + sdst[p]]) = gbh[p]; if constexpr (X3) *(f32x4*)(&sBl[nx * BN * KB_ROW + sdst[p]]) = gbl[p]; }
+                for (int p = 0; p < PB; ++p) { *(f32x4*)(&sBh[nx * BN * KB + sdst0 + p * RPP * KB]) = gbh[p]; if constexpr (X3) *(f32x4*)(&sBl[nx * BN * KB + sdst0 + p * RPP * KB]) = gbl[p]; }
             }
             __syncthreads();
         }
@@ -448,6 +448,177 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_bf16x3(const u16* __
                 cand_val[o] = top[ni].v[t]; cand_idx[o] = top[ni].i[t];
             }
             cand_bound[(size_t)qi * bound_stride + split * (2 * WR) + (wr * 2 + h)] = top[ni].v[T];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f16 candidates, LDS-DMA ring (the default squared-L2 kernel for big launches)
+// ---------------------------------------------------------------------------------------------
+// k_knn_l2_mfma16 moves every slice global -> VGPR -> LDS between two barriers, so load latency, the staging stores, the
+// fragment reads and the MFMAs of a workgroup run one after the other (measured: 29 % MFMA-busy at 20 GB/s per CU). Here the
+// slices are written straight into LDS by global_load_lds_dwordx4 (no staging registers, no ds_write), three slices ahead of the
+// one being multiplied, in a ring of four 32 KB stages; the prefetch stream runs across codeword tiles, so it also covers the
+// top-T epilogue. One barrier per slice: "my DMAs for slice g have landed" (s_waitcnt vmcnt) + s_barrier makes slice g visible
+// to all waves and proves that everybody is done reading the stage that the next DMA overwrites.
+//   tile 256 codewords x 256 queries, 8 waves (2 x 4), wave = 128 x 64 = 4 x 2 MFMA tiles of 32x32x16 f16
+//   stage: rows 0..255 = codeword slice, 256..511 = query slice, 64 B per row (32 k), 16-B segments XOR-swizzled by (row>>2)&3;
+//          a DMA instruction fills 1 KB = 16 rows in LDS order, so the swizzle is applied to the SOURCE address of each lane
+//   |c|^2 of a tile arrives the same way (one 1 KB DMA by wave 0) in a ring of four tiles
+#define RG_BM 256
+#define RG_BN 256
+#define RG_KB 32
+#define RG_STAGES 4
+#define RG_STAGE_HALVES ((RG_BM + RG_BN) * RG_KB)
+__device__ __forceinline__ void lds_dma16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+}
+template <int T, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ wh, const float* __restrict__ word_norm, int n_tiles_m, int ld, int k_steps,
+                                                        const u16* __restrict__ qh, int nq, const float* __restrict__ out_scale,
+                                                        int tiles_per_split, int n_splits,
+                                                        float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
+                                                        float* __restrict__ cand_bound, int bound_stride) {
+    constexpr int WR = 2, WC = 4, MI = 4, NI = 2, KB = RG_KB, BM = RG_BM, BN = RG_BN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
+    u16* ring = (u16*)knn_smem;                                        // [RG_STAGES][512 rows][32 halves]
+    float* sCn = (float*)(ring + RG_STAGES * RG_STAGE_HALVES);        // [4][BM]
+    const float oscale = out_scale[0];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wr = wv / WC, wc = wv % WC;
+    const int r = lane & 31, h = lane >> 5;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = jx % n_splits, qtile = (jx / n_splits) * 8 + xcd;
+    if (qtile * BN >= nq) return;
+    const int mt0 = split * tiles_per_split;
+    const int n_t = min(n_tiles_m, mt0 + tiles_per_split) - mt0;
+    if (n_t <= 0) return;
+    const int nk = (k_steps + 1) / 2;                                  // 32-deep slices
+    const int G = n_t * nk;                                            // slices in this workgroup's stream
+
+    // DMA role of this wave: waves 0-3 bring codeword rows, 4-7 query rows; 4 instructions x 16 rows per slice
+    const bool dma_a = wv < 4;
+    const int drow = (wv & 3) * 64 + (lane >> 2);                      // row inside the 256-row half (+ j*16)
+    const int dseg = (lane & 3) ^ ((drow >> 2) & 3);                   // logical segment that lands in physical slot lane&3
+    const u16* dsrc = dma_a ? wh + ((size_t)mt0 * BM + drow) * ld + dseg * 8
+                            : qh + ((size_t)qtile * BN + drow) * ld + dseg * 8;
+    const int ddst = (dma_a ? 0 : BM * KB) + (wv & 3) * 64 * KB;       // halves, wave-uniform
+    const size_t tile_stride = dma_a ? (size_t)BM * ld : 0;
+    int pt = 0, pkc = 0, pg = 0;                                       // prefetch cursor (tile, slice, stream index), clamped at the end
+    auto issue = [&]() {
+        u16* st = ring + (pg & (RG_STAGES - 1)) * RG_STAGE_HALVES + ddst;
+        if (wv == 0 && pkc == 0) lds_dma16(word_norm + (size_t)(mt0 + pt) * BM + lane * 4, sCn + (pt & 3) * BM);
+        const u16* sp = dsrc + pt * tile_stride + pkc * KB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16(sp + (size_t)j * 16 * ld, st + j * 16 * KB);
+        ++pg;
+        if (pt * nk + pkc + 1 < G) { if (++pkc == nk) { pkc = 0; ++pt; } }   // past the end: re-load the last slice into a free stage
+    };
+    issue(); issue(); issue();
+
+    const int fragA = (wr * (MI * 32) + r) * KB, fragB = BM * KB + (wc * (NI * 32) + r) * KB;
+    const int fsw = (r >> 2) & 3;
+    const int so0 = ((0 + h) ^ fsw) << 3, so1 = ((2 + h) ^ fsw) << 3;    // k-step 0 / 1 segment of this lane
+    TopT<T + 1> top[NI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n) top[n].init();
+    // The accumulators start at |c|^2 / out_scale instead of 0 (out_scale = -2/(s_q s_c) < 0, a power of two up to the factor -2,
+    // so the product is exact): after the last slice acc = (|c|^2 - 2 c.q) / out_scale, and ranking the scores ascending is ranking
+    // acc DESCENDING. The epilogue is then one compare per value against the lane's current threshold; TopT keeps -acc.
+    const float inv_os = 1.0f / oscale;
+    float thr[NI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n) thr[n] = -__builtin_inff();
+    f32x16 acc[MI][NI];
+
+    // Software pipeline. Step g multiplies slice g: its k-step-0 fragments (set X) were read during step g-1, its k-step-1
+    // fragments (set Y) are read while the k-step-0 MFMAs run, and slice g+1's k-step-0 fragments while the k-step-1 MFMAs run, so
+    // no MFMA waits on an LDS round trip. The barrier at the top of step g therefore publishes slice g+1 (one ahead of the
+    // multiply): this wave's DMAs up to slice g+1 have landed (only slice g+2's four may be in flight), its own LDS reads are
+    // done (lgkmcnt(0)), and after the barrier nobody reads slice g-1's stage any more -- which is where slice g+3 is sent.
+    f16x8 xa[MI], xb[NI], ya[MI], yb[NI];
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");      // slice 0 (and the first |c|^2 row) landed
+    {
+        const float* cnp = sCn + wr * (MI * 32) + 4 * h;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float c0 = cnp[mi * 32 + (e & 3) + 8 * (e >> 2)] * inv_os;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni][e] = c0;
+            }
+#pragma unroll
+        for (int n = 0; n < NI; ++n) xb[n] = *(const f16x8*)(ring + fragB + n * 32 * KB + so0);
+#pragma unroll
+        for (int m = 0; m < MI; ++m) xa[m] = *(const f16x8*)(ring + fragA + m * 32 * KB + so0);
+    }
+    int t = 0, kc = 0;
+    for (int g = 0; g < G; ++g) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!(DBG & 4) || g < 4) issue();                               // slice g+3 -> the stage of slice g-1
+        const u16* st = ring + (g & (RG_STAGES - 1)) * RG_STAGE_HALVES;
+        const u16* sn = ring + ((g + 1) & (RG_STAGES - 1)) * RG_STAGE_HALVES;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) yb[n] = *(const f16x8*)(st + fragB + n * 32 * KB + so1);
+#pragma unroll
+        for (int m = 0; m < MI; ++m) ya[m] = *(const f16x8*)(st + fragA + m * 32 * KB + so1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                if (!(DBG & 2)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[mi], xb[ni], acc[mi][ni], 0, 0, 0);
+                else acc[mi][ni][0] += (float)xa[mi][0] * (float)xb[ni][0];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NI; ++n) xb[n] = *(const f16x8*)(sn + fragB + n * 32 * KB + so0);
+#pragma unroll
+        for (int m = 0; m < MI; ++m) xa[m] = *(const f16x8*)(sn + fragA + m * 32 * KB + so0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                if (!(DBG & 2)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ya[mi], yb[ni], acc[mi][ni], 0, 0, 0);
+                else acc[mi][ni][0] += (float)ya[mi][0] * (float)yb[ni][0];
+        __builtin_amdgcn_sched_barrier(0);
+        if (++kc == nk) {
+            // epilogue of tile t. A lane inserts ~ (T+1)/n of the n values it has seen, so after the first tiles a 64-lane vector of
+            // values rarely holds an insertion: each vector is tested at wave level and the insertion code runs only for those.
+            // The accumulator is re-armed with the next tile's |c|^2 row, which landed with slice g+1.
+            const int row0 = (mt0 + t) * BM + wr * (MI * 32) + 4 * h;
+            const float* cnp = sCn + ((t + 1) & 3) * BM + wr * (MI * 32) + 4 * h;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float c0 = cnp[mi * 32 + (e & 3) + 8 * (e >> 2)] * inv_os;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const float a = acc[mi][ni][e];
+                        if (DBG & 1) { if (e == 0) top[ni].v[0] += a; }
+                        else if (__any(a > thr[ni])) { top[ni].push(-a, row0 + mi * 32 + (e & 3) + 8 * (e >> 2)); thr[ni] = -top[ni].v[T]; }
+                        acc[mi][ni][e] = c0;
+                    }
+                }
+            kc = 0; ++t;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the clamped re-loads past the end: LDS must be quiet before exit
+    // candidates: slot = split*(2*WR*T) + (wr*2 + h)*T + t; bound slot = split*(2*WR) + wr*2 + h
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int qi = qtile * BN + wc * (NI * 32) + ni * 32 + r;
+        if (qi < nq) {
+#pragma unroll
+            for (int tt = 0; tt < T; ++tt) {                            // v = -acc, score = out_scale * acc (+inf stays +inf: out_scale < 0)
+                const size_t o = (size_t)qi * cand_stride + split * (2 * WR * T) + (wr * 2 + h) * T + tt;
+                cand_val[o] = -oscale * top[ni].v[tt]; cand_idx[o] = top[ni].i[tt];
+            }
+            cand_bound[(size_t)qi * bound_stride + split * (2 * WR) + (wr * 2 + h)] = -oscale * top[ni].v[T];
         }
     }
 }
@@ -579,11 +750,12 @@ __device__ __forceinline__ float flann_chi2(const float* a, const float* b, int 
 
 struct VerifyParams {
     float ku;         // 1.01 * K * u : relative error bound of a K-term fp32 functor sum (u = 2^-24)
-    float dot_rel;    // bound on |approx(q.c) - q.c| / (|q||c|) of the candidate kernel (f32 fma chain: ku; bf16x3: see k_knn_l2_bf16x3)
+    float dot_rel;    // bound on |approx(q.c) - q.c| / (|q||c|) of the candidate kernel (f32 fma chain: ku; bf16x3: see k_knn_l2_mfma16)
     float cmax2;      // max |c|^2 over the codebook (L2 only)
     float dabs_c;     // f16 candidates: worst-case absolute error of one codebook element (2^-14 / scale), else 0
     const float* dabs_q;   // f16 candidates: the same for the query batch (device scalar), else nullptr
     float sqrt_dim;   // sqrt(dim_pad)
+    float cn_acc;     // k_knn_l2_ring adds |c|^2 through the accumulator: extra 1.01 (K+1) 2^-23 |c|max^2 on the score, else 0
 };
 // absolute part of the candidate kernel's dot-product error: sum |dq_i c_i| + |q_i dc_i| + |dq_i dc_i| with |dq_i| <= dq, |dc_i| <= dc
 __device__ __forceinline__ float knn_abs_err(const VerifyParams& vp, float qn2) {
@@ -627,7 +799,7 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
     }
     float slack;
     if (metric == ISMHIP_METRIC_CHI2) slack = 4.f * (((float)dim_pad + 8.f) * KNN_U + vp.ku) * fabsf(kth);
-    else slack = 2.f * (17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2)) + 4.f * vp.ku * (qn2 + fabsf(kth) + vp.cmax2);
+    else slack = 2.f * (17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2) + vp.cn_acc * vp.cmax2) + 4.f * vp.ku * (qn2 + fabsf(kth) + vp.cmax2);
     unsigned long long key = ~0ull;
     if (id >= 0 && !(av > kth + slack)) {     // NaN scores are never skipped
         const float* wp = words + (size_t)id * dim_pad;
@@ -660,14 +832,14 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
     // an inf or NaN in |q|^2, |c|max^2 or their product (or in the f16 scales), all of which make the error bound below non-finite.
     bool viol = false;
     const float eps_chk = metric == ISMHIP_METRIC_CHI2 ? qn2 + vp.cmax2
-                        : 17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2) + qn2;
+                        : 17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2) + vp.cn_acc * vp.cmax2 + qn2;
     if (lane < n_bound && (bnd != __builtin_inff() || !(eps_chk < __builtin_inff()))) {
         if (!have_k) viol = true;
         else if (metric == ISMHIP_METRIC_CHI2) {
             const float lo = bnd * (1.f - ((float)dim_pad + 8.f) * KNN_U) * (1.f - vp.ku);
             viol = !(dk < lo);
         } else {
-            const float eps_s = 17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2);
+            const float eps_s = 17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2) + vp.cn_acc * vp.cmax2;
             const float rhs = qn2 * (1.f - 16.f * KNN_U) + bnd - eps_s;
             viol = !(dk < rhs - vp.ku * fabsf(rhs) - 1e-37f);
         }
@@ -881,17 +1053,17 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     u16 *q_hi = nullptr, *q_lo = nullptr;
     if (use_lp) {
         const int nq_pad = (nq + BNq - 1) / BNq * BNq;
-        const size_t tot = (size_t)nq_pad * cb->dim_pad;
+        const size_t tot = (size_t)nq_pad * cb->ld16;
         q_hi = (u16*)ism_scratch(ctx, SCR_KNN_QSPLIT, tot * 2 * sizeof(u16));
         if (!q_hi) return ISMHIP_ERR_NOMEM;
         q_lo = q_hi + tot;
         if (mode == 0) {
             hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, qsc);
             ISM_CHECK_LAUNCH(ctx, "k_absmax");
-            hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->dim_pad, qsc, cb->f16_scale, q_hi);
+            hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->ld16, qsc, cb->f16_scale, q_hi);
             ISM_CHECK_LAUNCH(ctx, "k_to_f16");
         } else {
-            hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->dim_pad, q_hi, q_lo);
+            hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->ld16, q_hi, q_lo);
             ISM_CHECK_LAUNCH(ctx, "k_split_bf16");
         }
     }
@@ -903,18 +1075,50 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
             const u16* wh = mode == 0 ? cb->words_f16 : cb->words_bf16_hi;
             const u16* wl = mode == 0 ? nullptr : cb->words_bf16_lo;
             const int nterm = mode == 0 ? 1 : 3;
-            const size_t lds = (size_t)2 * (BM + BNq) * KB_ROW * sizeof(u16) * (nterm == 3 ? 2 : 1) + BM * sizeof(float);
-            const void* kern = big_tile ? (nterm == 3 ? (const void*)k_knn_l2_bf16x3<T, 2, 4, 4, 2, 3> : (const void*)k_knn_l2_bf16x3<T, 2, 4, 4, 2, 1>)
-                                        : (nterm == 3 ? (const void*)k_knn_l2_bf16x3<T, 2, 2, 2, 2, 3> : (const void*)k_knn_l2_bf16x3<T, 2, 2, 2, 2, 1>);
-            static bool attr[4] = {false, false, false, false};
-            const int ai = (big_tile ? 2 : 0) + (nterm == 3 ? 1 : 0);
+            const int kb = (nterm == 1 && !ctx->knn_kb32) ? 64 : 32;       // the two bf16x3 images only fit LDS with 32-deep slices
+            const size_t lds = (size_t)2 * (BM + BNq) * kb * sizeof(u16) * (nterm == 3 ? 2 : 1) + BM * sizeof(float);
+            const void* kern;
+            int ai;
+            if (big_tile) {
+                if (nterm == 3) { kern = (const void*)k_knn_l2_mfma16<T, 2, 4, 4, 2, 3, 32>; ai = 0; }
+                else if (kb == 64) { kern = (const void*)k_knn_l2_mfma16<T, 2, 4, 4, 2, 1, 64>; ai = 1; }
+                else { kern = (const void*)k_knn_l2_mfma16<T, 2, 4, 4, 2, 1, 32>; ai = 2; }
+            } else {
+                if (nterm == 3) { kern = (const void*)k_knn_l2_mfma16<T, 2, 2, 2, 2, 3, 32>; ai = 3; }
+                else if (kb == 64) { kern = (const void*)k_knn_l2_mfma16<T, 2, 2, 2, 2, 1, 64>; ai = 4; }
+                else { kern = (const void*)k_knn_l2_mfma16<T, 2, 2, 2, 2, 1, 32>; ai = 5; }
+            }
+            if (big_tile && nterm == 1 && !ctx->knn_no_ring) {
+                const void* rk = (const void*)k_knn_l2_ring<T, 0>;
+#ifdef ISM_KNN_DBG_VARIANTS
+                switch (ctx->knn_dbg) {
+                    case 1: rk = (const void*)k_knn_l2_ring<T, 1>; break;  case 3: rk = (const void*)k_knn_l2_ring<T, 3>; break;
+                    case 5: rk = (const void*)k_knn_l2_ring<T, 5>; break;  case 7: rk = (const void*)k_knn_l2_ring<T, 7>; break;
+                    case 9: rk = (const void*)k_knn_l2_ring<T, 9>; break;  case 13: rk = (const void*)k_knn_l2_ring<T, 13>; break;
+                    case 15: rk = (const void*)k_knn_l2_ring<T, 15>; break; case 11: rk = (const void*)k_knn_l2_ring<T, 11>; break;
+                    default: break;
+                }
+#endif
+                const size_t rlds = (size_t)RG_STAGES * RG_STAGE_HALVES * sizeof(u16) + 4 * RG_BM * sizeof(float);
+                static bool rattr = false;
+                if (ctx->knn_dbg) rattr = false;
+                if (!rattr) { ISM_HIP(ctx, hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds)); rattr = true; }
+                const float* word_norm = cb->word_norm; const float* osc = (const float*)(qsc + 1);
+                int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
+                const u16* qh_ = q_hi;
+                void* rargs[] = {&wh, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb};
+                ISM_HIP(ctx, hipLaunchKernel(rk, grid, dim3(512), rargs, rlds, ctx->stream));
+                ISM_CHECK_LAUNCH(ctx, "k_knn_l2_ring");
+            } else {
+            static bool attr[6] = {false, false, false, false, false, false};
             if (!attr[ai]) { ISM_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr[ai] = true; }
             const float* word_norm = cb->word_norm; const float* osc = (const float*)(qsc + 1);
-            int n_tiles_m = cb->n_words_pad / BM, dim_pad = cb->dim_pad, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
+            int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
             const u16* qh_ = q_hi; const u16* ql_ = q_lo;
-            void* args[] = {&wh, &wl, &word_norm, &n_tiles_m, &dim_pad, &qh_, &ql_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb};
+            void* args[] = {&wh, &wl, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &ql_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb};
             ISM_HIP(ctx, hipLaunchKernel(kern, grid, dim3(big_tile ? 512 : 256), args, lds, ctx->stream));
-            ISM_CHECK_LAUNCH(ctx, "k_knn_l2_bf16x3");
+            ISM_CHECK_LAUNCH(ctx, "k_knn_l2_mfma16");
+            }
         } else if (metric == ISMHIP_METRIC_L2SQ) {
             const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
             hipLaunchKernelGGL(k_knn_l2_mfma<T>, dim3(8 * ((n_qt + 7) / 8) * n_splits), dim3(256), 0, ctx->stream, cb->words, cb->word_norm,
@@ -937,6 +1141,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     vp.dabs_c = mode == 0 ? 6.103515625e-05f / cb->f16_scale : 0.f;
     vp.dabs_q = mode == 0 ? (const float*)(qsc + 2) : nullptr;
     vp.sqrt_dim = sqrtf((float)cb->dim_pad);
+    vp.cn_acc = mode == 0 ? 1.01f * (float)(cb->dim_pad + 1) * 1.1920929e-07f : 0.f;
     hipLaunchKernelGGL(k_knn_rerank, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
                        qq, nq, ldq, metric, cand_idx, cand_val, n_cand, n_cand, cand_bound, n_bound, vp, k, idx_out, dist_out, flag_count, qrec, items);
     ISM_CHECK_LAUNCH(ctx, "k_knn_rerank");
@@ -956,20 +1161,21 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
 
 }  // namespace
 
-// bf16 hi/lo and scaled-f16 images of the codebook for k_knn_l2_bf16x3 (called once from ismhip_codebook_create)
+// bf16 hi/lo and scaled-f16 images of the codebook for k_knn_l2_mfma16 (called once from ismhip_codebook_create)
 int ism_codebook_split_bf16(ismhip_ctx* ctx, ismhip_codebook* cb, uint32_t absmax_bits) {
-    const size_t tot = (size_t)cb->n_words_pad * cb->dim_pad;
+    cb->ld16 = (cb->dim + 63) / 64 * 64;
+    const size_t tot = (size_t)cb->n_words_pad * cb->ld16;
     if (hipMalloc((void**)&cb->words_bf16_hi, tot * 3 * sizeof(u16) + 16) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook bf16/f16 images");
     cb->words_bf16_lo = cb->words_bf16_hi + tot;
     cb->words_f16 = cb->words_bf16_lo + tot;
     uint32_t* sc = (uint32_t*)(cb->words_f16 + tot);
     hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, cb->words, cb->n_words_pad, cb->dim_pad, cb->dim_pad,
-                       cb->n_words_pad, cb->dim_pad, cb->words_bf16_hi, cb->words_bf16_lo);
+                       cb->n_words_pad, cb->ld16, cb->words_bf16_hi, cb->words_bf16_lo);
     ISM_CHECK_LAUNCH(ctx, "k_split_bf16");
     cb->f16_scale = f16_scale_for(absmax_bits);
     ISM_HIP(ctx, hipMemcpyAsync(sc, &absmax_bits, 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, cb->words, cb->n_words_pad, cb->dim_pad, cb->dim_pad,
-                       cb->n_words_pad, cb->dim_pad, sc, 1.0f, cb->words_f16);
+                       cb->n_words_pad, cb->ld16, sc, 1.0f, cb->words_f16);
     ISM_CHECK_LAUNCH(ctx, "k_to_f16");
     ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));       // absmax_bits is a stack variable of the caller's frame
     return ISMHIP_OK;

@@ -350,6 +350,25 @@ def test_knn_f16_query_with_outlier_magnitude(pkg, gpu, ora):
     assert np.array_equal(idx.cpu().numpy()[ok], widx[ok]) and np.array_equal(dist.cpu().numpy()[ok], wdist[ok])
 
 
+@pytest.mark.parametrize("dim", [352, 33, 16, 100])
+def test_knn_large_launch_matches_oracle(pkg, gpu, ora, dim):
+    """>= 4096 queries against >= 4096 codewords selects the 256x256 LDS-DMA ring kernel (k_knn_l2_ring); ragged sizes leave a partly
+    empty last query tile and padded codeword rows, dim 33 a half-empty last slice, dim 16 a single slice per tile."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(dim)
+    n_words, nq = 4096 + 300, 4096 + 77
+    centres = rng.random((64, dim)).astype(np.float32)
+    words = (centres[rng.integers(0, 64, n_words)] + 0.05 * rng.random((n_words, dim))).astype(np.float32)
+    q = (centres[rng.integers(0, 64, nq)] + 0.05 * rng.random((nq, dim))).astype(np.float32)
+    q[:10] = words[-10:]
+    host, cb = _cb(pkg, gpu, words)
+    for k in (1, 3):
+        idx, dist = pkg.capi.knn(ctx, cb, 0, T(q, dev), k)
+        widx, wdist = ora.knn(0, words, q, k)
+        assert np.array_equal(idx.cpu().numpy(), widx)
+        assert np.array_equal(dist.cpu().numpy(), wdist)
+
+
 def test_knn_ties_kat_and_ratio(pkg, gpu, ora):
     ctx, dev = gpu
     k = KAT["knn_ties"]
