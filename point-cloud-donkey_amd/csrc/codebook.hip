@@ -201,7 +201,7 @@ int ismhip_codebook_destroy(ismhip_ctx* ctx, ismhip_codebook* cb) {
     if (!cb) return ISMHIP_ERR_INVALID;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     void* ptrs[] = {cb->words, cb->word_norm, cb->word_weight, cb->vote_off, cb->vote_xyz, cb->vote_weight, cb->vote_class_weight,
-                    cb->vote_class, cb->vote_instance, cb->vote_bbox_quat, cb->vote_bbox_size, cb->class_sigma, cb->word_class, cb->words_bf16_hi};
+                    cb->vote_class, cb->vote_instance, cb->vote_bbox_quat, cb->vote_bbox_size, cb->class_sigma, cb->word_class, cb->words_bf16_hi, cb->words_f16t};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete cb;
     return ISMHIP_OK;

@@ -53,6 +53,7 @@ struct ismhip_codebook {
     unsigned short* words_bf16_hi = nullptr;   // [n_words_pad * dim_pad] RN_bf16(word)            (one allocation holds hi then lo)
     unsigned short* words_bf16_lo = nullptr;   // [n_words_pad * dim_pad] RN_bf16(word - hi)
     unsigned short* words_f16 = nullptr;       // [n_words_pad * dim_pad] RN_f16(word * f16_scale)  (same allocation)
+    unsigned short* words_f16t = nullptr;      // the f16 image in k_knn_l2_ring's streaming layout (k_to_f16_tiled), own allocation
     int ld16 = 0;                    // row stride (halves) of the 16-bit images: dim rounded up to 64, zero padded
     float f16_scale = 1.f;           // power of two: largest |element| * f16_scale in [2^13, 2^14)
     float max_norm2 = 0.f;           // max squared norm over the real rows (bounds the fp32 contraction error of kNN)
@@ -93,6 +94,7 @@ struct ismhip_ctx {
     std::vector<ismhip_cloud*> cloud_pool;
     uint32_t knn_stats[2] = {0, 0};   // last ismhip_knn: {queries, (query,slot) items} sent to the exact fallback (valid with timers on, after a sync)
     bool knn_small_tile = false; // env ISMHIP_KNN_TILE128=1: keep the bf16x3 kernel on its 128x128 tile (A/B runs)
+    int knn_t = 0;               // env ISMHIP_KNN_T = 2 | 3: candidates kept per slot (default 4 on the 16-bit paths); fewer = cheaper epilogue, more unproven slots
     int knn_dbg = 0;             // env ISMHIP_KNN_DBG: timing experiments on k_knn_l2_ring (1 no epilogue, 2 no MFMA, 3 no DMA); results invalid
     bool knn_no_ring = false;    // env ISMHIP_KNN_NORING=1: f16 candidates by the register-staged kernel instead of the LDS-DMA ring (A/B runs)
     bool knn_kb32 = false;       // env ISMHIP_KNN_KB32=1: f16 candidates with 32-deep LDS slices instead of 64 (A/B runs)
@@ -225,5 +227,50 @@ __device__ __forceinline__ bool row_cells(const GridMeta& m, const CellRange& cr
     lo = l < cr.lo[0] ? cr.lo[0] : l;
     hi = h > cr.hi[0] ? cr.hi[0] : h;
     return lo <= hi;
+}
+
+// ---- flattened ball traversal ---------------------------------------------------------------------------------------------
+// A ball query touches (2R/cell+1)^2 cell rows; walking them one after the other costs, per row, the chord arithmetic on all 64
+// lanes, two dependent cell_start loads and a mostly half-empty wave of points. Here the lanes first take one row EACH (chord,
+// start, length: one round trip for up to 64 rows), a wave prefix sum lays the rows end to end, and the wave then sweeps the
+// concatenated candidate list 64 at a time with every lane busy; a lane finds its row by walking a cursor through the prefix
+// table (rows are visited in order, so the cursor only moves forward). f(i, valid) gets the object-local sorted point index.
+struct WaveRows {
+    uint32_t off[65];      // exclusive prefix of the row lengths
+    uint32_t start[64];    // first sorted index of each row
+};
+template <class F>
+__device__ __forceinline__ void ball_for_each(const GridMeta& m, const uint32_t* __restrict__ cs, const CellRange& cr,
+                                              float qx, float qy, float qz, float r, int lane, WaveRows& wr, F&& f) {
+    const int ny = cr.hi[1] - cr.lo[1] + 1, nrows = ny * (cr.hi[2] - cr.lo[2] + 1);
+    for (int r0 = 0; r0 < nrows; r0 += 64) {
+        const int j = r0 + lane;
+        uint32_t s = 0, len = 0;
+        if (j < nrows) {
+            const int gz = cr.lo[2] + j / ny, gy = cr.lo[1] + j % ny;
+            int xl, xh;
+            if (row_cells(m, cr, gy, gz, qx, qy, qz, r, xl, xh)) {
+                const int rb = (gz * m.dim[1] + gy) * m.dim[0];
+                s = cs[rb + xl]; len = cs[rb + xh + 1] - s;
+            }
+        }
+        uint32_t inc = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += t; }
+        wr.off[lane + 1] = inc; wr.start[lane] = s;
+        if (lane == 0) wr.off[0] = 0;
+        const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+        uint32_t jc = 0;                                     // LDS traffic of one wave is ordered: no barrier needed
+        for (uint32_t c = 0; c < total; c += 64) {
+            const uint32_t idx = c + lane;
+            const bool v = idx < total;
+            uint32_t i = 0;
+            if (v) {
+                while (idx >= wr.off[jc + 1]) ++jc;
+                i = wr.start[jc] + (idx - wr.off[jc]);
+            }
+            f(i, v);
+        }
+    }
 }
 #endif

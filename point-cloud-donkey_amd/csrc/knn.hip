@@ -277,6 +277,30 @@ __global__ void k_to_f16(const float* __restrict__ src, int n, int dim, int ld, 
     dst[i] = __builtin_bit_cast(u16, hx);
 }
 
+// The same conversion into the layout k_knn_l2_ring streams: [256-row tile][32-k slice][row][4 x 16-byte segments], i.e. every
+// (tile, slice) is one contiguous 16 KB block that already is the LDS image (segment p of row r holds logical segment
+// p ^ ((r>>2)&3)). A DMA instruction then copies 1 KB of consecutive, fully used 128-byte lines; with a row-major image each
+// 32-k slice touches only half of every line and the other half is fetched again one slice later.
+__global__ void k_to_f16_tiled(const float* __restrict__ src, int n, int dim, int ld, int n_tiles, int nk,
+                               uint32_t* __restrict__ sc, float other_scale, u16* __restrict__ dst) {
+    const float s = f16_scale_for(sc[0]);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        ((float*)sc)[1] = -2.0f / (s * other_scale);
+        ((float*)sc)[2] = (sc[0] >> 23) == 255u ? __builtin_inff() : 6.103515625e-05f / s;
+    }
+    if (i >= (size_t)n_tiles * nk * 8192) return;
+    const int e = (int)(i & 7), p = (int)((i >> 3) & 3), r = (int)((i >> 5) & 255);
+    const size_t blk = i >> 13;
+    const int kc = (int)(blk % nk); const size_t tile = blk / nk;
+    const int col = kc * 32 + ((p ^ ((r >> 2) & 3)) << 3) + e;
+    const size_t row = tile * 256 + r;
+    float x = 0.f;
+    if (row < (size_t)n && col < dim) x = src[row * ld + col];
+    const _Float16 hx = (_Float16)(x * s);
+    dst[i] = __builtin_bit_cast(u16, hx);
+}
+
 // Tile geometry is a template: WR x WC waves, each MI x NI MFMA tiles of 32x32 -> BM = WR*MI*32 codeword rows by
 // BN = WC*NI*32 queries per workgroup. The CU's load path delivers ~30 B/clk from L2 (MI355X_MICROARCH 'Indexed rows'), a
 // 128x128 tile needs 32 KB per 32-k slice for 768 MFMA cycles per wave and is load-bound; the 256x256 tile (8 waves, 64 KB per
@@ -486,7 +510,8 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
     const float oscale = out_scale[0];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform values must live in SGPRs (DMA bases, ring pointers)
     const int wr = wv / WC, wc = wv % WC;
     const int r = lane & 31, h = lane >> 5;
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
@@ -498,21 +523,23 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
     const int nk = (k_steps + 1) / 2;                                  // 32-deep slices
     const int G = n_t * nk;                                            // slices in this workgroup's stream
 
-    // DMA role of this wave: waves 0-3 bring codeword rows, 4-7 query rows; 4 instructions x 16 rows per slice
+    // DMA role of this wave: waves 0-3 bring codeword rows, 4-7 query rows; 4 instructions x 16 rows per slice. The address of a
+    // lane is a wave-uniform 64-bit base (tile, slice, instruction: scalar arithmetic) plus a per-lane byte offset that never changes.
+    // (the 16-bit images are stored tile by tile, slice by slice, already swizzled: see k_to_f16_tiled -- a slice of a tile is a
+    // linear 16 KB copy; ld is unused here)
     const bool dma_a = wv < 4;
-    const int drow = (wv & 3) * 64 + (lane >> 2);                      // row inside the 256-row half (+ j*16)
-    const int dseg = (lane & 3) ^ ((drow >> 2) & 3);                   // logical segment that lands in physical slot lane&3
-    const u16* dsrc = dma_a ? wh + ((size_t)mt0 * BM + drow) * ld + dseg * 8
-                            : qh + ((size_t)qtile * BN + drow) * ld + dseg * 8;
+    const unsigned lane_off = (unsigned)(lane * 16);                   // bytes
+    const char* dbase = (dma_a ? (const char*)(wh + (size_t)mt0 * nk * (BM * KB)) : (const char*)(qh + (size_t)qtile * nk * (BN * KB)))
+                        + (wv & 3) * (64 * KB * 2);
     const int ddst = (dma_a ? 0 : BM * KB) + (wv & 3) * 64 * KB;       // halves, wave-uniform
-    const size_t tile_stride = dma_a ? (size_t)BM * ld : 0;
+    const size_t tile_stride = dma_a ? (size_t)nk * (BM * KB * 2) : 0; // bytes
     int pt = 0, pkc = 0, pg = 0;                                       // prefetch cursor (tile, slice, stream index), clamped at the end
     auto issue = [&]() {
         u16* st = ring + (pg & (RG_STAGES - 1)) * RG_STAGE_HALVES + ddst;
         if (wv == 0 && pkc == 0) lds_dma16(word_norm + (size_t)(mt0 + pt) * BM + lane * 4, sCn + (pt & 3) * BM);
-        const u16* sp = dsrc + pt * tile_stride + pkc * KB;
+        const char* sp = dbase + pt * tile_stride + (size_t)pkc * (BM * KB * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_dma16(sp + (size_t)j * 16 * ld, st + j * 16 * KB);
+        for (int j = 0; j < 4; ++j) lds_dma16(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);
         ++pg;
         if (pt * nk + pkc + 1 < G) { if (++pkc == nk) { pkc = 0; ++pt; } }   // past the end: re-load the last slice into a free stage
     };
@@ -1022,6 +1049,8 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     const int BM = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BM) : CHI_B;
     const int BNq = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BN) : CHI_B;
     const int wr_rows = big_tile ? 128 : 64;
+    const bool use_ring = big_tile && mode == 0 && !ctx->knn_no_ring && cb->words_f16t;
+    const int ring_nk = ((cb->dim + 15) / 16 + 1) / 2;                 // 32-k slices per row in the tiled images
     if (metric == ISMHIP_METRIC_L2SQ) {
         const int n_qt = (nq + BNq - 1) / BNq, n_mt = cb->n_words_pad / BM;
         const int max_s = 64 / (4 * T);
@@ -1053,14 +1082,15 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     u16 *q_hi = nullptr, *q_lo = nullptr;
     if (use_lp) {
         const int nq_pad = (nq + BNq - 1) / BNq * BNq;
-        const size_t tot = (size_t)nq_pad * cb->ld16;
+        const size_t tot = use_ring ? (size_t)(nq_pad / 256) * ring_nk * 8192 : (size_t)nq_pad * cb->ld16;
         q_hi = (u16*)ism_scratch(ctx, SCR_KNN_QSPLIT, tot * 2 * sizeof(u16));
         if (!q_hi) return ISMHIP_ERR_NOMEM;
         q_lo = q_hi + tot;
         if (mode == 0) {
             hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, qsc);
             ISM_CHECK_LAUNCH(ctx, "k_absmax");
-            hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->ld16, qsc, cb->f16_scale, q_hi);
+            if (use_ring) hipLaunchKernelGGL(k_to_f16_tiled, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad / 256, ring_nk, qsc, cb->f16_scale, q_hi);
+            else hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->ld16, qsc, cb->f16_scale, q_hi);
             ISM_CHECK_LAUNCH(ctx, "k_to_f16");
         } else {
             hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->ld16, q_hi, q_lo);
@@ -1088,7 +1118,8 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 else if (kb == 64) { kern = (const void*)k_knn_l2_mfma16<T, 2, 2, 2, 2, 1, 64>; ai = 4; }
                 else { kern = (const void*)k_knn_l2_mfma16<T, 2, 2, 2, 2, 1, 32>; ai = 5; }
             }
-            if (big_tile && nterm == 1 && !ctx->knn_no_ring) {
+            if (use_ring) {
+                wh = cb->words_f16t;
                 const void* rk = (const void*)k_knn_l2_ring<T, 0>;
 #ifdef ISM_KNN_DBG_VARIANTS
                 switch (ctx->knn_dbg) {
@@ -1177,6 +1208,14 @@ int ism_codebook_split_bf16(ismhip_ctx* ctx, ismhip_codebook* cb, uint32_t absma
     hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, cb->words, cb->n_words_pad, cb->dim_pad, cb->dim_pad,
                        cb->n_words_pad, cb->ld16, sc, 1.0f, cb->words_f16);
     ISM_CHECK_LAUNCH(ctx, "k_to_f16");
+    {
+        const int nk = ((cb->dim + 15) / 16 + 1) / 2, n_tiles = cb->n_words_pad / 256;
+        const size_t tt = (size_t)n_tiles * nk * 8192;
+        if (hipMalloc((void**)&cb->words_f16t, tt * sizeof(u16)) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook tiled f16 image");
+        hipLaunchKernelGGL(k_to_f16_tiled, dim3((unsigned)((tt + 255) / 256)), dim3(256), 0, ctx->stream, cb->words, cb->n_words_pad, cb->dim_pad, cb->dim_pad,
+                           n_tiles, nk, sc, 1.0f, cb->words_f16t);
+        ISM_CHECK_LAUNCH(ctx, "k_to_f16_tiled");
+    }
     ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));       // absmax_bits is a stack variable of the caller's frame
     return ISMHIP_OK;
 }
@@ -1193,6 +1232,8 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
     // T = candidates kept per slot. The bf16x3 candidate scores carry a larger error bound, so more are kept (T = 4): the proof
     // then compares against the 5th best of every slot and almost never fails.
     const bool wide = k > 2 || (metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi && ctx->knn_mode <= 1);
+    if (ctx->knn_t == 3 && k <= 3) return run_knn<3>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
+    if (ctx->knn_t == 2 && k <= 2) return run_knn<2>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
     return wide ? run_knn<4>(ctx, cb, metric, nq, q, k, idx_out, dist_out) : run_knn<2>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
 }
 

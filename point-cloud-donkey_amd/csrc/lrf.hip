@@ -70,25 +70,20 @@ __global__ __launch_bounds__(256) void k_lrf_cov(CloudView cv, const uint32_t* _
     double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0, sum = 0;
     int valid = 0;
     const double rd = (double)radius;
-    for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
-        for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
-            int xl, xh;
-            if (!row_cells(m, cr, gy, gz, cx, cy, cz, radius, xl, xh)) continue;
-            const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-            const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
-            for (uint32_t t = s + lane; t < e; t += 64) {
-                const float px = cv.sx[base + t], py = cv.sy[base + t], pz = cv.sz[base + t];
-                const float d2 = sqdist3(px, py, pz, cx, cy, cz);
-                if (d2 < r2 && !(px == cx && py == cy && pz == cz)) {
-                    const double vx = (double)(px - cx), vy = (double)(py - cy), vz = (double)(pz - cz);
-                    const double w = rd - sqrt_f32_as_f64(d2);
-                    const double wx = w * vx, wy = w * vy, wz = w * vz;
-                    c00 = fma(wx, vx, c00); c01 = fma(wx, vy, c01); c02 = fma(wx, vz, c02);
-                    c11 = fma(wy, vy, c11); c12 = fma(wy, vz, c12); c22 = fma(wz, vz, c22);
-                    sum += w; valid++;
-                }
-            }
+    __shared__ WaveRows s_rows[4];
+    ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6], [&](uint32_t t, bool v) {
+        if (!v) return;
+        const float px = cv.sx[base + t], py = cv.sy[base + t], pz = cv.sz[base + t];
+        const float d2 = sqdist3(px, py, pz, cx, cy, cz);
+        if (d2 < r2 && !(px == cx && py == cy && pz == cz)) {
+            const double vx = (double)(px - cx), vy = (double)(py - cy), vz = (double)(pz - cz);
+            const double w = rd - sqrt_f32_as_f64(d2);
+            const double wx = w * vx, wy = w * vy, wz = w * vz;
+            c00 = fma(wx, vx, c00); c01 = fma(wx, vy, c01); c02 = fma(wx, vz, c02);
+            c11 = fma(wy, vy, c11); c12 = fma(wy, vz, c12); c22 = fma(wz, vz, c22);
+            sum += w; valid++;
         }
+    });
     c00 = wave_sum_d(c00); c01 = wave_sum_d(c01); c02 = wave_sum_d(c02);
     c11 = wave_sum_d(c11); c12 = wave_sum_d(c12); c22 = wave_sum_d(c22);
     sum = wave_sum_d(sum); valid = wave_sum_i(valid);
@@ -142,23 +137,17 @@ __global__ __launch_bounds__(256, 4) void k_lrf_sign(CloudView cv, const uint32_
     CellRange cr;
     ball_cells(m, cx, cy, cz, radius, cr);
     int plusT = 0, plusN = 0;
-    for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
-        for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
-            int xl, xh;
-            if (!row_cells(m, cr, gy, gz, cx, cy, cz, radius, xl, xh)) continue;
-            const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-            const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
-#pragma unroll 1
-            for (uint32_t t = s + lane; t < e; t += 64) {
-                const float px = cv.sx[base + t], py = cv.sy[base + t], pz = cv.sz[base + t];
-                const float d2 = sqdist3(px, py, pz, cx, cy, cz);
-                if (d2 < r2 && !(px == cx && py == cy && pz == cz)) {
-                    const double vx = (double)(px - cx), vy = (double)(py - cy), vz = (double)(pz - cz);
-                    if (vx * v1[0] + vy * v1[1] + vz * v1[2] >= 0) plusT++;
-                    if (vx * v3[0] + vy * v3[1] + vz * v3[2] >= 0) plusN++;
-                }
-            }
+    __shared__ WaveRows s_rows[4];
+    ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6], [&](uint32_t t, bool v) {
+        if (!v) return;
+        const float px = cv.sx[base + t], py = cv.sy[base + t], pz = cv.sz[base + t];
+        const float d2 = sqdist3(px, py, pz, cx, cy, cz);
+        if (d2 < r2 && !(px == cx && py == cy && pz == cz)) {
+            const double vx = (double)(px - cx), vy = (double)(py - cy), vz = (double)(pz - cz);
+            if (vx * v1[0] + vy * v1[1] + vz * v1[2] >= 0) plusT++;
+            if (vx * v3[0] + vy * v3[1] + vz * v3[2] >= 0) plusN++;
         }
+    });
     plusT = 2 * wave_sum_i(plusT) - valid;
     plusN = 2 * wave_sum_i(plusN) - valid;
     if (plusT < 0) { v1[0] = -v1[0]; v1[1] = -v1[1]; v1[2] = -v1[2]; }
@@ -184,6 +173,7 @@ __global__ __launch_bounds__(128) void k_lrf_tie(CloudView cv, const float* __re
                                                  uint32_t key_cap) {
     // keys live in LDS when the neighbourhood fits (the common case), else in a per-wave global scratch row
     __shared__ unsigned long long s_keys[2][TIE_LDS_KEYS];
+    __shared__ WaveRows s_rows[2];
     const int lane = lane_id();
     const uint32_t gw = blockIdx.x * 2 + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * 2;
@@ -203,29 +193,21 @@ __global__ __launch_bounds__(128) void k_lrf_tie(CloudView cv, const float* __re
         unsigned long long* mykeys = r.valid <= TIE_LDS_KEYS ? s_keys[threadIdx.x >> 6] : gkeys;
         const uint32_t cap = r.valid <= TIE_LDS_KEYS ? (uint32_t)TIE_LDS_KEYS : key_cap;
         uint32_t n = 0;
-        for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
-            for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
-                int xl, xh;
-                if (!row_cells(m, cr, gy, gz, cx, cy, cz, radius, xl, xh)) continue;
-                const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-                const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
-                for (uint32_t t0 = s; t0 < e; t0 += 64) {
-                    const uint32_t i = t0 + lane;
-                    bool pass = false; float d2 = 0.f; uint32_t orig = 0;
-                    if (i < e) {
-                        const float px = cv.sx[base + i], py = cv.sy[base + i], pz = cv.sz[base + i];
-                        d2 = sqdist3(px, py, pz, cx, cy, cz);
-                        pass = d2 < r2 && !(px == cx && py == cy && pz == cz);
-                        orig = cv.sorig[base + i];
-                    }
-                    const unsigned long long mask = __ballot(pass);
-                    if (pass) {
-                        const uint32_t pos = n + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (pos < cap) mykeys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | orig;
-                    }
-                    n += __popcll(mask);
-                }
+        ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6], [&](uint32_t i, bool v) {
+            bool pass = false; float d2 = 0.f; uint32_t orig = 0;
+            if (v) {
+                const float px = cv.sx[base + i], py = cv.sy[base + i], pz = cv.sz[base + i];
+                d2 = sqdist3(px, py, pz, cx, cy, cz);
+                pass = d2 < r2 && !(px == cx && py == cy && pz == cz);
+                orig = cv.sorig[base + i];
             }
+            const unsigned long long mask = __ballot(pass);
+            if (pass) {
+                const uint32_t pos = n + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < cap) mykeys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | orig;
+            }
+            n += __popcll(mask);
+        });
         __threadfence_block();
         if (n > cap) n = cap;   // cannot happen: n == r.valid <= cap
         // rank selection by bitwise bisection: the element of rank t is the largest v with #(key < v) <= t.

@@ -48,6 +48,7 @@ struct ShotSmem {
     shot_bin_t hist[4][D];
     float4 qd[4][128];       // dx, dy, dz, d2 of queued neighbours
     uint32_t qi[4][128];     // sorted index of queued neighbours
+    WaveRows rows[4];
 };
 __device__ __forceinline__ void shot_dep(shot_bin_t* hist, int bin, float v) {
     atomicAdd(&hist[bin], (shot_bin_t)__float2uint_rn(v * SHOT_FIX_SCALE));
@@ -197,40 +198,32 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
     const uint32_t* cs = a.cell_start + (size_t)o * ISM_GRID_STRIDE;
     const uint32_t base = a.pt_off[o];
     uint32_t qn = 0, total = 0;
-    for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
-        for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
-            int xl, xh;
-            if (!row_cells(m, cr, gy, gz, cx, cy, cz, a.radius, xl, xh)) continue;
-            const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-            const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
-            for (uint32_t t0 = s; t0 < e; t0 += 64) {
-                const uint32_t i = t0 + lane;
-                bool pass = false; float dx = 0, dy = 0, dz = 0, d2 = 0;
-                if (i < e) {
-                    const float px = a.sx[base + i], py = a.sy[base + i], pz = a.sz[base + i];
-                    d2 = sqdist3(px, py, pz, cx, cy, cz);
-                    dx = px - cx; dy = py - cy; dz = pz - cz;
-                    pass = d2 < a.r2;
-                }
-                const unsigned long long mask = __ballot(pass);
-                if (pass) {
-                    const uint32_t pos = qn + __popcll(mask & ((1ull << lane) - 1ull));
-                    sm.qd[wv][pos] = make_float4(dx, dy, dz, d2); sm.qi[wv][pos] = base + i;
-                }
-                const uint32_t c = __popcll(mask);
-                qn += c; total += c;
-                if (qn >= 64) {
-                    // a full wave of neighbours (LDS traffic of one wave is ordered; no barrier needed)
-                    const float4 e = sm.qd[wv][lane];
-                    shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][lane], e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq, LRef, aRef, bRef);
-                    const uint32_t rem = qn - 64;
-                    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f); uint32_t t0i = 0;
-                    if ((uint32_t)lane < rem) { t4 = sm.qd[wv][64 + lane]; t0i = sm.qi[wv][64 + lane]; }
-                    if ((uint32_t)lane < rem) { sm.qd[wv][lane] = t4; sm.qi[wv][lane] = t0i; }
-                    qn = rem;
-                }
-            }
+    ball_for_each(m, cs, cr, cx, cy, cz, a.radius, lane, sm.rows[wv], [&](uint32_t i, bool v) {
+        bool pass = false; float dx = 0, dy = 0, dz = 0, d2 = 0;
+        if (v) {
+            const float px = a.sx[base + i], py = a.sy[base + i], pz = a.sz[base + i];
+            d2 = sqdist3(px, py, pz, cx, cy, cz);
+            dx = px - cx; dy = py - cy; dz = pz - cz;
+            pass = d2 < a.r2;
         }
+        const unsigned long long mask = __ballot(pass);
+        if (pass) {
+            const uint32_t pos = qn + __popcll(mask & ((1ull << lane) - 1ull));
+            sm.qd[wv][pos] = make_float4(dx, dy, dz, d2); sm.qi[wv][pos] = base + i;
+        }
+        const uint32_t c = __popcll(mask);
+        qn += c; total += c;
+        if (qn >= 64) {
+            // a full wave of neighbours (LDS traffic of one wave is ordered; no barrier needed)
+            const float4 e = sm.qd[wv][lane];
+            shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][lane], e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq, LRef, aRef, bRef);
+            const uint32_t rem = qn - 64;
+            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f); uint32_t t0i = 0;
+            if ((uint32_t)lane < rem) { t4 = sm.qd[wv][64 + lane]; t0i = sm.qi[wv][64 + lane]; }
+            if ((uint32_t)lane < rem) { sm.qd[wv][lane] = t4; sm.qi[wv][lane] = t0i; }
+            qn = rem;
+        }
+    });
     if (qn > 0) {
         const bool act = (uint32_t)lane < qn;
         const float4 e = sm.qd[wv][lane];
