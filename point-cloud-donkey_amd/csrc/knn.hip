@@ -507,6 +507,7 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
     u16* ring = (u16*)knn_smem;                                        // [RG_STAGES][512 rows][32 halves]
     float* sCn = (float*)(ring + RG_STAGES * RG_STAGE_HALVES);        // [4][BM]
+    float* sThr = sCn + 4 * BM;                                        // [8 waves][NI][64]: thresholds published to the partner wave
     const float oscale = out_scale[0];
 
     const int tid = threadIdx.x;
@@ -559,6 +560,14 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
 #pragma unroll
     for (int n = 0; n < NI; ++n) thr[n] = -__builtin_inff();
     f32x16 acc[MI][NI];
+    // A query column is scanned by four lane slots of this workgroup (two accumulator halves h x two wave rows wr). A value that
+    // is not better than the (T+1)-th best of ANY of them can be dropped by all of them: thresholds only rise, every dropped value
+    // is <= the threshold its lane used at the time <= that lane's final threshold, which is what the slot reports as its bound.
+    // Sharing cuts the insertions ~4x. Partner half: one cross-lane read per tile; partner wave: a 4-byte slot in LDS (a stale
+    // value is only a lower, i.e. more conservative, threshold).
+    const int pw = (1 - wr) * WC + wc;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) sThr[(wv * NI + n) * 64 + lane] = -__builtin_inff();
 
     // Software pipeline. Step g multiplies slice g: its k-step-0 fragments (set X) were read during step g-1, its k-step-1
     // fragments (set Y) are read while the k-step-0 MFMAs run, and slice g+1's k-step-0 fragments while the k-step-1 MFMAs run, so
@@ -593,6 +602,7 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
 #pragma unroll
         for (int m = 0; m < MI; ++m) ya[m] = *(const f16x8*)(st + fragA + m * 32 * KB + so1);
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -611,6 +621,7 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
             for (int ni = 0; ni < NI; ++ni)
                 if (!(DBG & 2)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ya[mi], yb[ni], acc[mi][ni], 0, 0, 0);
                 else acc[mi][ni][0] += (float)ya[mi][0] * (float)yb[ni][0];
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (++kc == nk) {
             // epilogue of tile t. A lane inserts ~ (T+1)/n of the n values it has seen, so after the first tiles a 64-lane vector of
@@ -627,10 +638,19 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
                     for (int ni = 0; ni < NI; ++ni) {
                         const float a = acc[mi][ni][e];
                         if (DBG & 1) { if (e == 0) top[ni].v[0] += a; }
-                        else if (__any(a > thr[ni])) { top[ni].push(-a, row0 + mi * 32 + (e & 3) + 8 * (e >> 2)); thr[ni] = -top[ni].v[T]; }
+                        else if (__builtin_expect(__any(a > thr[ni]), 0)) {
+                            if (a > thr[ni]) top[ni].push(-a, row0 + mi * 32 + (e & 3) + 8 * (e >> 2));
+                            thr[ni] = fmaxf(thr[ni], -top[ni].v[T]);
+                        }
                         acc[mi][ni][e] = c0;
                     }
                 }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                float sh = fmaxf(thr[ni], __shfl_xor(thr[ni], 32, 64));
+                sThr[(wv * NI + ni) * 64 + lane] = sh;
+                thr[ni] = fmaxf(sh, sThr[(pw * NI + ni) * 64 + lane]);
+            }
             kc = 0; ++t;
         }
     }
@@ -645,7 +665,7 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
                 const size_t o = (size_t)qi * cand_stride + split * (2 * WR * T) + (wr * 2 + h) * T + tt;
                 cand_val[o] = -oscale * top[ni].v[tt]; cand_idx[o] = top[ni].i[tt];
             }
-            cand_bound[(size_t)qi * bound_stride + split * (2 * WR) + (wr * 2 + h)] = -oscale * top[ni].v[T];
+            cand_bound[(size_t)qi * bound_stride + split * (2 * WR) + (wr * 2 + h)] = oscale * thr[ni];   // the lane's final threshold
         }
     }
 }
@@ -1130,7 +1150,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     default: break;
                 }
 #endif
-                const size_t rlds = (size_t)RG_STAGES * RG_STAGE_HALVES * sizeof(u16) + 4 * RG_BM * sizeof(float);
+                const size_t rlds = (size_t)RG_STAGES * RG_STAGE_HALVES * sizeof(u16) + 4 * RG_BM * sizeof(float) + 8 * 2 * 64 * sizeof(float);
                 static bool rattr = false;
                 if (ctx->knn_dbg) rattr = false;
                 if (!rattr) { ISM_HIP(ctx, hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds)); rattr = true; }
