@@ -243,6 +243,18 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ void k_absmax(const float* __restrict__ src, int n, int dim, int ld, uint32_t* __restrict__ out_bits) {
     uint32_t m = 0u;
     const size_t tot = (size_t)n * dim;
+    if (ld == dim) {                                   // contiguous rows: a flat, 16-byte-wide sweep
+        const size_t n4 = tot >> 2;
+        const uint4* s4 = (const uint4*)src;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            const uint4 v = s4[i];
+            const uint32_t a = max(max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), max(v.z & 0x7fffffffu, v.w & 0x7fffffffu));
+            m = a > m ? a : m;
+        }
+        for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+            const uint32_t b = __float_as_uint(src[i]) & 0x7fffffffu; m = b > m ? b : m;
+        }
+    } else
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / dim), col = (int)(i % dim);
         const uint32_t b = __float_as_uint(src[(size_t)row * ld + col]) & 0x7fffffffu;
@@ -812,6 +824,39 @@ __device__ __forceinline__ float knn_abs_err(const VerifyParams& vp, float qn2) 
 }
 #define KNN_U 5.9604645e-08f
 
+// The FLANN functors evaluated by a whole wave, bit-identical to the scalar loops above. L2: the functor adds one 4-element
+// group sum ((d0^2 + d1^2) + d2^2) + d3^2 per step to the running result; the group sums are independent, so the lanes compute
+// them from coalesced 16-byte loads and only the chain of additions (dim/4 of them, from LDS) stays sequential. chi2: the
+// per-element terms are independent, the chain adds them one by one (a skipped term adds +0, which leaves the result unchanged).
+// Every lane returns the distance. sT: per-wave scratch of dim floats.
+__device__ __forceinline__ float wave_functor(int metric, const float* __restrict__ a, const float* __restrict__ b, int dim, int lane, float* sT) {
+    const int n4 = dim >> 2;
+    int n_terms;
+    if (metric == ISMHIP_METRIC_CHI2) {
+        for (int i = lane; i < dim; i += 64) {
+            const float x = a[i], y = b[i], sum = x + y, diff = x - y;
+            sT[i] = sum > 0 ? diff * diff / sum : 0.f;
+        }
+        n_terms = dim;
+    } else {
+        for (int g = lane; g < n4; g += 64) {
+            const f32x4 x = *(const f32x4*)(a + 4 * g), y = *(const f32x4*)(b + 4 * g);
+            const float d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2], d3 = x[3] - y[3];
+            sT[g] = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+        for (int i = 4 * n4 + lane; i < dim; i += 64) { const float d0 = a[i] - b[i]; sT[n4 + (i - 4 * n4)] = d0 * d0; }
+        n_terms = n4 + (dim - 4 * n4);
+    }
+    float result = 0.f;                      // LDS traffic of one wave is ordered: the stores above are visible to the loads below
+    int i = 0;
+    for (; i + 3 < n_terms; i += 4) {
+        const f32x4 v = *(const f32x4*)(sT + i);
+        result += v[0]; result += v[1]; result += v[2]; result += v[3];
+    }
+    for (; i < n_terms; ++i) result += sT[i];
+    return result;
+}
+
 __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ words, int dim, int dim_pad, int n_words,
                                                     const float* __restrict__ q, int nq, int ldq, int metric,
                                                     const int* __restrict__ cand_idx, const float* __restrict__ cand_val, int cand_stride, int n_cand,
@@ -848,11 +893,17 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
     if (metric == ISMHIP_METRIC_CHI2) slack = 4.f * (((float)dim_pad + 8.f) * KNN_U + vp.ku) * fabsf(kth);
     else slack = 2.f * (17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2) + vp.cn_acc * vp.cmax2) + 4.f * vp.ku * (qn2 + fabsf(kth) + vp.cmax2);
     unsigned long long key = ~0ull;
-    if (id >= 0 && !(av > kth + slack)) {     // NaN scores are never skipped
-        const float* wp = words + (size_t)id * dim_pad;
-        const float d = metric == ISMHIP_METRIC_CHI2 ? flann_chi2(qp, wp, dim) : flann_l2(qp, wp, dim);
-        // distances are >= 0 (or NaN); positive float bit patterns order like unsigned integers
-        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;
+    {
+        __shared__ __attribute__((aligned(16))) float s_terms[4][1344];
+        float* sT = s_terms[threadIdx.x >> 6];
+        unsigned long long need = __ballot(id >= 0 && !(av > kth + slack));     // NaN scores are never skipped
+        while (need) {
+            const int src = __ffsll((long long)need) - 1; need &= need - 1;
+            const int cid = __shfl(id, src, 64);
+            const float d = wave_functor(metric, qp, words + (size_t)cid * dim_pad, dim, lane, sT);
+            // distances are >= 0 (or NaN); positive float bit patterns order like unsigned integers
+            if (lane == src) key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;
+        }
     }
     // every bound slot (L2: split x 4 lane slots, chi2: split) holds the smallest approximate score that slot dropped
     float bnd = __builtin_inff();
@@ -919,7 +970,7 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
 __host__ __device__ inline uint32_t knn_fb_parts(uint32_t n_items) {
     if (n_items == 0 || n_items > KNN_FB_UNITS / 2) return 1u;
     const uint32_t p = KNN_FB_UNITS / n_items;
-    return p > 64u ? 64u : p;
+    return p > 256u ? 256u : p;
 }
 #define KNN_FB_MAXJ 84          // dim_pad <= 1344 -> at most 84 elements per lane of a 16-lane row group
 __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ words, int dim, int dim_pad, int n_words,
@@ -928,6 +979,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
                                                       const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ items,
                                                       const int32_t* __restrict__ idx_in, const float* __restrict__ dist_in,
                                                       unsigned long long* __restrict__ item_out, size_t part_base) {
+    __shared__ __attribute__((aligned(16))) float s_terms[4][1344];
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, l16 = lane & 15;
     const uint32_t n_items = flag_count[1];
@@ -976,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
             while (hm) {                                                             // rare
                 const int src = __ffsll((long long)hm) - 1; hm &= hm - 1;
                 const int rr = __shfl(r, src, 64);
-                const float d = l2 ? flann_l2(qp, words + (size_t)rr * dim_pad, dim) : flann_chi2(qp, words + (size_t)rr * dim_pad, dim);
+                const float d = wave_functor(metric, qp, words + (size_t)rr * dim_pad, dim, lane, s_terms[threadIdx.x >> 6]);
                 unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)rr;
                 if (d != d) key = ~0ull - 1;                                        // NaN sorts last but stays a valid row
 #pragma unroll
@@ -988,26 +1040,40 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
     }
 }
 
-__global__ void k_knn_fallback_merge(int k, const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ qrec,
+// one wave per unproven query: the lanes fold the per-unit results (and the re-ranked candidates) into private sorted lists, k
+// rounds of a wave-wide minimum then pick the result; a row reached through two paths is taken once
+__global__ __launch_bounds__(256) void k_knn_fallback_merge(int k, const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ qrec,
                                      const unsigned long long* __restrict__ item_out, size_t part_base, int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
     const uint32_t n_q = flag_count[0];
     const uint32_t P = knn_fb_parts(flag_count[1]);
     const unsigned long long* outp = P > 1 ? item_out + 4 * part_base : item_out;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_q; t += gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < n_q; t += gridDim.x * 4) {
         const int qi = (int)qrec[3 * (size_t)t]; const uint32_t ibase = qrec[3 * (size_t)t + 1], ni = qrec[3 * (size_t)t + 2];
         unsigned long long fin[4] = {~0ull, ~0ull, ~0ull, ~0ull};
         auto ins = [&](unsigned long long key) {
-            for (int j = 0; j < k; ++j) if (fin[j] != ~0ull && (fin[j] & 0xffffffffull) == (key & 0xffffffffull)) return;   // same row twice
-            for (int j = 0; j < 4; ++j) if (j < k && key < fin[j]) { const unsigned long long tmp = fin[j]; fin[j] = key; key = tmp; }
+            for (int j = 0; j < 4; ++j) if (fin[j] != ~0ull && (fin[j] & 0xffffffffull) == (key & 0xffffffffull)) return;   // same row twice
+            for (int j = 0; j < 4; ++j) if (key < fin[j]) { const unsigned long long tmp = fin[j]; fin[j] = key; key = tmp; }
         };
-        for (int j = 0; j < k; ++j) {
-            const int id = idx_out[(size_t)qi * k + j];
-            if (id >= 0) ins(((unsigned long long)__float_as_uint(dist_out[(size_t)qi * k + j]) << 32) | (unsigned)id);
+        if (lane < k) {
+            const int id = idx_out[(size_t)qi * k + lane];
+            if (id >= 0) ins(((unsigned long long)__float_as_uint(dist_out[(size_t)qi * k + lane]) << 32) | (unsigned)id);
         }
-        for (uint32_t i = 0; i < ni * P; ++i) for (int j = 0; j < k; ++j) { const unsigned long long key = outp[4 * ((size_t)ibase * P + i) + j]; if (key != ~0ull) ins(key); }
+        for (uint32_t i = lane; i < ni * P; i += 64)
+            for (int j = 0; j < k; ++j) { const unsigned long long key = outp[4 * ((size_t)ibase * P + i) + j]; if (key != ~0ull) ins(key); }
         for (int j = 0; j < k; ++j) {
-            if (fin[j] == ~0ull) { idx_out[(size_t)qi * k + j] = -1; dist_out[(size_t)qi * k + j] = __builtin_nanf(""); }
-            else { idx_out[(size_t)qi * k + j] = (int)(fin[j] & 0xffffffffull); dist_out[(size_t)qi * k + j] = __uint_as_float((unsigned)(fin[j] >> 32)); }
+            unsigned long long mn = fin[0];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(mn, o, 64); mn = x < mn ? x : mn; }
+            if (lane == 0) {
+                if (mn == ~0ull) { idx_out[(size_t)qi * k + j] = -1; dist_out[(size_t)qi * k + j] = __builtin_nanf(""); }
+                else { idx_out[(size_t)qi * k + j] = (int)(mn & 0xffffffffull); dist_out[(size_t)qi * k + j] = __uint_as_float((unsigned)(mn >> 32)); }
+            }
+            if (mn == ~0ull) continue;
+            // drop the chosen row from every private list (it can sit in several lanes, with the same key)
+            unsigned long long kept[4] = {~0ull, ~0ull, ~0ull, ~0ull}; int c = 0;
+            for (int x = 0; x < 4; ++x) if (fin[x] != ~0ull && (fin[x] & 0xffffffffull) != (mn & 0xffffffffull)) kept[c++] = fin[x];
+            for (int x = 0; x < 4; ++x) fin[x] = kept[x];
         }
     }
 }
@@ -1051,6 +1117,7 @@ __global__ void k_rule(int nq, float thr, const int32_t* __restrict__ idx3, cons
 template <int T>
 int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q, int k,
             int32_t* idx_out, float* dist_out) {
+    if (cb->dim_pad / 16 > KNN_FB_MAXJ) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: descriptor longer than 1344 not built");
     const float* qq = q; int ldq = cb->dim;
     if (cb->dim_pad != cb->dim) {
         float* qpad = (float*)ism_scratch(ctx, SCR_QPAD, (size_t)nq * cb->dim_pad * sizeof(float));
@@ -1198,12 +1265,11 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     ISM_CHECK_LAUNCH(ctx, "k_knn_rerank");
     {
         TimerScope ts(ctx, "knn_fallback");
-        if (cb->dim_pad / 16 > KNN_FB_MAXJ) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: descriptor longer than 1344 not built");
         hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad,
                            cb->n_words, qq, ldq, metric, k, tiles_per_split, cb->n_words_pad / BM, BM, wr_rows,
                            flag_count, items, idx_out, dist_out, item_out, q_items);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback");
-        hipLaunchKernelGGL(k_knn_fallback_merge, dim3(64), dim3(256), 0, ctx->stream, k, flag_count, qrec, item_out, q_items, idx_out, dist_out);
+        hipLaunchKernelGGL(k_knn_fallback_merge, dim3(256), dim3(256), 0, ctx->stream, k, flag_count, qrec, item_out, q_items, idx_out, dist_out);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback_merge");
     }
     if (ctx->timers_on) ISM_HIP(ctx, hipMemcpyAsync(ctx->knn_stats, flag_count, 8, hipMemcpyDeviceToHost, ctx->stream));   // read back after a sync
