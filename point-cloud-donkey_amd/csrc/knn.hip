@@ -262,7 +262,13 @@ __global__ void k_absmax(const float* __restrict__ src, int n, int dim, int ld, 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
+    __shared__ uint32_t s_m[4];                        // one atomic per workgroup: thousands of same-address atomics serialise
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        if (m) atomicMax(out_bits, m);
+    }
 }
 __host__ __device__ inline float f16_scale_for(uint32_t absmax_bits) {
     const int e = (int)(absmax_bits >> 23);          // biased exponent; 0 = zero/subnormal, 255 = inf/NaN
@@ -1174,7 +1180,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         if (!q_hi) return ISMHIP_ERR_NOMEM;
         q_lo = q_hi + tot;
         if (mode == 0) {
-            hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, qsc);
+            hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, qsc);
             ISM_CHECK_LAUNCH(ctx, "k_absmax");
             if (use_ring) hipLaunchKernelGGL(k_to_f16_tiled, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad / 256, ring_nk, qsc, cb->f16_scale, q_hi);
             else hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->ld16, qsc, cb->f16_scale, q_hi);

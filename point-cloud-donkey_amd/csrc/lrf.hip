@@ -165,18 +165,19 @@ __global__ __launch_bounds__(256, 4) void k_lrf_sign(CloudView cv, const uint32_
     if (lane == 0) write_lrf(lrf_out + (size_t)k * 9, v1, v3);
 }
 
-#define TIE_LDS_KEYS 2048
-__global__ __launch_bounds__(128) void k_lrf_tie(CloudView cv, const float* __restrict__ kx, const float* __restrict__ ky,
+#define TIE_LDS_KEYS 8192     // keys of one neighbourhood in LDS (64 KB, one wave per workgroup); larger ones go to a global scratch row
+#define TIE_REG_KEYS 20      // keys per lane held in registers by the fast selection path (neighbourhoods up to 1280 points)
+__global__ __launch_bounds__(64) void k_lrf_tie(CloudView cv, const float* __restrict__ kx, const float* __restrict__ ky,
                                                  const float* __restrict__ kz, float radius, float r2,
                                                  float* __restrict__ lrf_out, const uint32_t* __restrict__ tie_count,
                                                  const TieRec* __restrict__ tie_rec, unsigned long long* __restrict__ keys,
                                                  uint32_t key_cap) {
     // keys live in LDS when the neighbourhood fits (the common case), else in a per-wave global scratch row
-    __shared__ unsigned long long s_keys[2][TIE_LDS_KEYS];
-    __shared__ WaveRows s_rows[2];
+    __shared__ unsigned long long s_keys[1][TIE_LDS_KEYS];
+    __shared__ WaveRows s_rows[1];
     const int lane = lane_id();
-    const uint32_t gw = blockIdx.x * 2 + (threadIdx.x >> 6);
-    const uint32_t nw = gridDim.x * 2;
+    const uint32_t gw = blockIdx.x;
+    const uint32_t nw = gridDim.x;
     const uint32_t n_tie = *tie_count;
     unsigned long long* gkeys = keys + (size_t)gw * key_cap;
     for (uint32_t t = gw; t < n_tie; t += nw) {
@@ -215,24 +216,55 @@ __global__ __launch_bounds__(128) void k_lrf_tie(CloudView cv, const float* __re
         const int median = (int)n / 2;
         const int tsel = median - 2;
         int idx_bits = 1; while ((1u << idx_bits) < key_cap) ++idx_bits;
-        unsigned long long sel = 0ull;
-        for (int bit = 62; bit >= 0; --bit) {
-            if (bit < 32 && bit >= idx_bits) continue;
-            const unsigned long long cand = sel | (1ull << bit);
-            int c = 0;
-            for (uint32_t i = lane; i < n; i += 64) c += mykeys[i] < cand;
-            c = wave_sum_i(c);
-            if (c <= tsel) sel = cand;
-        }
-        // sel = key of rank median-2; the next four follow by successive minima above the previous one
         unsigned long long five[5];
-        five[0] = sel;
-        for (int j = 1; j < 5; ++j) {
-            unsigned long long mn = ~0ull;
-            for (uint32_t i = lane; i < n; i += 64) { const unsigned long long kk = mykeys[i]; if (kk > five[j - 1] && kk < mn) mn = kk; }
+        if (n <= 64 * TIE_REG_KEYS) {
+            // the common case: the keys fit the register file (TIE_REG_KEYS per lane), every round is compares + one DPP wave sum
+            unsigned long long kr[TIE_REG_KEYS];
 #pragma unroll
-            for (int o2 = 32; o2 > 0; o2 >>= 1) { const unsigned long long tt = __shfl_xor(mn, o2, 64); mn = tt < mn ? tt : mn; }
-            five[j] = mn;
+            for (int j = 0; j < TIE_REG_KEYS; ++j) kr[j] = (uint32_t)(j * 64 + lane) < n ? mykeys[j * 64 + lane] : ~0ull;
+            unsigned long long sel = 0ull;
+            for (int bit = 62; bit >= 0; --bit) {
+                if (bit < 32 && bit >= idx_bits) continue;
+                const unsigned long long cand = sel | (1ull << bit);
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < TIE_REG_KEYS; ++j) c += kr[j] < cand;
+                c = wave_sum_i(c);
+                if (c <= tsel) sel = cand;
+            }
+            five[0] = sel;
+            for (int j = 1; j < 5; ++j) {
+                unsigned long long mn = ~0ull;
+#pragma unroll
+                for (int x = 0; x < TIE_REG_KEYS; ++x) { const unsigned long long kk = kr[x]; if (kk > five[j - 1] && kk < mn) mn = kk; }
+#pragma unroll
+                for (int o2 = 32; o2 > 0; o2 >>= 1) { const unsigned long long tt = __shfl_xor(mn, o2, 64); mn = tt < mn ? tt : mn; }
+                five[j] = mn;
+            }
+        } else {
+            unsigned long long sel = 0ull;
+            for (int bit = 62; bit >= 0; --bit) {
+                if (bit < 32 && bit >= idx_bits) continue;
+                const unsigned long long cand = sel | (1ull << bit);
+                int c = 0;
+                uint32_t i = lane;
+                for (; i + 192 < n; i += 256) {          // four independent LDS reads in flight
+                    const unsigned long long k0 = mykeys[i], k1 = mykeys[i + 64], k2 = mykeys[i + 128], k3 = mykeys[i + 192];
+                    c += (k0 < cand) + (k1 < cand) + (k2 < cand) + (k3 < cand);
+                }
+                for (; i < n; i += 64) c += mykeys[i] < cand;
+                c = wave_sum_i(c);
+                if (c <= tsel) sel = cand;
+            }
+            // sel = key of rank median-2; the next four follow by successive minima above the previous one
+            five[0] = sel;
+            for (int j = 1; j < 5; ++j) {
+                unsigned long long mn = ~0ull;
+                for (uint32_t i = lane; i < n; i += 64) { const unsigned long long kk = mykeys[i]; if (kk > five[j - 1] && kk < mn) mn = kk; }
+#pragma unroll
+                for (int o2 = 32; o2 > 0; o2 >>= 1) { const unsigned long long tt = __shfl_xor(mn, o2, 64); mn = tt < mn ? tt : mn; }
+                five[j] = mn;
+            }
         }
         int cntx = 0, cntz = 0;
         if (lane < 5) {
@@ -271,9 +303,9 @@ extern "C" int ismhip_shot_lrf(ismhip_ctx* ctx, const ismhip_cloud* cloud, const
     uint32_t* tie_count = (uint32_t*)ism_scratch(ctx, SCR_COUNTERS, 64);
     TieRec* tie_rec = (TieRec*)ism_scratch(ctx, SCR_TIE_REC, (size_t)nkp * sizeof(TieRec));
     double* cov = (double*)ism_scratch(ctx, SCR_LRF_COV, (size_t)nkp * 14 * sizeof(double));
-    const int tie_blocks = 512;   // 1024 waves of 2-wave workgroups
+    const int tie_blocks = 1024;  // one wave per workgroup
     const uint32_t key_cap = cloud->max_pts ? cloud->max_pts : 1;
-    unsigned long long* keys = (unsigned long long*)ism_scratch(ctx, SCR_TIE_KEYS, (size_t)tie_blocks * 2 * key_cap * 8);
+    unsigned long long* keys = (unsigned long long*)ism_scratch(ctx, SCR_TIE_KEYS, (size_t)tie_blocks * key_cap * 8);
     if (!tie_count || !tie_rec || !keys || !cov) return ISMHIP_ERR_NOMEM;
     double* axes = cov + (size_t)nkp * 8;
     CloudView cv{cloud->pt_off, cloud->meta, cloud->cell_start, cloud->sx, cloud->sy, cloud->sz, cloud->sorig, cloud->x, cloud->y, cloud->z};
@@ -287,7 +319,7 @@ extern "C" int ismhip_shot_lrf(ismhip_ctx* ctx, const ismhip_cloud* cloud, const
     ISM_CHECK_LAUNCH(ctx, "k_lrf_eig");
     hipLaunchKernelGGL(k_lrf_sign, grid, dim3(256), 0, ctx->stream, cv, ko, kpx, kpy, kpz, radius, r2, cov, axes, lrf9_out, tie_count, tie_rec);
     ISM_CHECK_LAUNCH(ctx, "k_lrf_sign");
-    hipLaunchKernelGGL(k_lrf_tie, dim3(tie_blocks), dim3(128), 0, ctx->stream, cv, kpx, kpy, kpz, radius, r2, lrf9_out, tie_count, tie_rec, keys, key_cap);
+    hipLaunchKernelGGL(k_lrf_tie, dim3(tie_blocks), dim3(64), 0, ctx->stream, cv, kpx, kpy, kpz, radius, r2, lrf9_out, tie_count, tie_rec, keys, key_cap);
     ISM_CHECK_LAUNCH(ctx, "k_lrf_tie");
     return ISMHIP_OK;
 }

@@ -42,6 +42,34 @@ struct ShotArgs {
 #define SHOT_FIX_SCALE 268435456.0f          /* 2^28 */
 #define SHOT_FIX_INV   3.7252902984619140625e-09 /* 2^-28 */
 typedef unsigned long long shot_bin_t;
+// The interpolation weights are CONTINUOUS in distance / inclination / azimuth (all hard bin decisions are taken on the
+// signs and squares above them), so these three only need ~1e-7 absolute accuracy -- far inside the 1e-4 parity tolerance --
+// and not libm's last ulp: the IEEE division / sqrt expansions and OCML's acosf / atan2f were a quarter of the kernel's VALU.
+// acos: Abramowitz & Stegun 4.4.46 (|err| <= 2e-8 before rounding); atan: A&S 4.4.49 (|err| <= 2e-8).
+__device__ __forceinline__ float shot_acos(float x) {
+    const float a = fabsf(x);
+    float p = -0.0012624911f;
+    p = __builtin_fmaf(p, a, 0.0066700901f); p = __builtin_fmaf(p, a, -0.0170881256f); p = __builtin_fmaf(p, a, 0.0308918810f);
+    p = __builtin_fmaf(p, a, -0.0501743046f); p = __builtin_fmaf(p, a, 0.0889789874f); p = __builtin_fmaf(p, a, -0.2145988016f);
+    p = __builtin_fmaf(p, a, 1.5707963050f);
+    const float r = __builtin_amdgcn_sqrtf(fmaxf(1.0f - a, 0.f)) * p;
+    return x < 0.f ? 3.14159265358979323846f - r : r;
+}
+__device__ __forceinline__ float shot_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mn * __builtin_amdgcn_rcpf(mx);          // mx > 0: the caller excludes x == y == 0
+    const float z = a * a;
+    float p = 0.0028662257f;
+    p = __builtin_fmaf(p, z, -0.0161657367f); p = __builtin_fmaf(p, z, 0.0429096138f); p = __builtin_fmaf(p, z, -0.0752896400f);
+    p = __builtin_fmaf(p, z, 0.1065626393f); p = __builtin_fmaf(p, z, -0.1420889944f); p = __builtin_fmaf(p, z, 0.1999355085f);
+    p = __builtin_fmaf(p, z, -0.3333314528f); p = __builtin_fmaf(p, z, 1.0f);
+    float r = a * p;
+    if (ay > ax) r = 1.57079632679489661923f - r;
+    if (x < 0.f) r = 3.14159265358979323846f - r;
+    return y < 0.f ? -r : r;
+}
+
 template <bool COLOR>
 struct ShotSmem {
     static constexpr int D = COLOR ? 1344 : 352;
@@ -70,7 +98,7 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
     // every hard decision must be taken exactly as the reference takes it. The cosine bin is computed in double from the float
     // cosine (createBinDistanceShape), and the radial shell test compares in double.
     const double bd_d = ((1.0 + (double)cosd) * 10.0) / 2.0;
-    const float dist = sqrtf(d2);
+    const float dist = __builtin_amdgcn_sqrtf(d2);
     if (dist < 1e-15f) return;                                                    // areEquals(distance, 0)
     float xl = (dx * fx[0] + dy * fx[1]) + dz * fx[2];
     float yl = (dx * fy[0] + dy * fy[1]) + dz * fy[2];
@@ -99,7 +127,7 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
     int step_c = 0, vol_c = 0; float w_col = 0.f;
     if (COLOR) {
         const float L = a.sL[gi], A = a.sa[gi], B = a.sb[gi];
-        float cd = (fabsf(LRef - L) + ((fabsf(aRef - A) + fabsf(bRef - B)) * 0.5f)) / 3.0f;
+        float cd = (fabsf(LRef - L) + ((fabsf(aRef - A) + fabsf(bRef - B)) * 0.5f)) / 3.0f;   // feeds a hard bin: exact division
         cd = fminf(1.0f, fmaxf(0.0f, cd));
         const double bc_d = (double)cd * 30.0;                                    // colorDistance (float) * nr_color_bins_ in double
         const double step_cd = floor(bc_d + 0.5);
@@ -127,23 +155,23 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
         else { winc += 1.f - rd; SHOT_DEP(di + 2, rd); }
     }
     // elevation
-    float ic = zl / dist;
+    float ic = zl * __builtin_amdgcn_rcpf(dist);
     ic = fminf(1.0f, fmaxf(-1.0f, ic));
-    const float inc = acosf(ic);
+    const float inc = shot_acos(ic);
     if (!(zl > 0.f)) {        // inclination > 90 deg, or exactly 90 deg with z <= 0: the same test that picked the sector's elevation bit
-        const float id = (inc - PST_RAD_135f) / PST_RAD_90f;
+        const float id = (inc - PST_RAD_135f) * (1.0f / PST_RAD_90f);
         if (inc > PST_RAD_135f) winc += 1.f - id;
         else { winc += 1.f + id; SHOT_DEP(di + 1, -id); }
     } else {
-        const float id = (inc - PST_RAD_45f) / PST_RAD_90f;
+        const float id = (inc - PST_RAD_45f) * (1.0f / PST_RAD_90f);
         if (inc < PST_RAD_45f) winc += 1.f + id;
         else { winc += 1.f - id; SHOT_DEP(di - 1, id); }
     }
     // azimuth
     if (yl != 0.f || xl != 0.f) {
-        const float az = atan2f(yl, xl);
+        const float az = shot_atan2(yl, xl);
         const int sel = di >> 2;
-        float ad = (az - (-PST_RAD_PI_7_8f + PST_RAD_45f * (float)sel)) / PST_RAD_45f;
+        float ad = (az - (-PST_RAD_PI_7_8f + PST_RAD_45f * (float)sel)) * (1.0f / PST_RAD_45f);
         ad = fmaxf(-0.5f, fminf(ad, 0.5f));
         if (ad > 0.f) { winc += 1.f - ad; SHOT_DEP((di + 4) % 32, ad); }
         else { winc += 1.f + ad; SHOT_DEP((di - 4 + 32) % 32, -ad); }
