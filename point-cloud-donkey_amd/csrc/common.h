@@ -239,9 +239,11 @@ struct WaveRows {
     uint32_t off[65];      // exclusive prefix of the row lengths
     uint32_t start[64];    // first sorted index of each row
 };
-template <class F>
+// L(i, valid) loads and returns the point record (issued one sweep AHEAD of its use, so the next 64 candidates are in flight
+// while the current ones are processed); F(record, i, valid) consumes it.
+template <class L, class F>
 __device__ __forceinline__ void ball_for_each(const GridMeta& m, const uint32_t* __restrict__ cs, const CellRange& cr,
-                                              float qx, float qy, float qz, float r, int lane, WaveRows& wr, F&& f) {
+                                              float qx, float qy, float qz, float r, int lane, WaveRows& wr, L&& load, F&& f) {
     const int ny = cr.hi[1] - cr.lo[1] + 1, nrows = ny * (cr.hi[2] - cr.lo[2] + 1);
     for (int r0 = 0; r0 < nrows; r0 += 64) {
         const int j = r0 + lane;
@@ -261,15 +263,23 @@ __device__ __forceinline__ void ball_for_each(const GridMeta& m, const uint32_t*
         if (lane == 0) wr.off[0] = 0;
         const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
         uint32_t jc = 0;                                     // LDS traffic of one wave is ordered: no barrier needed
+        auto locate = [&](uint32_t idx, bool v) -> uint32_t {
+            if (!v) return 0u;
+            while (idx >= wr.off[jc + 1]) ++jc;
+            return wr.start[jc] + (idx - wr.off[jc]);
+        };
+        if (total == 0) continue;
+        bool vn = (uint32_t)lane < total;
+        uint32_t in = locate((uint32_t)lane, vn);
+        auto rn = load(in, vn);
         for (uint32_t c = 0; c < total; c += 64) {
-            const uint32_t idx = c + lane;
-            const bool v = idx < total;
-            uint32_t i = 0;
-            if (v) {
-                while (idx >= wr.off[jc + 1]) ++jc;
-                i = wr.start[jc] + (idx - wr.off[jc]);
+            const bool v = vn; const uint32_t i = in; const auto rec = rn;
+            if (c + 64 < total) {
+                vn = c + 64 + lane < total;
+                in = locate(c + 64 + lane, vn);
+                rn = load(in, vn);
             }
-            f(i, v);
+            f(rec, i, v);
         }
     }
 }

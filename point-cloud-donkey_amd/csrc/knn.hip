@@ -515,6 +515,9 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_mfma16(const u16* __
 __device__ __forceinline__ void lds_dma16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
 }
+__device__ __forceinline__ void lds_dma16_nt(const void* g, void* l) {      // non-temporal: see MI355X_MICROARCH 'nt-weights'
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 2);
+}
 template <int T, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ wh, const float* __restrict__ word_norm, int n_tiles_m, int ld, int k_steps,
                                                         const u16* __restrict__ qh, int nq, const float* __restrict__ out_scale,
@@ -558,7 +561,11 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
         if (wv == 0 && pkc == 0) lds_dma16(word_norm + (size_t)(mt0 + pt) * BM + lane * 4, sCn + (pt & 3) * BM);
         const char* sp = dbase + pt * tile_stride + (size_t)pkc * (BM * KB * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_dma16(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);
+        for (int j = 0; j < 4; ++j) {
+            if ((DBG & 64) && dma_a) lds_dma16_nt(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);
+            else if ((DBG & 128) && !dma_a) lds_dma16_nt(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);
+            else lds_dma16(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);
+        }
         ++pg;
         if (pt * nk + pkc + 1 < G) { if (++pkc == nk) { pkc = 0; ++pt; } }   // past the end: re-load the last slice into a free stage
     };
@@ -611,14 +618,16 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
     }
     int t = 0, kc = 0;
     for (int g = 0; g < G; ++g) {
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!(DBG & 32)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (!(DBG & 4) || g < 4) issue();                               // slice g+3 -> the stage of slice g-1
         const u16* st = ring + (g & (RG_STAGES - 1)) * RG_STAGE_HALVES;
         const u16* sn = ring + ((g + 1) & (RG_STAGES - 1)) * RG_STAGE_HALVES;
+        if (!(DBG & 16) || g == 0) {
 #pragma unroll
         for (int n = 0; n < NI; ++n) yb[n] = *(const f16x8*)(st + fragB + n * 32 * KB + so1);
 #pragma unroll
         for (int m = 0; m < MI; ++m) ya[m] = *(const f16x8*)(st + fragA + m * 32 * KB + so1);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -628,10 +637,12 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
                 if (!(DBG & 2)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[mi], xb[ni], acc[mi][ni], 0, 0, 0);
                 else acc[mi][ni][0] += (float)xa[mi][0] * (float)xb[ni][0];
         __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 16)) {
 #pragma unroll
         for (int n = 0; n < NI; ++n) xb[n] = *(const f16x8*)(sn + fragB + n * 32 * KB + so0);
 #pragma unroll
         for (int m = 0; m < MI; ++m) xa[m] = *(const f16x8*)(sn + fragA + m * 32 * KB + so0);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -1220,6 +1231,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     case 5: rk = (const void*)k_knn_l2_ring<T, 5>; break;  case 7: rk = (const void*)k_knn_l2_ring<T, 7>; break;
                     case 9: rk = (const void*)k_knn_l2_ring<T, 9>; break;  case 13: rk = (const void*)k_knn_l2_ring<T, 13>; break;
                     case 15: rk = (const void*)k_knn_l2_ring<T, 15>; break; case 11: rk = (const void*)k_knn_l2_ring<T, 11>; break;
+                    case 21: rk = (const void*)k_knn_l2_ring<T, 21>; break; case 64: rk = (const void*)k_knn_l2_ring<T, 64>; break; case 128: rk = (const void*)k_knn_l2_ring<T, 128>; break; case 192: rk = (const void*)k_knn_l2_ring<T, 192>; break; case 53: rk = (const void*)k_knn_l2_ring<T, 53>; break; case 37: rk = (const void*)k_knn_l2_ring<T, 37>; break;
                     default: break;
                 }
 #endif

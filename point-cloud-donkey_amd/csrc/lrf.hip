@@ -19,6 +19,9 @@ uint32_t* ism_upload_offsets(ismhip_ctx* ctx, int slot, const uint32_t* off_h, i
 
 namespace {
 
+struct P3 { float x, y, z; };
+struct P3o { float x, y, z; uint32_t orig; };
+
 struct TieRec {
     double v1[3], v3[3];
     uint32_t kp, obj;
@@ -71,9 +74,11 @@ __global__ __launch_bounds__(256) void k_lrf_cov(CloudView cv, const uint32_t* _
     int valid = 0;
     const double rd = (double)radius;
     __shared__ WaveRows s_rows[4];
-    ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6], [&](uint32_t t, bool v) {
+    ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6],
+                  [&](uint32_t t, bool v) { P3 p = {0.f, 0.f, 0.f}; if (v) { p.x = cv.sx[base + t]; p.y = cv.sy[base + t]; p.z = cv.sz[base + t]; } return p; },
+                  [&](const P3& p, uint32_t, bool v) {
         if (!v) return;
-        const float px = cv.sx[base + t], py = cv.sy[base + t], pz = cv.sz[base + t];
+        const float px = p.x, py = p.y, pz = p.z;
         const float d2 = sqdist3(px, py, pz, cx, cy, cz);
         if (d2 < r2 && !(px == cx && py == cy && pz == cz)) {
             const double vx = (double)(px - cx), vy = (double)(py - cy), vz = (double)(pz - cz);
@@ -138,9 +143,11 @@ __global__ __launch_bounds__(256, 4) void k_lrf_sign(CloudView cv, const uint32_
     ball_cells(m, cx, cy, cz, radius, cr);
     int plusT = 0, plusN = 0;
     __shared__ WaveRows s_rows[4];
-    ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6], [&](uint32_t t, bool v) {
+    ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6],
+                  [&](uint32_t t, bool v) { P3 p = {0.f, 0.f, 0.f}; if (v) { p.x = cv.sx[base + t]; p.y = cv.sy[base + t]; p.z = cv.sz[base + t]; } return p; },
+                  [&](const P3& p, uint32_t, bool v) {
         if (!v) return;
-        const float px = cv.sx[base + t], py = cv.sy[base + t], pz = cv.sz[base + t];
+        const float px = p.x, py = p.y, pz = p.z;
         const float d2 = sqdist3(px, py, pz, cx, cy, cz);
         if (d2 < r2 && !(px == cx && py == cy && pz == cz)) {
             const double vx = (double)(px - cx), vy = (double)(py - cy), vz = (double)(pz - cz);
@@ -194,13 +201,14 @@ __global__ __launch_bounds__(64) void k_lrf_tie(CloudView cv, const float* __res
         unsigned long long* mykeys = r.valid <= TIE_LDS_KEYS ? s_keys[threadIdx.x >> 6] : gkeys;
         const uint32_t cap = r.valid <= TIE_LDS_KEYS ? (uint32_t)TIE_LDS_KEYS : key_cap;
         uint32_t n = 0;
-        ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6], [&](uint32_t i, bool v) {
+        ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6],
+                      [&](uint32_t i, bool v) { P3o p = {0.f, 0.f, 0.f, 0u}; if (v) { p.x = cv.sx[base + i]; p.y = cv.sy[base + i]; p.z = cv.sz[base + i]; p.orig = cv.sorig[base + i]; } return p; },
+                      [&](const P3o& p, uint32_t, bool v) {
             bool pass = false; float d2 = 0.f; uint32_t orig = 0;
             if (v) {
-                const float px = cv.sx[base + i], py = cv.sy[base + i], pz = cv.sz[base + i];
-                d2 = sqdist3(px, py, pz, cx, cy, cz);
-                pass = d2 < r2 && !(px == cx && py == cy && pz == cz);
-                orig = cv.sorig[base + i];
+                d2 = sqdist3(p.x, p.y, p.z, cx, cy, cz);
+                pass = d2 < r2 && !(p.x == cx && p.y == cy && p.z == cz);
+                orig = p.orig;
             }
             const unsigned long long mask = __ballot(pass);
             if (pass) {

@@ -27,7 +27,7 @@ struct ShotArgs {
     const uint32_t* pt_off; const GridMeta* meta; const uint32_t* cell_start;
     const float *sx, *sy, *sz, *snx, *sny, *snz, *sL, *sa, *sb;
     const uint32_t* kp_off; const float *kx, *ky, *kz; const uint32_t* kp_rgba;
-    const float* lrf; float radius, r2;
+    const float* lrf; float radius, r2, r12sq_f;
     const float *lut_srgb, *lut_sxyz;
     float* desc; uint32_t* count;
 };
@@ -70,6 +70,18 @@ __device__ __forceinline__ float shot_atan2(float y, float x) {
     return y < 0.f ? -r : r;
 }
 
+// step = floor(m*x + c) and off = float((m*x + c0) - step) exactly as the reference's double arithmetic yields them, for a float x
+// whose product m*x (m = 5 or 30) is exact in double -- true wherever m*x + c can reach an integer. One fma rounds the exact value
+// once; floor of the rounded value differs from the true floor only if the rounding went UP onto an integer, which the sign of a
+// second fma (the exact residual, rounded) reveals. c0 = c - 0.5: the offset is measured from the bin centre.
+__device__ __forceinline__ void shot_hard_bin(float m, float x, float c, float c0, int& step, float& off) {
+    const float t = __builtin_fmaf(m, x, c);
+    float k = floorf(t);
+    if (t == k && __builtin_fmaf(m, x, c - k) < 0.f) k -= 1.f;
+    step = (int)k;
+    off = __builtin_fmaf(m, x, c0 - k);
+}
+
 template <bool COLOR>
 struct ShotSmem {
     static constexpr int D = COLOR ? 1344 : 352;
@@ -87,7 +99,7 @@ template <bool COLOR>
 __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hist, bool act, uint32_t gi,
                                                float dx, float dy, float dz, float d2,
                                                const float fx[3], const float fy[3], const float fz[3],
-                                               float r12, float r14, float r34, float inv_r12, double r12sq,
+                                               float r12, float r14, float r34, float inv_r12, float r12sq_f,
                                                float LRef, float aRef, float bRef) {
     if (!act) return;
     const float nxv = a.snx[gi], nyv = a.sny[gi], nzv = a.snz[gi];
@@ -95,9 +107,9 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
     float cosd = (nxv * fz[0] + nyv * fz[1]) + nzv * fz[2];
     cosd = fminf(1.0f, fmaxf(-1.0f, cosd));
     // PCL's interpolation is only partly soft: the whole accumulated weight lands in the HARD-assigned (sector, step) bin, so
-    // every hard decision must be taken exactly as the reference takes it. The cosine bin is computed in double from the float
-    // cosine (createBinDistanceShape), and the radial shell test compares in double.
-    const double bd_d = ((1.0 + (double)cosd) * 10.0) / 2.0;
+    // every hard decision must be taken exactly as the reference takes it. The reference computes the cosine bin in double from
+    // the float cosine (createBinDistanceShape) and compares the radial shell on squares in double; both are reproduced below
+    // without FP64 instructions (shot_hard_bin, r12sq_f).
     const float dist = __builtin_amdgcn_sqrtf(d2);
     if (dist < 1e-15f) return;                                                    // areEquals(distance, 0)
     float xl = (dx * fx[0] + dy * fx[1]) + dz * fx[2];
@@ -113,13 +125,12 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
     if (same_sign || xl == 0.f) di += (fabsf(xl) >= fabsf(yl)) ? 0 : 4;
     else di += (fabsf(xl) > fabsf(yl)) ? 4 : 0;
     di += zl > 0.f ? 1 : 0;
-    const bool outer = (double)d2 > r12sq;                                        // distance > radius1_2, decided on the squares in double
+    const bool outer = d2 > r12sq_f;                                              // distance > radius1_2: (double)d2 > r^2/4 in double == d2 > largest float <= r^2/4
     di += outer ? 2 : 0;
 
-    const double step_d = floor(bd_d + 0.5);
-    const int step = (int)step_d;
+    int step; float bd;
+    shot_hard_bin(5.f, cosd, 5.5f, 5.f, step, bd);                                // bin = floor(((1 + cos) * 10) / 2 + 0.5), bd = offset from its centre
     const int vol = di * 11;
-    float bd = (float)(bd_d - step_d);
     float w_shape = 1.f - fabsf(bd);
     if (bd > 0.f) shot_dep(hist, vol + ((step + 1) % 10), bd);
     else shot_dep(hist, vol + ((step - 1 + 10) % 10), -bd);
@@ -129,11 +140,9 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
         const float L = a.sL[gi], A = a.sa[gi], B = a.sb[gi];
         float cd = (fabsf(LRef - L) + ((fabsf(aRef - A) + fabsf(bRef - B)) * 0.5f)) / 3.0f;   // feeds a hard bin: exact division
         cd = fminf(1.0f, fmaxf(0.0f, cd));
-        const double bc_d = (double)cd * 30.0;                                    // colorDistance (float) * nr_color_bins_ in double
-        const double step_cd = floor(bc_d + 0.5);
-        step_c = (int)step_cd;
+        float bc;
+        shot_hard_bin(30.f, cd, 0.5f, 0.f, step_c, bc);                           // colorDistance (float) * nr_color_bins_, taken in double by the reference
         vol_c = 352 + di * 31;
-        float bc = (float)(bc_d - step_cd);
         w_col = 1.f - fabsf(bc);
         if (bc > 0.f) shot_dep(hist, vol_c + ((step_c + 1) % 30), bc);
         else shot_dep(hist, vol_c + ((step_c - 1 + 30) % 30), -bc);
@@ -222,14 +231,17 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
     float LRef = 0.f, aRef = 0.f, bRef = 0.f;
     if (COLOR) rgb2lab_norm(a.lut_srgb, a.lut_sxyz, a.kp_rgba[k], LRef, aRef, bRef);
     const float r12 = a.radius * 0.5f, r14 = a.radius * 0.25f, r34 = (a.radius * 3.0f) * 0.25f, inv_r12 = 1.0f / r12;
-    const double r12sq = 0.25 * (double)a.radius * (double)a.radius;
+    const float r12sq_f = a.r12sq_f;
     const uint32_t* cs = a.cell_start + (size_t)o * ISM_GRID_STRIDE;
     const uint32_t base = a.pt_off[o];
     uint32_t qn = 0, total = 0;
-    ball_for_each(m, cs, cr, cx, cy, cz, a.radius, lane, sm.rows[wv], [&](uint32_t i, bool v) {
+    struct P3 { float x, y, z; };
+    ball_for_each(m, cs, cr, cx, cy, cz, a.radius, lane, sm.rows[wv],
+                  [&](uint32_t i, bool v) { P3 p = {0.f, 0.f, 0.f}; if (v) { p.x = a.sx[base + i]; p.y = a.sy[base + i]; p.z = a.sz[base + i]; } return p; },
+                  [&](const P3& p, uint32_t i, bool v) {
         bool pass = false; float dx = 0, dy = 0, dz = 0, d2 = 0;
         if (v) {
-            const float px = a.sx[base + i], py = a.sy[base + i], pz = a.sz[base + i];
+            const float px = p.x, py = p.y, pz = p.z;
             d2 = sqdist3(px, py, pz, cx, cy, cz);
             dx = px - cx; dy = py - cy; dz = pz - cz;
             pass = d2 < a.r2;
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
         if (qn >= 64) {
             // a full wave of neighbours (LDS traffic of one wave is ordered; no barrier needed)
             const float4 e = sm.qd[wv][lane];
-            shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][lane], e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq, LRef, aRef, bRef);
+            shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][lane], e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq_f, LRef, aRef, bRef);
             const uint32_t rem = qn - 64;
             float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f); uint32_t t0i = 0;
             if ((uint32_t)lane < rem) { t4 = sm.qd[wv][64 + lane]; t0i = sm.qi[wv][64 + lane]; }
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
     if (qn > 0) {
         const bool act = (uint32_t)lane < qn;
         const float4 e = sm.qd[wv][lane];
-        shot_neighbour<COLOR>(a, hist, act, act ? sm.qi[wv][lane] : 0u, e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq, LRef, aRef, bRef);
+        shot_neighbour<COLOR>(a, hist, act, act ? sm.qi[wv][lane] : 0u, e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq_f, LRef, aRef, bRef);
     }
     if (a.count && lane == 0) a.count[k] = total;
     if (total < 5) {                                    // computePointSHOT: fewer than 5 neighbours -> NaN descriptor
@@ -292,6 +304,12 @@ int launch_shot(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_o
     a.sL = cloud->sL; a.sa = cloud->sa; a.sb = cloud->sb;
     a.kp_off = ko; a.kx = kpx; a.ky = kpy; a.kz = kpz; a.kp_rgba = kp_rgba; a.lrf = lrf9;
     a.radius = radius; a.r2 = (float)((double)radius * (double)radius);
+    {   // largest float <= (radius/2)^2 taken in double: the shell test (double)d2 > r12sq of the reference, as a float compare
+        const double t = 0.25 * (double)radius * (double)radius;
+        float tf = (float)t;
+        if ((double)tf > t) tf = nextafterf(tf, -INFINITY);
+        a.r12sq_f = tf;
+    }
     a.lut_srgb = ctx->lut_srgb; a.lut_sxyz = ctx->lut_sxyz;
     a.desc = desc_out; a.count = count_out;
     TimerScope ts(ctx, name);
