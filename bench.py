@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="objects per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="objects per step per GPU (sized for 288 GB of HBM: big launches amortise the latency-bound stages)")
     ap.add_argument("--train-per-class", type=int, default=10, help="training objects per class (codebook ~ 1024 words each)")
     ap.add_argument("--resident-batches", type=int, default=2, help="distinct input batches kept in HBM and cycled")
     ap.add_argument("--cpu-objects", type=int, default=4, help="objects of the bounded CPU-baseline sample (0 = skip)")
