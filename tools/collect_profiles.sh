@@ -1,0 +1,13 @@
+#!/bin/bash
+# Collects the judged profiles of the default bench command on the GPU box (run through gpurun from the repo root).
+#   1. rocprofv3 --kernel-trace --stats        -> gpurun_out/prof_final/
+#   2. --pmc FETCH_SIZE / --pmc WRITE_SIZE     -> gpurun_out/pmc_fetch_final/, pmc_write_final/   (separate passes, as the guide prescribes)
+#   3. SQ counters of the dominant kernel      -> gpurun_out/pmc_sq_final{A,B}/
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+set -e
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o bench -- python3 bench.py --cpu-objects 0 > gpurun_out/prof_final.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch_final -- python3 bench.py --cpu-objects 0 --steps 2 --warmup 1 > gpurun_out/pmc_fetch_final.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write_final -- python3 bench.py --cpu-objects 0 --steps 2 --warmup 1 > gpurun_out/pmc_write_final.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_sq_finalA -- python3 bench.py --cpu-objects 0 --steps 2 --warmup 1 > gpurun_out/pmc_sq_finalA.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA --output-format csv -d gpurun_out/pmc_sq_finalB -- python3 bench.py --cpu-objects 0 --steps 2 --warmup 1 > gpurun_out/pmc_sq_finalB.log 2>&1
+ls gpurun_out/prof_final | head
