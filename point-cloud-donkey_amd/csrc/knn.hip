@@ -569,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
         ++pg;
         if (pt * nk + pkc + 1 < G) { if (++pkc == nk) { pkc = 0; ++pt; } }   // past the end: re-load the last slice into a free stage
     };
-    issue(); issue(); issue();
+    issue(); issue(); issue(); issue();
 
     const int fragA = (wr * (MI * 32) + r) * KB, fragB = BM * KB + (wc * (NI * 32) + r) * KB;
     const int fsw = (r >> 2) & 3;
@@ -594,13 +594,14 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
 #pragma unroll
     for (int n = 0; n < NI; ++n) sThr[(wv * NI + n) * 64 + lane] = -__builtin_inff();
 
-    // Software pipeline. Step g multiplies slice g: its k-step-0 fragments (set X) were read during step g-1, its k-step-1
-    // fragments (set Y) are read while the k-step-0 MFMAs run, and slice g+1's k-step-0 fragments while the k-step-1 MFMAs run, so
-    // no MFMA waits on an LDS round trip. The barrier at the top of step g therefore publishes slice g+1 (one ahead of the
-    // multiply): this wave's DMAs up to slice g+1 have landed (only slice g+2's four may be in flight), its own LDS reads are
-    // done (lgkmcnt(0)), and after the barrier nobody reads slice g-1's stage any more -- which is where slice g+3 is sent.
+    // Software pipeline. Step g multiplies slice g: its k-step-1 fragments (set Y) are read at the top of the step, behind the
+    // k-step-0 MFMAs (set X, read during step g-1); slice g+1's k-step-0 fragments are read behind the k-step-1 MFMAs, so no MFMA
+    // waits on an LDS round trip. ONE barrier per step, in the middle: before it every wave has waited for its own DMAs of slice
+    // g+1 (slices g+2, g+3 = 8 instructions stay in flight) and for its own LDS reads (lgkmcnt(0): slice g's stage is no longer
+    // read by anybody), after it slice g+1 is visible to all and slice g+4 is sent into slice g's stage: three slices (96 KB)
+    // of look-ahead in a ring of four stages.
     f16x8 xa[MI], xb[NI], ya[MI], yb[NI];
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");      // slice 0 (and the first |c|^2 row) landed
+    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");     // slice 0 (and the first |c|^2 row) landed
     {
         const float* cnp = sCn + wr * (MI * 32) + 4 * h;
 #pragma unroll
@@ -618,8 +619,6 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
     }
     int t = 0, kc = 0;
     for (int g = 0; g < G; ++g) {
-        if (!(DBG & 32)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (!(DBG & 4) || g < 4) issue();                               // slice g+3 -> the stage of slice g-1
         const u16* st = ring + (g & (RG_STAGES - 1)) * RG_STAGE_HALVES;
         const u16* sn = ring + ((g + 1) & (RG_STAGES - 1)) * RG_STAGE_HALVES;
         if (!(DBG & 16) || g == 0) {
@@ -637,6 +636,8 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
                 if (!(DBG & 2)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[mi], xb[ni], acc[mi][ni], 0, 0, 0);
                 else acc[mi][ni][0] += (float)xa[mi][0] * (float)xb[ni][0];
         __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 32)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!(DBG & 4) || g < 4) issue();                               // slice g+4 -> the stage of slice g
         if (!(DBG & 16)) {
 #pragma unroll
         for (int n = 0; n < NI; ++n) xb[n] = *(const f16x8*)(sn + fragB + n * 32 * KB + so0);
