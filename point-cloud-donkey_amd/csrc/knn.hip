@@ -494,6 +494,12 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_mfma16(const u16* __
     }
 }
 
+// |c|^2 / out_scale for every codebook row (out_scale is known on the device only: it holds the batch's query scale)
+__global__ void k_scale_norms(const float* __restrict__ norm, int n, const float* __restrict__ out_scale, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = norm[i] * (1.0f / out_scale[0]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // f16 candidates, LDS-DMA ring (the default squared-L2 kernel for big launches)
 // ---------------------------------------------------------------------------------------------
@@ -578,9 +584,9 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
 #pragma unroll
     for (int n = 0; n < NI; ++n) top[n].init();
     // The accumulators start at |c|^2 / out_scale instead of 0 (out_scale = -2/(s_q s_c) < 0, a power of two up to the factor -2,
-    // so the product is exact): after the last slice acc = (|c|^2 - 2 c.q) / out_scale, and ranking the scores ascending is ranking
-    // acc DESCENDING. The epilogue is then one compare per value against the lane's current threshold; TopT keeps -acc.
-    const float inv_os = 1.0f / oscale;
+    // so the division is exact; word_norm here is that pre-scaled row, see k_scale_norms): after the last slice
+    // acc = (|c|^2 - 2 c.q) / out_scale, and ranking the scores ascending is ranking acc DESCENDING. The epilogue is then one
+    // compare per value against the lane's current threshold; TopT keeps -acc.
     float thr[NI];
 #pragma unroll
     for (int n = 0; n < NI; ++n) thr[n] = -__builtin_inff();
@@ -603,15 +609,6 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
     f16x8 xa[MI], xb[NI], ya[MI], yb[NI];
     asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");     // slice 0 (and the first |c|^2 row) landed
     {
-        const float* cnp = sCn + wr * (MI * 32) + 4 * h;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float c0 = cnp[mi * 32 + (e & 3) + 8 * (e >> 2)] * inv_os;
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni][e] = c0;
-            }
 #pragma unroll
         for (int n = 0; n < NI; ++n) xb[n] = *(const f16x8*)(ring + fragB + n * 32 * KB + so0);
 #pragma unroll
@@ -629,12 +626,29 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+        if (kc == 0) {
+            // first slice of tile t: the accumulators START from the tile's row of |c|^2 / out_scale (pre-scaled per launch by
+            // k_scale_norms, landed by DMA with this slice), passed as the C operand -- no re-arming moves in the epilogue
+            const float* cnp = sCn + (t & 3) * BM + wr * (MI * 32) + 4 * h;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                f32x16 c0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = *(const f32x4*)(cnp + mi * 32 + 8 * j);     // rows 8j + 4h + 0..3 = elements 4j..4j+3
+                    c0[4 * j] = v[0]; c0[4 * j + 1] = v[1]; c0[4 * j + 2] = v[2]; c0[4 * j + 3] = v[3];
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[mi], xb[ni], c0, 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 if (!(DBG & 2)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[mi], xb[ni], acc[mi][ni], 0, 0, 0);
                 else acc[mi][ni][0] += (float)xa[mi][0] * (float)xb[ni][0];
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (!(DBG & 32)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (!(DBG & 4) || g < 4) issue();                               // slice g+4 -> the stage of slice g
@@ -656,23 +670,22 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
         if (++kc == nk) {
             // epilogue of tile t. A lane inserts ~ (T+1)/n of the n values it has seen, so after the first tiles a 64-lane vector of
             // values rarely holds an insertion: each vector is tested at wave level and the insertion code runs only for those.
-            // The accumulator is re-armed with the next tile's |c|^2 row, which landed with slice g+1.
-            const int row0 = (mt0 + t) * BM + wr * (MI * 32) + 4 * h;
-            const float* cnp = sCn + ((t + 1) & 3) * BM + wr * (MI * 32) + 4 * h;
+                        const int row0 = (mt0 + t) * BM + wr * (MI * 32) + 4 * h;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float c0 = cnp[mi * 32 + (e & 3) + 8 * (e >> 2)] * inv_os;
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
                         const float a = acc[mi][ni][e];
                         if (DBG & 1) { if (e == 0) top[ni].v[0] += a; }
                         else if (__builtin_expect(__any(a > thr[ni]), 0)) {
+                            if (DBG & 256) { top[ni].i[0] += 1; }
+                            else {
                             if (a > thr[ni]) top[ni].push(-a, row0 + mi * 32 + (e & 3) + 8 * (e >> 2));
                             thr[ni] = fmaxf(thr[ni], -top[ni].v[T]);
+                            }
                         }
-                        acc[mi][ni][e] = c0;
                     }
                 }
 #pragma unroll
@@ -1235,7 +1248,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     case 5: rk = (const void*)k_knn_l2_ring<T, 5>; break;  case 7: rk = (const void*)k_knn_l2_ring<T, 7>; break;
                     case 9: rk = (const void*)k_knn_l2_ring<T, 9>; break;  case 13: rk = (const void*)k_knn_l2_ring<T, 13>; break;
                     case 15: rk = (const void*)k_knn_l2_ring<T, 15>; break; case 11: rk = (const void*)k_knn_l2_ring<T, 11>; break;
-                    case 21: rk = (const void*)k_knn_l2_ring<T, 21>; break; case 64: rk = (const void*)k_knn_l2_ring<T, 64>; break; case 128: rk = (const void*)k_knn_l2_ring<T, 128>; break; case 192: rk = (const void*)k_knn_l2_ring<T, 192>; break; case 53: rk = (const void*)k_knn_l2_ring<T, 53>; break; case 37: rk = (const void*)k_knn_l2_ring<T, 37>; break;
+                    case 21: rk = (const void*)k_knn_l2_ring<T, 21>; break; case 256: rk = (const void*)k_knn_l2_ring<T, 256>; break; case 64: rk = (const void*)k_knn_l2_ring<T, 64>; break; case 128: rk = (const void*)k_knn_l2_ring<T, 128>; break; case 192: rk = (const void*)k_knn_l2_ring<T, 192>; break; case 53: rk = (const void*)k_knn_l2_ring<T, 53>; break; case 37: rk = (const void*)k_knn_l2_ring<T, 37>; break;
                     default: break;
                 }
 #endif
@@ -1243,7 +1256,12 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 static bool rattr = false;
                 if (ctx->knn_dbg) rattr = false;
                 if (!rattr) { ISM_HIP(ctx, hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds)); rattr = true; }
-                const float* word_norm = cb->word_norm; const float* osc = (const float*)(qsc + 1);
+                const float* osc = (const float*)(qsc + 1);
+                float* cn_scaled = (float*)ism_scratch(ctx, SCR_QNORM2, (size_t)cb->n_words_pad * sizeof(float));
+                if (!cn_scaled) return ISMHIP_ERR_NOMEM;
+                hipLaunchKernelGGL(k_scale_norms, dim3((cb->n_words_pad + 255) / 256), dim3(256), 0, ctx->stream, cb->word_norm, cb->n_words_pad, osc, cn_scaled);
+                ISM_CHECK_LAUNCH(ctx, "k_scale_norms");
+                const float* word_norm = cn_scaled;
                 int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
                 const u16* qh_ = q_hi;
                 void* rargs[] = {&wh, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb};

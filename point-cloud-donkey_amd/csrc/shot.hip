@@ -132,9 +132,15 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
     shot_hard_bin(5.f, cosd, 5.5f, 5.f, step, bd);                                // bin = floor(((1 + cos) * 10) / 2 + 0.5), bd = offset from its centre
     const int vol = di * 11;
     float w_shape = 1.f - fabsf(bd);
-    if (bd > 0.f) shot_dep(hist, vol + ((step + 1) % 10), bd);
-    else shot_dep(hist, vol + ((step - 1 + 10) % 10), -bd);
-
+    // Everything below is branch-free: each of the four interpolation directions yields ONE (neighbouring bin, weight) pair
+    // chosen by selects -- written as the reference's if/else ladders it compiled into eight divergent deposit sites with
+    // partial exec masks and their branch overhead. The float operations (and so the results) are the same: in the "deposit"
+    // case of every ladder the reference adds 1 -/+ t with t of the sign that makes it 1 - |t|, and deposits |t|.
+    {
+        int t = bd > 0.f ? step + 1 : step + 9;                                   // (step + 1) % 10 | (step - 1 + 10) % 10, step in 0..10
+        t = t >= 10 ? t - 10 : t;
+        shot_dep(hist, vol + t, fabsf(bd));
+    }
     int step_c = 0, vol_c = 0; float w_col = 0.f;
     if (COLOR) {
         const float L = a.sL[gi], A = a.sa[gi], B = a.sb[gi];
@@ -144,48 +150,40 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
         shot_hard_bin(30.f, cd, 0.5f, 0.f, step_c, bc);                           // colorDistance (float) * nr_color_bins_, taken in double by the reference
         vol_c = 352 + di * 31;
         w_col = 1.f - fabsf(bc);
-        if (bc > 0.f) shot_dep(hist, vol_c + ((step_c + 1) % 30), bc);
-        else shot_dep(hist, vol_c + ((step_c - 1 + 30) % 30), -bc);
+        int t = bc > 0.f ? step_c + 1 : step_c + 29;                              // % 30
+        t = t >= 30 ? t - 30 : t;
+        shot_dep(hist, vol_c + t, fabsf(bc));
     }
-#define SHOT_DEP(sector, v)                                                          \
-    do {                                                                             \
-        shot_dep(hist, (sector) * 11 + step, (v));                                   \
-        if (COLOR) shot_dep(hist, 352 + (sector) * 31 + step_c, (v));                \
-    } while (0)
     float winc = 0.f;
-    // radial
-    if (outer) {
-        const float rd = (dist - r34) * inv_r12;
-        if (dist > r34) winc += 1.f - rd;
-        else { winc += 1.f + rd; SHOT_DEP(di - 2, -rd); }
-    } else {
-        const float rd = (dist - r14) * inv_r12;
-        if (dist < r14) winc += 1.f + rd;
-        else { winc += 1.f - rd; SHOT_DEP(di + 2, rd); }
-    }
+    // radial: outer shell interpolates towards the inner one below 3r/4, inner shell towards the outer one above r/4
+    const float xr = outer ? (dist - r34) * inv_r12 : -((dist - r14) * inv_r12);
+    const float wr_ = xr > 0.f ? 0.f : fabsf(xr);
+    winc += 1.f - fabsf(xr);
+    const int sec_r = outer ? di - 2 : di + 2;
     // elevation
     float ic = zl * __builtin_amdgcn_rcpf(dist);
     ic = fminf(1.0f, fmaxf(-1.0f, ic));
     const float inc = shot_acos(ic);
-    if (!(zl > 0.f)) {        // inclination > 90 deg, or exactly 90 deg with z <= 0: the same test that picked the sector's elevation bit
-        const float id = (inc - PST_RAD_135f) * (1.0f / PST_RAD_90f);
-        if (inc > PST_RAD_135f) winc += 1.f - id;
-        else { winc += 1.f + id; SHOT_DEP(di + 1, -id); }
-    } else {
-        const float id = (inc - PST_RAD_45f) * (1.0f / PST_RAD_90f);
-        if (inc < PST_RAD_45f) winc += 1.f + id;
-        else { winc += 1.f - id; SHOT_DEP(di - 1, id); }
-    }
+    const bool lower = !(zl > 0.f);   // inclination > 90 deg, or exactly 90 deg with z <= 0: the same test that picked the sector's elevation bit
+    const float ide = (inc - (lower ? PST_RAD_135f : PST_RAD_45f)) * (1.0f / PST_RAD_90f);
+    const float xe = lower ? ide : -ide;
+    const float we = xe > 0.f ? 0.f : fabsf(xe);
+    winc += 1.f - fabsf(xe);
+    const int sec_e = lower ? di + 1 : di - 1;
     // azimuth
+    float wa = 0.f; int sec_a = di;
     if (yl != 0.f || xl != 0.f) {
         const float az = shot_atan2(yl, xl);
         const int sel = di >> 2;
         float ad = (az - (-PST_RAD_PI_7_8f + PST_RAD_45f * (float)sel)) * (1.0f / PST_RAD_45f);
         ad = fmaxf(-0.5f, fminf(ad, 0.5f));
-        if (ad > 0.f) { winc += 1.f - ad; SHOT_DEP((di + 4) % 32, ad); }
-        else { winc += 1.f + ad; SHOT_DEP((di - 4 + 32) % 32, -ad); }
+        wa = fabsf(ad);
+        winc += 1.f - wa;
+        sec_a = (ad > 0.f ? di + 4 : di - 4) & 31;
     }
-#undef SHOT_DEP
+    if (wr_ != 0.f) { shot_dep(hist, sec_r * 11 + step, wr_); if (COLOR) shot_dep(hist, 352 + sec_r * 31 + step_c, wr_); }
+    if (we != 0.f) { shot_dep(hist, sec_e * 11 + step, we); if (COLOR) shot_dep(hist, 352 + sec_e * 31 + step_c, we); }
+    if (wa != 0.f) { shot_dep(hist, sec_a * 11 + step, wa); if (COLOR) shot_dep(hist, 352 + sec_a * 31 + step_c, wa); }
     shot_dep(hist, vol + step, w_shape + winc);
     if (COLOR) shot_dep(hist, vol_c + step_c, w_col + winc);
 }
