@@ -115,6 +115,17 @@ int  ismhip_fpfh33(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* k
 int  ismhip_center_dist(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_offsets_h,
                         const float* kpx, const float* kpy, const float* kpz, float* out);
 
+/* ---- keypoints (the step in front of the path): KeypointsVoxelGrid::iComputeKeypoints
+ *      (keypoints/keypoints_voxel_grid.cpp:30-46) -> pcl::VoxelGrid<PointXYZRGB> with a cubic leaf. Per object the
+ *      centroids (xyz, and rgb when rgba is given) of the occupied voxels in ascending voxel index, packed object
+ *      after object into kx|ky|kz[|krgba] (device, `capacity` entries; the number of points always suffices);
+ *      kp_offsets_h_out[n_obj+1] (host) receives the per-object ranges. Non-finite points are ignored. The call
+ *      synchronises. */
+int  ismhip_voxel_keypoints(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_h,
+                            const float* x, const float* y, const float* z, const uint32_t* rgba, float leaf,
+                            uint32_t capacity, float* kx, float* ky, float* kz, uint32_t* krgba,
+                            uint32_t* kp_offsets_h_out);
+
 /* ---- feature filtering: Features::operator() drops non-finite LRFs (features.cpp:66-76),
  *      ImplicitShapeModel::removeNaNFeatures drops NaN descriptors (implicit_shape_model.cpp:1276-1308).
  *      Stable stream compaction of rows; keep_offsets_h_out[n_obj+1] (host) receives the new per-object

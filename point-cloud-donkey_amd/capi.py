@@ -23,7 +23,7 @@ EXPORTS = [
     "ismhip_timers_enable", "ismhip_timers_reset", "ismhip_timer_get",
     "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids",
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
-    "ismhip_compact_features",
+    "ismhip_compact_features", "ismhip_voxel_keypoints",
     "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word",
     "ismhip_knn", "ismhip_knn_ratio", "ismhip_knn_rule", "ismhip_cast_votes", "ismhip_find_maxima",
 ]
@@ -246,6 +246,21 @@ def center_dist(ctx, cloud, kp_offsets, kpx, kpy, kpz):
     out = torch.empty((int(ko[-1]),), dtype=torch.float32, device=kpx.device)
     ctx.check(lib().ismhip_center_dist(ctx._h, cloud._h, _p(ko), _p(kpx), _p(kpy), _p(kpz), _p(out)), "ismhip_center_dist")
     return out
+
+
+def voxel_keypoints(ctx, pt_offsets, x, y, z, leaf, rgba=None):
+    """KeypointsVoxelGrid on the device: returns (kp_offsets[n_obj+1] numpy, kx, ky, kz, krgba or None) packed object after object"""
+    torch = _torch()
+    po = _u32(pt_offsets)
+    n_obj = len(po) - 1
+    n = int(po[-1])
+    kx = torch.empty((n,), dtype=torch.float32, device=x.device); ky = torch.empty_like(kx); kz = torch.empty_like(kx)
+    kc = torch.empty((n,), dtype=torch.int32, device=x.device) if rgba is not None else None
+    ko = np.zeros(n_obj + 1, dtype=np.uint32)
+    ctx.check(lib().ismhip_voxel_keypoints(ctx._h, C.c_int(n_obj), _p(po), _p(x), _p(y), _p(z), _p(rgba), C.c_float(leaf), C.c_uint32(n),
+                                           _p(kx), _p(ky), _p(kz), _p(kc), _p(ko)), "ismhip_voxel_keypoints")
+    m = int(ko[-1])
+    return ko, kx[:m], ky[:m], kz[:m], (kc[:m] if kc is not None else None)
 
 
 def compact_features(ctx, kp_offsets, desc, lrf, kpx, kpy, kpz):

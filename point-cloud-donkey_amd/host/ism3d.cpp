@@ -93,8 +93,13 @@ public:
         if (n && hipMemcpy(v.data(), b.p, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) throw RuntimeException("hipMemcpy D2H failed");
     }
     // concatenates the objects into SoA arrays, uploads them and builds the search surface
-    void uploadBatch(const std::vector<const PointCloud*>& clouds, const std::vector<KeypointSet>& kps, float cell, bool with_color) {
+    // kps == nullptr: voxel-grid keypoints are computed on the device (ismhip_voxel_keypoints) with leaf `device_leaf`
+    void uploadBatch(const std::vector<const PointCloud*>& clouds, const std::vector<KeypointSet>* kps_p, float cell, bool with_color, float device_leaf = 0.f) {
+        static const std::vector<KeypointSet> no_kps;
+        const bool dev_kp = kps_p == nullptr;
         n_obj = (int)clouds.size();
+        const std::vector<KeypointSet>& kps = dev_kp ? no_kps : *kps_p;
+        static const KeypointSet empty_set;
         pt_off.assign(1, 0); kp_off.assign(1, 0);
         std::vector<float> hx, hy, hz, hnx, hny, hnz, hkx, hky, hkz;
         std::vector<uint32_t> hrgba, hkrgba;
@@ -107,7 +112,7 @@ public:
                 else hrgba.insert(hrgba.end(), c.size(), 0u);
             }
             pt_off.push_back((uint32_t)hx.size());
-            const KeypointSet& k = kps[o];
+            const KeypointSet& k = dev_kp ? empty_set : kps[o];
             hkx.insert(hkx.end(), k.x.begin(), k.x.end()); hky.insert(hky.end(), k.y.begin(), k.y.end()); hkz.insert(hkz.end(), k.z.begin(), k.z.end());
             if (with_color) {
                 if (k.rgba.size() == k.size()) hkrgba.insert(hkrgba.end(), k.rgba.begin(), k.rgba.end());
@@ -116,9 +121,22 @@ public:
             kp_off.push_back((uint32_t)hkx.size());
         }
         if (cloud) { ismhip_cloud_destroy(ctx, cloud); cloud = nullptr; }
-        h2d(x, hx); h2d(y, hy); h2d(z, hz); h2d(nx, hnx); h2d(ny, hny); h2d(nz, hnz); h2d(kx, hkx); h2d(ky, hky); h2d(kz, hkz);
+        h2d(x, hx); h2d(y, hy); h2d(z, hz); h2d(nx, hnx); h2d(ny, hny); h2d(nz, hnz);
         has_color = with_color;
-        if (with_color) { h2d(rgba, hrgba); h2d(krgba, hkrgba); }
+        if (with_color) h2d(rgba, hrgba);
+        if (dev_kp) {
+            // KeypointsVoxelGrid::iComputeKeypoints on the device: centroids stay in HBM, only the per-object counts come back
+            const size_t n_pts = hx.size();
+            kx.reserve(std::max<size_t>(n_pts, 1) * 4); ky.reserve(std::max<size_t>(n_pts, 1) * 4); kz.reserve(std::max<size_t>(n_pts, 1) * 4);
+            if (with_color) krgba.reserve(std::max<size_t>(n_pts, 1) * 4);
+            kp_off.assign((size_t)n_obj + 1, 0);
+            check(ismhip_voxel_keypoints(ctx, n_obj, pt_off.data(), x.as<float>(), y.as<float>(), z.as<float>(), with_color ? rgba.as<uint32_t>() : nullptr,
+                                         device_leaf, (uint32_t)n_pts, kx.as<float>(), ky.as<float>(), kz.as<float>(),
+                                         with_color ? krgba.as<uint32_t>() : nullptr, kp_off.data()), "ismhip_voxel_keypoints");
+        } else {
+            h2d(kx, hkx); h2d(ky, hky); h2d(kz, hkz);
+            if (with_color) h2d(krgba, hkrgba);
+        }
         check(ismhip_cloud_create(ctx, n_obj, pt_off.data(), x.as<float>(), y.as<float>(), z.as<float>(), nx.as<float>(), ny.as<float>(),
                                   nz.as<float>(), with_color ? rgba.as<uint32_t>() : nullptr, cell, &cloud), "ismhip_cloud_create");
     }
@@ -728,16 +746,25 @@ static bool firstNormalValid(const PointCloud& c) {   // :615-625 — decided fr
 std::shared_ptr<DeviceFeatures> ImplicitShapeModel::computeFeatures(const std::vector<const PointCloud*>& clouds, bool) {   // :733-927
     DeviceSession& s = session();
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<KeypointSet> kps;
-    for (const PointCloud* c : clouds) {
+    for (const PointCloud* c : clouds)
         if (!firstNormalValid(*c)) throw RuntimeException("input cloud has no normals: normal estimation on the device is not built yet (SURVEY §8f row 3)");
-        kps.push_back((*m_keypoints_detector)(*c));
-    }
-    auto t1 = std::chrono::steady_clock::now();
-    m_processing_times["keypoints"] += std::chrono::duration<double, std::milli>(t1 - t0).count();
     const float cell = std::min(m_feature_descriptor->getRadius(), m_feature_descriptor->getType() == "FPFH" ? m_feature_descriptor->getRadius()
                                                                                                            : m_feature_descriptor->getReferenceFrameRadius()) * 0.5f;
-    s.uploadBatch(clouds, kps, cell, m_feature_descriptor->needsColor());
+    // VoxelGrid keypoints are taken on the device with the batch (ismhip_voxel_keypoints); any other detector, or
+    // ISM3D_HOST_KEYPOINTS=1, runs the host implementation per object and uploads its result
+    const auto* vg = dynamic_cast<const KeypointsVoxelGrid*>(m_keypoints_detector.get());
+    const char* host_kp = getenv("ISM3D_HOST_KEYPOINTS");
+    auto t1 = t0;
+    if (vg && !(host_kp && host_kp[0] == '1')) {
+        s.uploadBatch(clouds, nullptr, cell, m_feature_descriptor->needsColor(), vg->getLeafSize());
+        t1 = std::chrono::steady_clock::now();
+    } else {
+        std::vector<KeypointSet> kps;
+        for (const PointCloud* c : clouds) kps.push_back((*m_keypoints_detector)(*c));
+        t1 = std::chrono::steady_clock::now();
+        s.uploadBatch(clouds, &kps, cell, m_feature_descriptor->needsColor());
+    }
+    m_processing_times["keypoints"] += std::chrono::duration<double, std::milli>(t1 - t0).count();
     auto f = (*m_feature_descriptor)(s);
     s.sync();
     m_processing_times["features"] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();

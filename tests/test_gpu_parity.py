@@ -388,6 +388,36 @@ def test_knn_ties_kat_and_ratio(pkg, gpu, ora):
         assert np.array_equal(gd.cpu().numpy(), wd)
 
 
+# ------------------------------------------------------------------------------------------------ keypoints (the step in front of the path)
+@pytest.mark.parametrize("leaf,color", [(0.1, False), (0.05, True), (0.37, True)])
+def test_voxel_keypoints_match_oracle(pkg, gpu, ora, leaf, color):
+    """KeypointsVoxelGrid (pcl::VoxelGrid centroids in ascending voxel index): counts, order and colours exact, positions to 1e-6
+    relative (the device sums in 64-bit fixed point, the reference in float). Ragged batch with an empty object, non-finite
+    points, negative coordinates and a single-point object."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(int(leaf * 1000))
+    sizes = [5000, 0, 1, 12345, 777]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    n = int(off[-1])
+    xyz = (rng.random((n, 3)) * np.array([2.0, 1.0, 3.0]) - np.array([1.0, 0.2, 2.5])).astype(np.float32)
+    xyz[off[3]:off[4]] *= 0.3                                             # a denser object
+    xyz[17] = np.nan; xyz[int(off[3]) + 5, 1] = np.inf                    # ignored, as pcl::VoxelGrid skips non-finite points
+    rgba = rng.integers(0, 1 << 24, n, dtype=np.uint32) if color else None
+    ko, kx, ky, kz, kc = pkg.capi.voxel_keypoints(ctx, off, T(xyz[:, 0].copy(), dev), T(xyz[:, 1].copy(), dev), T(xyz[:, 2].copy(), dev), leaf,
+                                                  rgba=T(rgba.view(np.int32), dev) if color else None)
+    kx, ky, kz = kx.cpu().numpy(), ky.cpu().numpy(), kz.cpu().numpy()
+    for o in range(len(sizes)):
+        s, e = int(off[o]), int(off[o + 1])
+        wx, wy, wz, wc = ora.voxel_grid(xyz[s:e, 0], xyz[s:e, 1], xyz[s:e, 2], leaf, rgba[s:e] if color else None)
+        a, b = int(ko[o]), int(ko[o + 1])
+        assert b - a == len(wx), (o, b - a, len(wx))
+        for got, want in ((kx[a:b], wx), (ky[a:b], wy), (kz[a:b], wz)):
+            np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
+        if color:
+            assert np.array_equal(kc.cpu().numpy()[a:b].view(np.uint32), wc)
+    assert ko[2] - ko[1] == 0 and ko[3] - ko[2] == 1
+
+
 # ------------------------------------------------------------------------------------------------ votes + maxima
 @pytest.mark.parametrize("flags", [0, 1, 2, 4, 8, 15])
 def test_cast_votes_matches_oracle(pkg, gpu, ora, flags):
