@@ -87,6 +87,12 @@ int  ismhip_cloud_create(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_
                          const float* nx, const float* ny, const float* nz,
                          const uint32_t* rgba, float cell_size, ismhip_cloud** out);
 int  ismhip_cloud_destroy(ismhip_ctx* ctx, ismhip_cloud* cloud);
+/* Normals for clouds that come without them: ImplicitShapeModel::computeNormals, ConsistentNormalsMethod 2 (the default,
+ * implicit_shape_model.cpp:1014-1018) -> NormalOrientation::processSHOTLRF (utils/normal_orientation.cpp:48-110): a SHOT
+ * frame of radius NormalRadius at every point, normal = inverted z axis; NaN where the frame is invalid (< 5 neighbours).
+ * The cloud may have been created with any normal arrays (their values are not read before this call); the outputs
+ * (device, original point order, may alias the arrays given to ismhip_cloud_create) also replace the cloud's normals. */
+int  ismhip_estimate_normals(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, float* nx_out, float* ny_out, float* nz_out);
 /* per-object centroid (features_shot.cpp:45-51) -> centroid_out[n_obj*3] */
 int  ismhip_cloud_centroids(ismhip_ctx* ctx, const ismhip_cloud* cloud, float* centroid_out);
 

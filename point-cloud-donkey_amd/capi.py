@@ -21,7 +21,7 @@ ERR_NODEVICE = -5
 EXPORTS = [
     "ismhip_abi_version", "ismhip_ctx_create", "ismhip_ctx_create_on_stream", "ismhip_ctx_destroy", "ismhip_sync", "ismhip_last_error",
     "ismhip_timers_enable", "ismhip_timers_reset", "ismhip_timer_get",
-    "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids",
+    "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids", "ismhip_estimate_normals",
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
     "ismhip_compact_features", "ismhip_voxel_keypoints",
     "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word",
@@ -246,6 +246,13 @@ def center_dist(ctx, cloud, kp_offsets, kpx, kpy, kpz):
     out = torch.empty((int(ko[-1]),), dtype=torch.float32, device=kpx.device)
     ctx.check(lib().ismhip_center_dist(ctx._h, cloud._h, _p(ko), _p(kpx), _p(kpy), _p(kpz), _p(out)), "ismhip_center_dist")
     return out
+
+
+def estimate_normals(ctx, cloud, radius, nx, ny, nz):
+    """ImplicitShapeModel::computeNormals (method 2): fills nx, ny, nz (device tensors, original order) and the cloud's own copies"""
+    ctx.check(lib().ismhip_estimate_normals(ctx._h, cloud._h, C.c_float(radius), _p(nx), _p(ny), _p(nz)), "ismhip_estimate_normals")
+    cloud._keep = getattr(cloud, "_keep", ()) + (nx, ny, nz)
+    return nx, ny, nz
 
 
 def voxel_keypoints(ctx, pt_offsets, x, y, z, leaf, rgba=None):

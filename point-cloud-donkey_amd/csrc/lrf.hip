@@ -331,3 +331,48 @@ extern "C" int ismhip_shot_lrf(ismhip_ctx* ctx, const ismhip_cloud* cloud, const
     ISM_CHECK_LAUNCH(ctx, "k_lrf_tie");
     return ISMHIP_OK;
 }
+
+
+// ---- normals from the SHOT frame (the step in front of the path) -------------------------------------------
+// Reference seam: ImplicitShapeModel::computeNormals with ConsistentNormalsMethod 2, the default (implicit_shape_model.cpp:
+// 1014-1018) -> NormalOrientation::processSHOTLRF (utils/normal_orientation.cpp:48-110): a SHOT frame with radius NormalRadius at
+// EVERY point of the cloud, normal = inverted z axis. Points whose frame is invalid (< 5 neighbours) get a NaN normal here and are
+// dropped as "points with NaN normals" later; the reference patches them through a mis-indexed loop (it recomputes the normals of
+// points 0..k-1 instead of the k invalid ones, normal_orientation.cpp:92-104) -- that accident is not reproduced.
+namespace {
+__global__ __launch_bounds__(256) void k_normals_from_lrf(uint32_t n, const float* __restrict__ lrf, float* __restrict__ nx, float* __restrict__ ny, float* __restrict__ nz) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* f = lrf + (size_t)i * 9;
+    const bool ok = isfinite(f[0]) && isfinite(f[3]) && isfinite(f[6]);
+    const float q = __builtin_nanf("");
+    nx[i] = ok ? -f[6] : q; ny[i] = ok ? -f[7] : q; nz[i] = ok ? -f[8] : q;
+}
+// the cloud's cell-sorted normal copies follow (sorted position s of object o holds original point sorig[s])
+__global__ __launch_bounds__(256) void k_sorted_normals(const uint32_t* __restrict__ pt_off, const GridMeta* __restrict__ meta, const uint32_t* __restrict__ sorig,
+                                                        const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz,
+                                                        float* __restrict__ snx, float* __restrict__ sny, float* __restrict__ snz) {
+    const int o = blockIdx.y;
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= meta[o].n_finite) return;
+    const uint32_t base = pt_off[o], src = base + sorig[base + s];
+    snx[base + s] = nx[src]; sny[base + s] = ny[src]; snz[base + s] = nz[src];
+}
+}  // namespace
+
+extern "C" int ismhip_estimate_normals(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, float* nx_out, float* ny_out, float* nz_out) {
+    if (!ctx || !cloud || !nx_out || !ny_out || !nz_out || !(radius > 0.f)) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "estimate_normals: bad argument");
+    const uint32_t n = cloud->n_pts;
+    if (n == 0) return ISMHIP_OK;
+    float* lrf = (float*)ism_scratch(ctx, SCR_FPFH_SPFH, (size_t)n * 9 * sizeof(float));
+    if (!lrf) return ISMHIP_ERR_NOMEM;
+    int rc = ismhip_shot_lrf(ctx, cloud, cloud->pt_off_h.data(), cloud->x, cloud->y, cloud->z, radius, lrf);
+    if (rc != ISMHIP_OK) return rc;
+    hipLaunchKernelGGL(k_normals_from_lrf, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, lrf, nx_out, ny_out, nz_out);
+    ISM_CHECK_LAUNCH(ctx, "k_normals_from_lrf");
+    hipLaunchKernelGGL(k_sorted_normals, dim3((cloud->max_pts + 255) / 256, cloud->n_obj), dim3(256), 0, ctx->stream, cloud->pt_off, cloud->meta, cloud->sorig,
+                       nx_out, ny_out, nz_out, cloud->snx, cloud->sny, cloud->snz);
+    ISM_CHECK_LAUNCH(ctx, "k_sorted_normals");
+    cloud->nx = nx_out; cloud->ny = ny_out; cloud->nz = nz_out;
+    return ISMHIP_OK;
+}

@@ -743,11 +743,51 @@ static bool firstNormalValid(const PointCloud& c) {   // :615-625 — decided fr
     return true;
 }
 
-std::shared_ptr<DeviceFeatures> ImplicitShapeModel::computeFeatures(const std::vector<const PointCloud*>& clouds, bool) {   // :733-927
+std::shared_ptr<DeviceFeatures> ImplicitShapeModel::computeFeatures(const std::vector<const PointCloud*>& clouds_in, bool) {   // :733-927
     DeviceSession& s = session();
     auto t0 = std::chrono::steady_clock::now();
-    for (const PointCloud* c : clouds)
-        if (!firstNormalValid(*c)) throw RuntimeException("input cloud has no normals: normal estimation on the device is not built yet (SURVEY §8f row 3)");
+    // clouds that come without normals get them on the device (computeNormals :940-1032, ConsistentNormalsMethod 2), then lose the
+    // points whose normal is NaN (filterNormals :1034-1075); the features are computed on those completed copies
+    std::vector<const PointCloud*> clouds = clouds_in;
+    std::vector<std::unique_ptr<PointCloud>> completed;
+    {
+        std::vector<size_t> need;
+        for (size_t i = 0; i < clouds.size(); ++i) if (!firstNormalValid(*clouds[i])) need.push_back(i);
+        if (!need.empty()) {
+            if (m_consistent_normals_method != 2)
+                throw RuntimeException("input cloud has no normals and ConsistentNormalsMethod " + std::to_string(m_consistent_normals_method) +
+                                       " is not built (built: 2 = SHOT reference frames)");
+            std::vector<std::unique_ptr<PointCloud>> tmp;
+            std::vector<const PointCloud*> part;
+            for (size_t i : need) {
+                tmp.emplace_back(new PointCloud(*clouds[i]));
+                PointCloud& c = *tmp.back();
+                c.nx.assign(c.size(), 0.f); c.ny.assign(c.size(), 0.f); c.nz.assign(c.size(), 0.f);
+                part.push_back(&c);
+            }
+            const std::vector<KeypointSet> none(part.size());
+            s.uploadBatch(part, &none, m_normal_radius * 0.5f, false);
+            s.check(ismhip_estimate_normals(s.ctx, s.cloud, m_normal_radius, s.nx.as<float>(), s.ny.as<float>(), s.nz.as<float>()), "ismhip_estimate_normals");
+            std::vector<float> hnx, hny, hnz;
+            const size_t n_all = s.pt_off.back();
+            s.d2h(hnx, s.nx, n_all); s.d2h(hny, s.ny, n_all); s.d2h(hnz, s.nz, n_all);
+            for (size_t k = 0; k < need.size(); ++k) {
+                const PointCloud& src = *tmp[k];
+                std::unique_ptr<PointCloud> out(new PointCloud());
+                const size_t b = s.pt_off[k];
+                const bool col = src.rgba.size() == src.size();
+                for (size_t i = 0; i < src.size(); ++i) {
+                    const float a = hnx[b + i], bb = hny[b + i], cc = hnz[b + i];
+                    if (std::isnan(a) || std::isnan(bb) || std::isnan(cc)) continue;
+                    out->x.push_back(src.x[i]); out->y.push_back(src.y[i]); out->z.push_back(src.z[i]);
+                    out->nx.push_back(a); out->ny.push_back(bb); out->nz.push_back(cc);
+                    if (col) out->rgba.push_back(src.rgba[i]);
+                }
+                clouds[need[k]] = out.get();
+                completed.push_back(std::move(out));
+            }
+        }
+    }
     const float cell = std::min(m_feature_descriptor->getRadius(), m_feature_descriptor->getType() == "FPFH" ? m_feature_descriptor->getRadius()
                                                                                                            : m_feature_descriptor->getReferenceFrameRadius()) * 0.5f;
     // VoxelGrid keypoints are taken on the device with the batch (ismhip_voxel_keypoints); any other detector, or

@@ -418,6 +418,46 @@ def test_voxel_keypoints_match_oracle(pkg, gpu, ora, leaf, color):
     assert ko[2] - ko[1] == 0 and ko[3] - ko[2] == 1
 
 
+def test_estimate_normals_from_shot_frames(pkg, gpu, ora):
+    """ImplicitShapeModel::computeNormals, ConsistentNormalsMethod 2: normal = inverted z axis of the SHOT frame (radius NormalRadius)
+    at every point, NaN where the frame is invalid. The cloud is created with zero normals; after the call its own (cell-sorted)
+    normals must be the estimated ones too: SHOT-352 computed on that cloud has to match the oracle fed with the oracle's normals."""
+    ctx, dev = gpu
+    syn = pkg.synthetic
+    ds = syn.Dataset(3, 3, split=0, n_points=3000, n_keypoints=64)
+    nb = ds.batch(range(3))
+    xyz = nb["xyz"].copy()
+    xyz[5] += 50.0                                                        # an isolated point: invalid frame -> NaN normal
+    po = nb["pt_off"]
+    x, y, z = (T(xyz[:, i].copy(), dev) for i in range(3))
+    zeros = [T(np.zeros(len(xyz), np.float32), dev) for _ in range(3)]
+    r_n = 0.12
+    cloud = pkg.capi.Cloud(ctx, po, x, y, z, zeros[0], zeros[1], zeros[2], 0.15)
+    nx, ny, nz = pkg.capi.estimate_normals(ctx, cloud, r_n, *zeros)
+    got = np.stack([nx.cpu().numpy(), ny.cpu().numpy(), nz.cpu().numpy()], 1)
+    frames = ora.shot_lrf(po, xyz[:, 0], xyz[:, 1], xyz[:, 2], po, xyz[:, 0], xyz[:, 1], xyz[:, 2], r_n)
+    want = -frames[:, 6:9]
+    bad = ~np.isfinite(frames[:, 0])
+    want[bad] = np.nan
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got[5]).all()
+    ok = ~np.isnan(want[:, 0])
+    # an eigenvector of a near-degenerate covariance may flip or rotate in the last bits; all but a handful agree to 1e-5
+    err = np.abs(got[ok] - want[ok]).max(1)
+    assert (err < 1e-4).mean() > 0.999, (err > 1e-4).sum()
+    # descriptors on the same cloud use the refreshed normals
+    kp, ko = nb["kp"], nb["kp_off"]
+    kx, ky, kz = (T(kp[:, i].copy(), dev) for i in range(3))
+    lrf = pkg.capi.shot_lrf(ctx, cloud, ko, kx, ky, kz, 0.3)
+    desc, _ = pkg.capi.shot352(ctx, cloud, ko, kx, ky, kz, lrf, 0.4, want_counts=True)
+    wl = ora.shot_lrf(po, xyz[:, 0], xyz[:, 1], xyz[:, 2], ko, kp[:, 0], kp[:, 1], kp[:, 2], 0.3)
+    gn = got.copy()                                                        # the oracle gets the DEVICE normals: isolates the descriptor stage
+    wd, _ = ora.shot352(po, xyz[:, 0], xyz[:, 1], xyz[:, 2], gn[:, 0], gn[:, 1], gn[:, 2], ko, kp[:, 0], kp[:, 1], kp[:, 2], wl, 0.4)
+    d = desc.cpu().numpy()
+    assert np.array_equal(np.isnan(d).any(1), np.isnan(wd).any(1))
+    m = ~np.isnan(wd).any(1)
+    assert np.abs(d[m] - wd[m]).max() <= 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ votes + maxima
 @pytest.mark.parametrize("flags", [0, 1, 2, 4, 8, 15])
 def test_cast_votes_matches_oracle(pkg, gpu, ora, flags):

@@ -133,6 +133,28 @@ def test_host_train_write_read_detect_matches_python_harness(pkg, gpu, tmp_path)
 
 
 @pytest.mark.gpu
+def test_host_clouds_without_normals_get_them_on_the_device(pkg, gpu):
+    """Inputs whose first normal is zero/NaN count as normal-less (implicit_shape_model.cpp:615-625): the host layer then estimates
+    normals on the device (ConsistentNormalsMethod 2: inverted z axis of a SHOT frame with NormalRadius at every point), drops points
+    with NaN normals and carries on. Trained and tested without a single input normal, the synthetic objects must still be told apart."""
+    train, test = _dataset(pkg, 3, 9, 6)
+    order = sorted(range(9), key=lambda i: (train.label(i), i))
+    m = hb.Model()
+    m.config_from_json(_cfg(**{"Parameters/NormalRadius": 0.15}))
+    for i in order:
+        o = train.get(i)
+        m.add_training(o["xyz"], np.zeros_like(o["normals"]), o["label"], i)
+    m.train()
+    assert m.codebook_size() > 100
+    nb = test.batch(range(6))
+    got = m.detect_batch(nb["pt_off"], nb["xyz"], np.zeros_like(nb["normals"]), max_maxima=4)
+    assert (got["cls"][:, 0] == nb["labels"]).all()
+    m.config_from_json(_cfg(**{"Parameters/NormalRadius": 0.15, "Parameters/ConsistentNormalsMethod": 0}))
+    with pytest.raises(hb.HostError, match="ConsistentNormalsMethod 0 is not built"):
+        m.detect_batch(nb["pt_off"], nb["xyz"], np.zeros_like(nb["normals"]), max_maxima=4)
+
+
+@pytest.mark.gpu
 def test_eval_tool_end_to_end(pkg, tmp_path):
     train, test = _dataset(pkg, 3, 6, 6)
     names = ["chair", "table", "lamp"]
