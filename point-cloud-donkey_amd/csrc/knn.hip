@@ -565,7 +565,7 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
     auto issue = [&]() {
         u16* st = ring + (pg & (RG_STAGES - 1)) * RG_STAGE_HALVES + ddst;
         if (wv == 0 && pkc == 0) lds_dma16(word_norm + (size_t)(mt0 + pt) * BM + lane * 4, sCn + (pt & 3) * BM);
-        const char* sp = dbase + pt * tile_stride + (size_t)pkc * (BM * KB * 2);
+        const char* sp = ((DBG & 512) ? (dma_a ? (const char*)wh : (const char*)qh) + (wv & 3) * (64 * KB * 2) : dbase + pt * tile_stride) + (size_t)pkc * (BM * KB * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if ((DBG & 64) && dma_a) lds_dma16_nt(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);
@@ -1248,7 +1248,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     case 5: rk = (const void*)k_knn_l2_ring<T, 5>; break;  case 7: rk = (const void*)k_knn_l2_ring<T, 7>; break;
                     case 9: rk = (const void*)k_knn_l2_ring<T, 9>; break;  case 13: rk = (const void*)k_knn_l2_ring<T, 13>; break;
                     case 15: rk = (const void*)k_knn_l2_ring<T, 15>; break; case 11: rk = (const void*)k_knn_l2_ring<T, 11>; break;
-                    case 21: rk = (const void*)k_knn_l2_ring<T, 21>; break; case 256: rk = (const void*)k_knn_l2_ring<T, 256>; break; case 64: rk = (const void*)k_knn_l2_ring<T, 64>; break; case 128: rk = (const void*)k_knn_l2_ring<T, 128>; break; case 192: rk = (const void*)k_knn_l2_ring<T, 192>; break; case 53: rk = (const void*)k_knn_l2_ring<T, 53>; break; case 37: rk = (const void*)k_knn_l2_ring<T, 37>; break;
+                    case 21: rk = (const void*)k_knn_l2_ring<T, 21>; break; case 513: rk = (const void*)k_knn_l2_ring<T, 513>; break; case 256: rk = (const void*)k_knn_l2_ring<T, 256>; break; case 64: rk = (const void*)k_knn_l2_ring<T, 64>; break; case 128: rk = (const void*)k_knn_l2_ring<T, 128>; break; case 192: rk = (const void*)k_knn_l2_ring<T, 192>; break; case 53: rk = (const void*)k_knn_l2_ring<T, 53>; break; case 37: rk = (const void*)k_knn_l2_ring<T, 37>; break;
                     default: break;
                 }
 #endif
