@@ -597,6 +597,45 @@ def test_end_to_end_full_size_properties_and_oracle_sample(pkg, gpu, ora):
     np.testing.assert_allclose(mx["pos"][0, :n], out["pos"][0, :n].cpu().numpy(), atol=2e-3)
 
 
+def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
+    """BASELINE configs[1] scale without an oracle: 102 400 codewords x 352, 32 768 queries of clustered, descriptor-like unit
+    vectors (plus exact duplicates of codewords and duplicated codewords). The default path (f16 MFMA candidates -> exact re-rank ->
+    proof -> exact scan of unproven slots) and the exact-f32 MFMA candidate path are independent routes to the same contract, so
+    indices and distances must agree bit for bit; duplicates must resolve to the lowest row at distance 0."""
+    import torch
+    _, dev = gpu
+    g = torch.Generator(device="cpu").manual_seed(7)
+    n_words, nq, dim = 102400, 32768, 352
+    centres = torch.rand((400, dim), generator=g)
+    words = centres[torch.randint(0, 400, (n_words,), generator=g)] + 0.05 * torch.rand((n_words, dim), generator=g)
+    words = (words * (torch.rand((n_words, dim), generator=g) > 0.3)).float()              # sparse like SHOT histograms
+    words /= words.norm(dim=1, keepdim=True)
+    words[50000:50010] = words[10:20]                                                       # duplicated codewords: ties to the lowest row
+    q = centres[torch.randint(0, 400, (nq,), generator=g)] + 0.05 * torch.rand((nq, dim), generator=g)
+    q = (q * (torch.rand((nq, dim), generator=g) > 0.3)).float()
+    q /= q.norm(dim=1, keepdim=True)
+    q[:20] = words[:20]
+    wn = words.numpy()
+    off = np.arange(n_words + 1, dtype=np.uint32)
+    res = {}
+    for mode in ("f16", "f32"):
+        monkeypatch.setenv("ISMHIP_KNN_MODE", mode)
+        ctx = pkg.capi.Ctx(0)
+        cb = pkg.capi.Codebook(ctx, wn, off, np.zeros((n_words, 3), np.float32), np.zeros(n_words, np.uint32), np.zeros(n_words, np.uint32), 1,
+                               np.ones(1, np.float32))
+        ctx.timers_enable(True)
+        idx, dist = pkg.capi.knn(ctx, cb, 0, q.to(dev), 2)
+        res[mode] = (idx.cpu().numpy(), dist.cpu().numpy(), _knn_flagged(ctx))
+        cb.close()
+    assert np.array_equal(res["f16"][0], res["f32"][0])
+    assert np.array_equal(res["f16"][1], res["f32"][1])
+    i16, d16, flagged = res["f16"]
+    assert np.array_equal(i16[:20, 0], np.arange(20)) and (d16[:20, 0] == 0).all()
+    assert np.array_equal(i16[10:20, 1], np.arange(50000, 50010)) and (d16[10:20, 1] == 0).all()    # the duplicate is the second neighbour
+    assert (d16[:, 0] <= d16[:, 1]).all()
+    assert flagged[0] < nq // 20, flagged                                                   # the proof carries the bulk, the scan the rest
+
+
 def test_errors_are_loud(pkg, gpu):
     import ctypes as C
     ctx, dev = gpu
