@@ -3,25 +3,22 @@
 // FLANNExactMatch semantics (flann::SearchParams(-1)); distance functors utils/distance.h:45,65 (FLANN L2 = squared
 // Euclidean, ChiSquareDistance), SURVEY Appendix A.6.
 //
-// Two stages:
-//  1. candidate generation (the dominant kernel of the whole path)
-//     L2  : k_knn_l2_mfma — score(c,q) = |c|^2 - 2 c.q as a dense [codewords x queries] contraction on the FP32
-//           matrix cores (v_mfma_f32_32x32x2_f32, exact f32 fma chain). 128x128 output tile per 4-wave workgroup,
-//           each wave 64x64 = 2x2 MFMA tiles, K staged through LDS in 32-wide slices (register-prefetched, double
-//           buffered). Codewords are the MFMA ROWS and queries the COLUMNS, so that a lane holds 16 codeword scores
-//           of ONE query per accumulator tile: the running top-T per query is kept in registers with no cross-lane
-//           traffic and the Nq x Nc matrix is never materialised. Roofline: 2*Nq*Nc*D flop vs 157.3 TFLOP/s.
-//     chi2: k_knn_chi2 — not a contraction (sum (a-b)^2/(a+b)); 64x64 VALU tile, 4x4 pairs per thread, v_rcp_f32.
-//     Both keep the T best candidates per lane/thread slot (T >= k) AND the value of the best candidate they dropped.
-//  2. k_knn_rerank — one wave per query: every candidate's distance is recomputed with the FLANN functor's own
-//     summation order (bit-identical to the CPU functor) and the k smallest (distance, row) pairs are selected;
-//     ties go to the lowest row. The result is then PROVEN: every codeword outside the candidate set has an approximate
-//     score >= B (the smallest dropped value), so its true distance is >= |q|^2 + B - eps with eps a rigorous bound on the
-//     fp32 contraction error (2(K+8)u(|c|max^2 + 2|q||c|max)); if the k-th exact distance is not safely below that, the query
-//     is queued for
-//  3. k_knn_fallback — exact scan of the whole codebook for the queued queries (coalesced direct (a-b)^2 sums select the
-//     rows, the functor order ranks them). Rare for unit-norm SHOT/CSHOT descriptors, common for un-normalised FPFH-33
-//     (values up to 100: |c|^2 ~ 1e4 makes eps ~ 0.1), where it keeps the answer exact at VALU speed.
+// Three stages:
+//  1. candidate generation (the dominant kernel of the whole path). Score(c,q) = |c|^2 - 2 c.q as a dense [codewords x queries]
+//     contraction on the matrix cores; codewords are the MFMA ROWS and queries the COLUMNS, so a lane holds 16 codeword scores of
+//     ONE query per accumulator tile: the running top-T per query lives in registers with no cross-lane traffic and the Nq x Nc
+//     matrix is never materialised. Every kernel keeps, per lane slot, the T best candidates AND the value of the best candidate
+//     it dropped (the slot's bound).
+//       k_knn_l2_ring    f16 MFMA, 256x256 tile, LDS-DMA ring          default for launches >= 4096 queries x 4096 codewords
+//       k_knn_l2_mfma16  f16 (or bf16x3) MFMA, register-staged tiles   smaller launches; ISMHIP_KNN_MODE=bf16x3 for A/B runs
+//       k_knn_l2_mfma    f32 MFMA (exact fma chain)                    ISMHIP_KNN_MODE=f32: the independent route used by the tests
+//       k_knn_chi2       VALU 64x64 tile, v_rcp_f32                    chi-square is not a contraction
+//  2. k_knn_rerank — one wave per query: candidates that can still matter are recomputed with the FLANN functor's own summation
+//     order (bit-identical to the CPU functor), the k smallest (distance, row) pairs are selected (ties: lowest row), and the
+//     result is PROVEN slot by slot from the slot bounds and a rigorous bound of the candidate kernel's error; a (query, slot) pair
+//     that cannot be proven is queued for
+//  3. k_knn_fallback / k_knn_fallback_merge — exact scan of the queued slots' rows. Rare for descriptor data, the rule for
+//     adversarial inputs (un-normalised magnitudes, hundreds of near-duplicates): it keeps the answer exact in every case.
 #include "common.h"
 
 namespace {
