@@ -34,6 +34,20 @@ int ism3d_add_training(void* m, int n, const float* x, const float* y, const flo
 int ism3d_add_training_file(void* m, const char* file, unsigned class_id, unsigned instance_id) {
     GUARD(return ((ImplicitShapeModel*)m)->addTrainingModel(std::string(file), class_id, instance_id) ? 0 : -2;)
 }
+// loads a cloud file the way addTrainingModel does and copies it out (reader tests); returns the point count, -2 on failure.
+// Arrays may be NULL to query the size; rgba_out receives 0 for clouds without colour.
+int ism3d_load_cloud(const char* file, int cap, float* x, float* y, float* z, float* nx, float* ny, float* nz, uint32_t* rgba_out) {
+    GUARD(
+        auto c = ImplicitShapeModel::loadPointCloud(std::string(file));
+        if (!c) return -2;
+        const int n = (int)c->size();
+        for (int i = 0; i < n && i < cap; ++i) {
+            if (x) { x[i] = c->x[i]; y[i] = c->y[i]; z[i] = c->z[i]; }
+            if (nx) { nx[i] = c->nx[i]; ny[i] = c->ny[i]; nz[i] = c->nz[i]; }
+            if (rgba_out) rgba_out[i] = c->rgba.size() == c->size() ? c->rgba[i] : 0u;
+        }
+        return n;)
+}
 int ism3d_train(void* m) { GUARD(((ImplicitShapeModel*)m)->train(); return 0;) }
 int ism3d_codebook_size(void* m) { return ((ImplicitShapeModel*)m)->getCodebook()->getSize(); }
 int ism3d_num_classes(void* m) { return ((ImplicitShapeModel*)m)->numClasses(); }

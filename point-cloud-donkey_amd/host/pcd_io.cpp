@@ -1,5 +1,5 @@
 // pcd_io.cpp — point cloud file loading for ImplicitShapeModel::loadPointCloud (reference: implicit_shape_model.cpp:213-249
-// loads .pcd / .ply into PointXYZRGBNormal through PCL). Built here: PCD v0.7 "ascii" and "binary" (not binary_compressed),
+// loads .pcd / .ply into PointXYZRGBNormal through PCL). Built here: PCD v0.7 "ascii", "binary" and "binary_compressed" (LZF),
 // fields x y z [rgb|rgba] [normal_x normal_y normal_z] in any order; other fields are skipped. NaN points are removed
 // (pcl::removeNaNFromPointCloud, implicit_shape_model.cpp:608-611). IO is outside the hot path (host only).
 #include <cmath>
@@ -22,6 +22,29 @@ double readScalar(const char* p, const Field& f) {
         case 'I': if (f.size == 1) return *(const int8_t*)p; if (f.size == 2) { int16_t v; std::memcpy(&v, p, 2); return v; } { int32_t v; std::memcpy(&v, p, 4); return v; }
     }
     return 0;
+}
+// LZF (Marc Lehmann's format, as written by pcl::lzfCompress): a control byte < 32 starts a literal run of ctrl+1 bytes; otherwise
+// it is a back reference of length (ctrl >> 5) + 2 (7 -> one more length byte) at distance ((ctrl & 31) << 8 | next byte) + 1.
+bool lzfDecompress(const unsigned char* in, size_t in_len, unsigned char* out, size_t out_len) {
+    size_t ip = 0, op = 0;
+    while (ip < in_len) {
+        unsigned ctrl = in[ip++];
+        if (ctrl < 32) {
+            const size_t run = ctrl + 1;
+            if (ip + run > in_len || op + run > out_len) return false;
+            std::memcpy(out + op, in + ip, run);
+            ip += run; op += run;
+        } else {
+            size_t len = ctrl >> 5;
+            if (len == 7) { if (ip >= in_len) return false; len += in[ip++]; }
+            if (ip >= in_len) return false;
+            const size_t dist = ((size_t)(ctrl & 0x1f) << 8 | in[ip++]) + 1;
+            len += 2;
+            if (dist > op || op + len > out_len) return false;
+            for (size_t i = 0; i < len; ++i, ++op) out[op] = out[op - dist];      // overlapping copies repeat the pattern
+        }
+    }
+    return op == out_len;
 }
 }  // namespace
 
@@ -92,7 +115,31 @@ std::shared_ptr<PointCloud> ImplicitShapeModel::loadPointCloud(const std::string
             if (irgb >= 0) std::memcpy(&rgb, rec + fields[irgb].offset, 4);
             push(v, rgb);
         }
-    } else { std::cerr << "ERROR: PCD DATA \"" << data << "\" is not built (ascii, binary): " << file << std::endl; return nullptr; }
+    } else if (data == "binary_compressed") {
+        // pcl::PCDWriter::writeBinaryCompressed: uint32 compressed size, uint32 uncompressed size, then one LZF stream whose
+        // plain form is field-major (all x, then all y, ...: each field's size*count bytes per point, point after point)
+        uint32_t csize = 0, usize = 0;
+        in.read((char*)&csize, 4); in.read((char*)&usize, 4);
+        if (!in || usize != (uint64_t)stride * points) { std::cerr << "ERROR: malformed binary_compressed PCD: " << file << std::endl; return nullptr; }
+        std::vector<unsigned char> cbuf(csize), ubuf(usize);
+        in.read((char*)cbuf.data(), csize);
+        if ((size_t)in.gcount() != csize || !lzfDecompress(cbuf.data(), csize, ubuf.data(), usize)) {
+            std::cerr << "ERROR: corrupt LZF stream in PCD: " << file << std::endl; return nullptr;
+        }
+        std::vector<size_t> base(fields.size());
+        size_t off = 0;
+        for (size_t f = 0; f < fields.size(); ++f) { base[f] = off; off += (size_t)fields[f].size * fields[f].count * points; }
+        auto at = [&](int f, size_t p) { return (const char*)ubuf.data() + base[f] + p * (size_t)fields[f].size * fields[f].count; };
+        for (size_t p = 0; p < points; ++p) {
+            std::vector<double> v(6, 0.0); uint32_t rgb = 0;
+            v[0] = readScalar(at(ix, p), fields[ix]); v[1] = readScalar(at(iy, p), fields[iy]); v[2] = readScalar(at(iz, p), fields[iz]);
+            if (inx >= 0) v[3] = readScalar(at(inx, p), fields[inx]);
+            if (iny >= 0) v[4] = readScalar(at(iny, p), fields[iny]);
+            if (inz >= 0) v[5] = readScalar(at(inz, p), fields[inz]);
+            if (irgb >= 0) std::memcpy(&rgb, at(irgb, p), 4);
+            push(v, rgb);
+        }
+    } else { std::cerr << "ERROR: PCD DATA \"" << data << "\" is not built (ascii, binary, binary_compressed): " << file << std::endl; return nullptr; }
     return cloud;
 }
 

@@ -106,6 +106,69 @@ class Model:
             pass
 
 
+def load_cloud(path, cap=1 << 20):
+    L = lib()
+    x = np.empty(cap, np.float32); y = np.empty(cap, np.float32); z = np.empty(cap, np.float32)
+    nx = np.empty(cap, np.float32); ny = np.empty(cap, np.float32); nz = np.empty(cap, np.float32); c = np.empty(cap, np.uint32)
+    n = L.ism3d_load_cloud(path.encode(), cap, _p(x), _p(y), _p(z), _p(nx), _p(ny), _p(nz), _p(c))
+    if n < 0:
+        raise HostError(f"loadPointCloud: {L.ism3d_last_error().decode()} (rc {n})")
+    return np.stack([x[:n], y[:n], z[:n]], 1), np.stack([nx[:n], ny[:n], nz[:n]], 1), c[:n]
+
+
+def lzf_compress(data: bytes) -> bytes:
+    """small greedy LZF encoder (test helper): literal runs and back references as liblzf / pcl::lzfCompress emit them"""
+    out = bytearray(); lit = bytearray(); i = 0; n = len(data); table = {}
+
+    def flush():
+        nonlocal lit
+        for s in range(0, len(lit), 32):
+            chunk = lit[s:s + 32]
+            out.append(len(chunk) - 1); out.extend(chunk)
+        lit = bytearray()
+    while i < n:
+        key = data[i:i + 3]
+        j = table.get(key, -1) if len(key) == 3 else -1
+        if len(key) == 3:
+            table[key] = i
+        if j >= 0 and 0 < i - j <= 8192:
+            ln = 3
+            while i + ln < n and ln < 264 and data[j + ln] == data[i + ln]:
+                ln += 1
+            flush()
+            dist = i - j - 1
+            l2 = ln - 2
+            if l2 < 7:
+                out.append((l2 << 5) | (dist >> 8))
+            else:
+                out.append((7 << 5) | (dist >> 8)); out.append(l2 - 7)
+            out.append(dist & 0xff)
+            i += ln
+        else:
+            lit.append(data[i]); i += 1
+    flush()
+    return bytes(out)
+
+
+def write_pcd_compressed(path, xyz, normals, rgba=None):
+    """PCD DATA binary_compressed as pcl::PCDWriter::writeBinaryCompressed lays it out (field-major plain stream, LZF)"""
+    import struct
+    n = len(xyz)
+    fields = ["x", "y", "z"] + (["rgb"] if rgba is not None else []) + ["normal_x", "normal_y", "normal_z", "curvature"]
+    types = ["F", "F", "F"] + (["U"] if rgba is not None else []) + ["F", "F", "F", "F"]
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\nWIDTH %d\nHEIGHT 1\n"
+           "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary_compressed\n") % (" ".join(fields), " ".join(["4"] * len(fields)), " ".join(types),
+                                                                            " ".join(["1"] * len(fields)), n, n)
+    cols = [xyz[:, 0], xyz[:, 1], xyz[:, 2]]
+    if rgba is not None:
+        cols.append(rgba.astype(np.uint32).view(np.float32))
+    cols += [normals[:, 0], normals[:, 1], normals[:, 2], np.zeros(n, np.float32)]
+    plain = b"".join(np.ascontiguousarray(c, np.float32).tobytes() for c in cols)
+    comp = lzf_compress(plain)
+    with open(path, "wb") as f:
+        f.write(hdr.encode()); f.write(struct.pack("<II", len(comp), len(plain))); f.write(comp)
+
+
 def write_pcd(path, xyz, normals, rgba=None, binary=False):
     n = len(xyz)
     fields = ["x", "y", "z"] + (["rgb"] if rgba is not None else []) + ["normal_x", "normal_y", "normal_z", "curvature"]

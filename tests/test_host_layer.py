@@ -83,6 +83,26 @@ def test_pcd_reader_ascii_and_binary(tmp_path):
         hb.Model().add_training_file(str(tmp_path / "missing.pcd"), 0, 0)
 
 
+def test_pcd_reader_three_encodings_agree(tmp_path):
+    """ascii, binary and binary_compressed (LZF, field-major) files of the same cloud load to the same points; the compressed
+    stream holds literal runs and back references (constant curvature column, repeated coordinates)."""
+    rng = np.random.default_rng(1)
+    xyz = rng.normal(size=(400, 3)).astype(np.float32); nrm = rng.normal(size=(400, 3)).astype(np.float32)
+    xyz[100:200] = xyz[0:100]                                    # long matches for the encoder
+    rgba = rng.integers(0, 1 << 24, 400).astype(np.uint32)
+    xyz[7, 0] = np.nan                                           # removed on load in every encoding
+    pa, pb, pc = (str(tmp_path / n) for n in ("a.pcd", "b.pcd", "c.pcd"))
+    hb.write_pcd(pa, xyz, nrm, rgba, binary=False); hb.write_pcd(pb, xyz, nrm, rgba, binary=True); hb.write_pcd_compressed(pc, xyz, nrm, rgba)
+    assert os.path.getsize(pc) < os.path.getsize(pb)             # the encoder did find its matches
+    a, b, c = hb.load_cloud(pa), hb.load_cloud(pb), hb.load_cloud(pc)
+    keep = ~np.isnan(xyz[:, 0])
+    for got in (a, b, c):
+        assert np.array_equal(got[0], xyz[keep]) and np.array_equal(got[1], nrm[keep]) and np.array_equal(got[2], rgba[keep])
+    open(pc, "r+b").truncate(os.path.getsize(pc) - 9)            # a cut stream is an error, not a short cloud
+    with pytest.raises(hb.HostError):
+        hb.load_cloud(pc)
+
+
 def _dataset(pkg, n_classes, n_train, n_test):
     syn = pkg.synthetic
     train = syn.Dataset(n_classes, n_train, split=0, n_points=4096, leaf=0.2)
