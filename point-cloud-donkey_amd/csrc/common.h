@@ -94,6 +94,7 @@ struct ismhip_ctx {
     std::vector<ismhip_cloud*> cloud_pool;
     uint32_t knn_stats[2] = {0, 0};   // last ismhip_knn: {queries, (query,slot) items} sent to the exact fallback (valid with timers on, after a sync)
     bool knn_small_tile = false; // env ISMHIP_KNN_TILE128=1: keep the bf16x3 kernel on its 128x128 tile (A/B runs)
+    bool knn_ring32 = false;     // env ISMHIP_KNN_RING32=1: the ring kernel on the 32x32x16 MFMA shape instead of 16x16x32 (A/B runs)
     int knn_splits = 0;          // env ISMHIP_KNN_SPLITS: force the number of codebook splits of the squared-L2 candidate kernels (A/B runs)
     int knn_t = 0;               // env ISMHIP_KNN_T = 2 | 3: candidates kept per slot (default 4 on the 16-bit paths); fewer = cheaper epilogue, more unproven slots
     int knn_dbg = 0;             // env ISMHIP_KNN_DBG: timing experiments on k_knn_l2_ring (1 no epilogue, 2 no MFMA, 3 no DMA); results invalid

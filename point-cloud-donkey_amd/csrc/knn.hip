@@ -292,9 +292,9 @@ __global__ void k_to_f16(const float* __restrict__ src, int n, int dim, int ld, 
     dst[i] = __builtin_bit_cast(u16, hx);
 }
 
-// The same conversion into the layout k_knn_l2_ring streams: [256-row tile][32-k slice][row][4 x 16-byte segments], i.e. every
-// (tile, slice) is one contiguous 16 KB block that already is the LDS image (segment p of row r holds logical segment
-// p ^ ((r>>2)&3)). A DMA instruction then copies 1 KB of consecutive, fully used 128-byte lines; with a row-major image each
+// The same conversion into the layout k_knn_l2_ring / k_knn_l2_ring16 stream: [256-row tile][32-k slice][row][4 x 16-byte
+// segments], i.e. every (tile, slice) is one contiguous 16 KB block that already is the LDS image (segment p of row r holds
+// logical segment p ^ F[(r>>2)&3], F = {0,2,3,1}). A DMA instruction then copies 1 KB of consecutive, fully used 128-byte lines; with a row-major image each
 // 32-k slice touches only half of every line and the other half is fetched again one slice later.
 __global__ void k_to_f16_tiled(const float* __restrict__ src, int n, int dim, int ld, int n_tiles, int nk,
                                uint32_t* __restrict__ sc, float other_scale, u16* __restrict__ dst) {
@@ -308,7 +308,7 @@ __global__ void k_to_f16_tiled(const float* __restrict__ src, int n, int dim, in
     const int e = (int)(i & 7), p = (int)((i >> 3) & 3), r = (int)((i >> 5) & 255);
     const size_t blk = i >> 13;
     const int kc = (int)(blk % nk); const size_t tile = blk / nk;
-    const int col = kc * 32 + ((p ^ ((r >> 2) & 3)) << 3) + e;
+    const int col = kc * 32 + ((p ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) << 3) + e;      // F = {0,2,3,1}[(r>>2)&3]: conflict-free for both MFMA shapes
     const size_t row = tile * 256 + r;
     float x = 0.f;
     if (row < (size_t)n && col < dim) x = src[row * ld + col];
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
     issue(); issue(); issue(); issue();
 
     const int fragA = (wr * (MI * 32) + r) * KB, fragB = BM * KB + (wc * (NI * 32) + r) * KB;
-    const int fsw = (r >> 2) & 3;
+    const int fsw = (0x78 >> (2 * ((r >> 2) & 3))) & 3;                 // F[(row >> 2) & 3], see k_to_f16_tiled
     const int so0 = ((0 + h) ^ fsw) << 3, so1 = ((2 + h) ^ fsw) << 3;    // k-step 0 / 1 segment of this lane
     TopT<T + 1> top[NI];
 #pragma unroll
@@ -706,6 +706,163 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
                 cand_val[o] = -oscale * top[ni].v[tt]; cand_idx[o] = top[ni].i[tt];
             }
             cand_bound[(size_t)qi * bound_stride + split * (2 * WR) + (wr * 2 + h)] = oscale * thr[ni];   // the lane's final threshold
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same ring on v_mfma_f32_16x16x32_f16
+// ---------------------------------------------------------------------------------------------
+// A bare MFMA loop (tools/mfma_shape_bench.hip: operands in registers, two waves per SIMD, random f16) sustains 1.96 PFLOP/s
+// with the 16x16x32 shape against 1.63 with 32x32x16 on this chip: same cycles per FLOP, but the chip holds a higher clock on the
+// small shape (MI355X_MICROARCH 'DVFS give-back' item 7). Geometry, ring, DMA and synchronisation are those of k_knn_l2_ring;
+// what changes is the fragment and accumulator layout:
+//   A / B fragment of a 16-row tile: lane l reads row (l & 15), 16-byte segment (l >> 4) of the 64-byte slice row: ONE ds_read_b128
+//     per 16 x 32 tile (8 for the wave's 128 codeword rows + 4 for its 64 queries per slice); conflict-free with segments XOR-swizzled
+//     by F[(row >> 2) & 3], F = {0,2,3,1} (worked out against ds_read_b128's lane groups {0-3,12-15,20-27}, ...)
+//   C tile: lane l holds rows 4 (l >> 4) + j, j = 0..3, of column (l & 15): a lane now serves FOUR query columns (one per n-tile)
+//     with four codeword rows per tile each, so a query column is scanned by 8 lane slots per workgroup (4 row groups x 2 wave
+//     rows) and the kernel leaves 8 slots per codebook split (the host limits it to two splits: 64 candidates per query)
+template <int T, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict__ wh, const float* __restrict__ word_norm, int n_tiles_m, int ld, int k_steps,
+                                                          const u16* __restrict__ qh, int nq, const float* __restrict__ out_scale,
+                                                          int tiles_per_split, int n_splits,
+                                                          float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
+                                                          float* __restrict__ cand_bound, int bound_stride) {
+    constexpr int WC = 4, MT = 8, NT = 4, KB = RG_KB, BM = RG_BM, BN = RG_BN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
+    u16* ring = (u16*)knn_smem;                                        // [RG_STAGES][512 rows][32 halves]
+    float* sCn = (float*)(ring + RG_STAGES * RG_STAGE_HALVES);        // [4][BM]
+    float* sThr = sCn + 4 * BM;                                        // [8 waves][NT][64]
+    const float oscale = out_scale[0];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv / WC, wc = wv % WC;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = jx % n_splits, qtile = (jx / n_splits) * 8 + xcd;
+    if (qtile * BN >= nq) return;
+    const int mt0 = split * tiles_per_split;
+    const int n_t = min(n_tiles_m, mt0 + tiles_per_split) - mt0;
+    if (n_t <= 0) return;
+    const int nk = (k_steps + 1) / 2;
+    const int G = n_t * nk;
+
+    const bool dma_a = wv < 4;
+    const unsigned lane_off = (unsigned)(lane * 16);
+    const char* dbase = (dma_a ? (const char*)(wh + (size_t)mt0 * nk * (BM * KB)) : (const char*)(qh + (size_t)qtile * nk * (BN * KB)))
+                        + (wv & 3) * (64 * KB * 2);
+    const int ddst = (dma_a ? 0 : BM * KB) + (wv & 3) * 64 * KB;
+    const size_t tile_stride = dma_a ? (size_t)nk * (BM * KB * 2) : 0;
+    int pt = 0, pkc = 0, pg = 0;
+    auto issue = [&]() {
+        u16* st = ring + (pg & (RG_STAGES - 1)) * RG_STAGE_HALVES + ddst;
+        if (wv == 0 && pkc == 0) lds_dma16(word_norm + (size_t)(mt0 + pt) * BM + lane * 4, sCn + (pt & 3) * BM);
+        const char* sp = dbase + pt * tile_stride + (size_t)pkc * (BM * KB * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);
+        ++pg;
+        if (pt * nk + pkc + 1 < G) { if (++pkc == nk) { pkc = 0; ++pt; } }
+    };
+    issue(); issue(); issue(); issue();
+
+    // fragment address of this lane inside a 16-row tile: row fr, physical segment fq ^ F[(fr >> 2) & 3]
+    const int fso = (fr * KB) + ((fq ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 3);
+    const int fragA = wr * (MT * 16) * KB + fso, fragB = BM * KB + wc * (NT * 16) * KB + fso;
+    TopT<T + 1> top[NT];
+    float thr[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { top[n].init(); thr[n] = -__builtin_inff(); }
+    f32x4 acc[MT][NT];
+    const int pw = (1 - wr) * WC + wc;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) sThr[(wv * NT + n) * 64 + lane] = -__builtin_inff();
+
+    // pipeline as in k_knn_l2_ring, with the fragments split by codeword rows instead of k-steps: X = tiles 0-3 (read during the
+    // previous step), Y = tiles 4-7 and the four query fragments (read at the top of the step)
+    f16x8 xa[4], ya[4], bq[NT];
+    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < 4; ++m) xa[m] = *(const f16x8*)(ring + fragA + m * 16 * KB);
+    int t = 0, kc = 0;
+    for (int g = 0; g < G; ++g) {
+        const u16* st = ring + (g & (RG_STAGES - 1)) * RG_STAGE_HALVES;
+        const u16* sn = ring + ((g + 1) & (RG_STAGES - 1)) * RG_STAGE_HALVES;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bq[n] = *(const f16x8*)(st + fragB + n * 16 * KB);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) ya[m] = *(const f16x8*)(st + fragA + (4 + m) * 16 * KB);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        // first slice of a tile: the accumulators START from the tile's pre-scaled |c|^2 row (rows 16 mt + 4 fq + j), passed as
+        // the C operand of the tile's first MFMAs
+        const float* cnp = sCn + (t & 3) * BM + wr * (MT * 16) + 4 * fq;
+        auto mma4 = [&](int mb, const f16x8* af) {
+            if (kc == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x4 c0 = *(const f32x4*)(cnp + (mb + mt) * 16);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mb + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bq[nt], c0, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mb + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bq[nt], acc[mb + mt][nt], 0, 0, 0);
+            }
+        };
+        mma4(0, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xa[m] = *(const f16x8*)(sn + fragA + m * 16 * KB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(4, ya);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++kc == nk) {
+            const int row0 = (mt0 + t) * BM + wr * (MT * 16) + 4 * fq;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float a = acc[mt][nt][j];
+                        if (DBG & 1) { if (j == 0) top[nt].v[0] += a; }
+                        else if (__builtin_expect(__any(a > thr[nt]), 0)) {
+                            if (a > thr[nt]) top[nt].push(-a, row0 + mt * 16 + j);
+                            thr[nt] = fmaxf(thr[nt], -top[nt].v[T]);
+                        }
+                    }
+            // thresholds shared by the 8 lane slots of a query column: the four row groups of this wave (lanes fr, fr+16, fr+32,
+            // fr+48), then the partner wave row through LDS (see k_knn_l2_ring)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float sh = fmaxf(thr[nt], __shfl_xor(thr[nt], 16, 64));
+                sh = fmaxf(sh, __shfl_xor(sh, 32, 64));
+                sThr[(wv * NT + nt) * 64 + lane] = sh;
+                thr[nt] = fmaxf(sh, sThr[(pw * NT + nt) * 64 + lane]);
+            }
+            kc = 0; ++t;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // candidates: slot = split*(8*T) + (wr*4 + fq)*T + t; bound slot = split*8 + wr*4 + fq
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int qi = qtile * BN + wc * (NT * 16) + nt * 16 + fr;
+        if (qi < nq) {
+#pragma unroll
+            for (int tt = 0; tt < T; ++tt) {
+                const size_t o = (size_t)qi * cand_stride + split * (8 * T) + (wr * 4 + fq) * T + tt;
+                cand_val[o] = -oscale * top[nt].v[tt]; cand_idx[o] = top[nt].i[tt];
+            }
+            cand_bound[(size_t)qi * bound_stride + split * 8 + (wr * 4 + fq)] = oscale * thr[nt];
         }
     }
 }
@@ -1012,7 +1169,8 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
     const int g = lane >> 4, l16 = lane & 15;
     const uint32_t n_items = flag_count[1];
     const bool l2 = metric != ISMHIP_METRIC_CHI2;
-    const int rows_per_tile = l2 ? wr_rows / 2 : tile_rows;       // a lane slot sees half of its wave-row block (bit 2 of the row == h)
+    const bool lay16 = l2 && wr_rows < 0;                         // k_knn_l2_ring16: slot b = split*8 + wr*4 + fq owns rows wr*128 + 16 m + 4 fq + j
+    const int rows_per_tile = lay16 ? 32 : (l2 ? wr_rows / 2 : tile_rows);   // else a lane slot sees half of its wave-row block (bit 2 of the row == h)
     const int nj = dim_pad / 16;
     const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     // With few items a wave per item would leave the chip idle behind a handful of long scans: every item is cut into P row
@@ -1023,8 +1181,8 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
         const uint32_t it = u / P, part_i = u % P;
         const int qi = (int)items[2 * (size_t)it], b = (int)items[2 * (size_t)it + 1];
         const float* qp = q + (size_t)qi * ldq;
-        const int split = l2 ? (b >> 2) : b;
-        const int wr = (b >> 1) & 1, h = b & 1;
+        const int split = lay16 ? (b >> 3) : (l2 ? (b >> 2) : b);
+        const int wr = lay16 ? (b >> 2) & 1 : (b >> 1) & 1, h = b & 1, fq = b & 3;
         const int mt0 = split * tiles_per_split, mt1 = min(n_tiles, mt0 + tiles_per_split);
         const int total = (mt1 - mt0) * rows_per_tile;
         unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
@@ -1040,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
             int r = n_words;                                  // out of range = idle group
             if (e < e_end) {
                 const int tile = mt0 + e / rows_per_tile, y = e % rows_per_tile;
-                const int x = l2 ? (wr * wr_rows + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y;
+                const int x = lay16 ? (wr * 128 + ((y >> 2) << 4) + (fq << 2) + (y & 3)) : (l2 ? (wr * wr_rows + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y);
                 r = tile * tile_rows + x;
             }
             float part = 0.f;
@@ -1165,17 +1323,19 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     const int BNq = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BN) : CHI_B;
     const int wr_rows = big_tile ? 128 : 64;
     const bool use_ring = big_tile && mode == 0 && !ctx->knn_no_ring && cb->words_f16t;
+    const bool ring16 = use_ring && !ctx->knn_ring32;                  // 16x16x32 MFMA shape: 8 lane slots per query and split instead of 4
+    const int slots = ring16 ? 8 : 4;
     const int ring_nk = ((cb->dim + 15) / 16 + 1) / 2;                 // 32-k slices per row in the tiled images
     if (metric == ISMHIP_METRIC_L2SQ) {
         const int n_qt = (nq + BNq - 1) / BNq, n_mt = cb->n_words_pad / BM;
-        const int max_s = 64 / (4 * T);
+        const int max_s = 64 / (slots * T);
         // at least two codebook splits: with one, the 32 workgroups of an XCD hold 32 different query tiles (6 MB of f16 queries
         // re-read per codeword tile) and fall out of its 4 MB L2; two splits halve that working set (measured 21.0 -> 19.9 ms at 262144 queries)
         n_splits = std::max(1, std::min(std::min(max_s, n_mt), std::max(2, (1024 + n_qt - 1) / n_qt)));
         if (ctx->knn_splits > 0) n_splits = std::max(1, std::min(std::min(max_s, n_mt), ctx->knn_splits));
         tiles_per_split = (n_mt + n_splits - 1) / n_splits;
         n_splits = (n_mt + tiles_per_split - 1) / tiles_per_split;
-        cand_per_split = 4 * T;
+        cand_per_split = slots * T;
     } else {
         const int n_qt = (nq + CHI_B - 1) / CHI_B, n_mt = cb->n_words_pad / CHI_B;
         const int max_s = 64 / T;
@@ -1185,7 +1345,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         cand_per_split = T;
     }
     n_cand = n_splits * cand_per_split;
-    const int n_bound = metric == ISMHIP_METRIC_L2SQ ? n_splits * 4 : n_splits;
+    const int n_bound = metric == ISMHIP_METRIC_L2SQ ? n_splits * slots : n_splits;
     float* cand_val = (float*)ism_scratch(ctx, SCR_KNN_CAND_VAL, (size_t)nq * (n_cand + n_bound) * sizeof(float));
     int* cand_idx = (int*)ism_scratch(ctx, SCR_KNN_CAND_IDX, (size_t)nq * n_cand * sizeof(int));
     // queue of unproven work: 16 counters | query records [nq*3] | items [nq*n_bound*2] | item results [nq*n_bound*4] u64
@@ -1238,7 +1398,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
             }
             if (use_ring) {
                 wh = cb->words_f16t;
-                const void* rk = (const void*)k_knn_l2_ring<T, 0>;
+                const void* rk = ring16 ? (const void*)k_knn_l2_ring16<T, 0> : (const void*)k_knn_l2_ring<T, 0>;
 #ifdef ISM_KNN_DBG_VARIANTS
                 switch (ctx->knn_dbg) {
                     case 1: rk = (const void*)k_knn_l2_ring<T, 1>; break;  case 3: rk = (const void*)k_knn_l2_ring<T, 3>; break;
@@ -1249,8 +1409,9 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     default: break;
                 }
 #endif
-                const size_t rlds = (size_t)RG_STAGES * RG_STAGE_HALVES * sizeof(u16) + 4 * RG_BM * sizeof(float) + 8 * 2 * 64 * sizeof(float);
-                static bool rattr = false;
+                const size_t rlds = (size_t)RG_STAGES * RG_STAGE_HALVES * sizeof(u16) + 4 * RG_BM * sizeof(float) + 8 * 4 * 64 * sizeof(float);
+                static bool rattr_a[2] = {false, false};
+                bool& rattr = rattr_a[ring16 ? 1 : 0];
                 if (ctx->knn_dbg) rattr = false;
                 if (!rattr) { ISM_HIP(ctx, hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds)); rattr = true; }
                 const float* osc = (const float*)(qsc + 1);
@@ -1303,7 +1464,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     {
         TimerScope ts(ctx, "knn_fallback");
         hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad,
-                           cb->n_words, qq, ldq, metric, k, tiles_per_split, cb->n_words_pad / BM, BM, wr_rows,
+                           cb->n_words, qq, ldq, metric, k, tiles_per_split, cb->n_words_pad / BM, BM, ring16 ? -1 : wr_rows,
                            flag_count, items, idx_out, dist_out, item_out, q_items);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback");
         hipLaunchKernelGGL(k_knn_fallback_merge, dim3(256), dim3(256), 0, ctx->stream, k, flag_count, qrec, item_out, q_items, idx_out, dist_out);
