@@ -9,7 +9,7 @@ path's one exchange: an all-gather of the per-object class-score records (RCCL).
 value = objects processed by all ranks / max-over-ranks time of the K timed steps.
 
 The JSON line also carries
-  roofline      : the dominant kernel (k_knn_l2_ring, the f16-MFMA candidate stage of the exact kNN, MFMA-bound): algorithmic
+  roofline      : the dominant kernel (k_knn_l2_ring16, the f16-MFMA candidate stage of the exact kNN, MFMA-bound): algorithmic
                   flop per launch (2 * queries * codewords * 352) / mean launch time, measured with HIP events on the stream
                   the kernel runs on (ismhip timers), vs the dense F16/BF16 MFMA peak
   roofline_shot : descriptor extraction (k_shot<false>, HBM-bound, gather model bytes of SURVEY.md §8d)
@@ -146,9 +146,9 @@ def main():
         ach = flop / (ms_knn * 1e-3) / 1e12
         knn_mode = os.environ.get("ISMHIP_KNN_MODE", "f16")
         # f16: one MFMA per product -> executed = algorithmic flop; bf16x3 executes 3x the algorithmic flop, priced as executed
-        kname, peak, mult = {"f16": ("k_knn_l2_ring", PEAK_F16_MFMA_TFLOPS, 1.0),
+        kname, peak, mult = {"f16": ("k_knn_l2_ring" if os.environ.get("ISMHIP_KNN_RING32") == "1" else "k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0),
                              "bf16x3": ("k_knn_l2_mfma16<bf16x3>", PEAK_F16_MFMA_TFLOPS, 3.0),
-                             "f32": ("k_knn_l2_mfma", PEAK_FP32_MFMA_TFLOPS, 1.0)}.get(knn_mode, ("k_knn_l2_ring", PEAK_F16_MFMA_TFLOPS, 1.0))
+                             "f32": ("k_knn_l2_mfma", PEAK_FP32_MFMA_TFLOPS, 1.0)}.get(knn_mode, ("k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0))
         ach *= mult
         # beyond-L2 bytes per launch of this kernel from the committed PMC passes of this very command (separate FETCH_SIZE /
         # WRITE_SIZE runs, gfx950 correction applied: profiles/round1_pmc_traffic.json); null for any other workload shape
@@ -156,14 +156,14 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
             if tj.get("batch") == B and knn_mode == "f16" and args.points == 16384 and args.keypoints == 1024:
-                traffic = tj["k_knn_l2_ring"]["bytes_per_launch"]
+                traffic = tj["k_knn_l2_ring16"]["bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
         roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 3), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_note": "bytes beyond the XCD L2s (Infinity Cache + HBM) per launch, PMC; the kernel is MFMA-bound: its "
                                     "algorithmic bytes (f16 codebook + queries once) are 0.26 GB, the rest is tile re-streaming served by the Infinity Cache",
-                    "attainable_note": "a bare MFMA loop of this kernel's geometry (no loads, no epilogue) measures 1383 TFLOP/s on this chip under DVFS",
+                    "attainable_note": "bare MFMA loops (tools/mfma_shape_bench.hip, operands in registers, random f16) sustain 1.96 PFLOP/s with 16x16x32 and 1.63 with 32x32x16 on this chip under DVFS",
                     "flop_per_launch": flop * mult, "ms_per_launch": round(ms_knn, 4),
                     "note": "candidate stage of the exact kNN: 16-bit MFMA scores rank the codewords, every returned neighbour is "
                             "re-ranked with the exact f32 FLANN functor and proven (see DESIGN.md)"}
