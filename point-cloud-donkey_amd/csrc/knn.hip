@@ -792,36 +792,38 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
         const u16* sn = ring + ((g + 1) & (RG_STAGES - 1)) * RG_STAGE_HALVES;
 #pragma unroll
         for (int n = 0; n < NT; ++n) bq[n] = *(const f16x8*)(st + fragB + n * 16 * KB);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) ya[m] = *(const f16x8*)(st + fragA + (4 + m) * 16 * KB);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
         // first slice of a tile: the accumulators START from the tile's pre-scaled |c|^2 row (rows 16 mt + 4 fq + j), passed as
-        // the C operand of the tile's first MFMAs
+        // the C operand of the tile's first MFMAs. The fragment reads of the other half-step are issued one per four MFMAs, so
+        // the first MFMAs wait only for the query fragments and the reads ride inside the MFMA stream.
         const float* cnp = sCn + (t & 3) * BM + wr * (MT * 16) + 4 * fq;
-        auto mma4 = [&](int mb, const f16x8* af) {
+        auto mma4 = [&](int mb, const f16x8* af, f16x8* nxt, const u16* nsrc) {
             if (kc == 0) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const f32x4 c0 = *(const f32x4*)(cnp + (mb + mt) * 16);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[mb + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bq[nt], c0, 0, 0, 0);
+                    nxt[mt] = *(const f16x8*)(nsrc + mt * 16 * KB);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[mb + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bq[nt], acc[mb + mt][nt], 0, 0, 0);
+                    nxt[mt] = *(const f16x8*)(nsrc + mt * 16 * KB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         };
-        mma4(0, xa);
+        mma4(0, xa, ya, st + fragA + 4 * 16 * KB);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         issue();
-#pragma unroll
-        for (int m = 0; m < 4; ++m) xa[m] = *(const f16x8*)(sn + fragA + m * 16 * KB);
         __builtin_amdgcn_sched_barrier(0);
-        mma4(4, ya);
+        mma4(4, ya, xa, sn + fragA);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (++kc == nk) {
