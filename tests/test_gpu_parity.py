@@ -600,7 +600,7 @@ def test_end_to_end_full_size_properties_and_oracle_sample(pkg, gpu, ora):
 def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
     """BASELINE configs[1] scale without an oracle: 102 400 codewords x 352, 32 768 queries of clustered, descriptor-like unit
     vectors (plus exact duplicates of codewords and duplicated codewords). The default path (f16 MFMA candidates -> exact re-rank ->
-    proof -> exact scan of unproven slots) and the exact-f32 MFMA candidate path are independent routes to the same contract, so
+    proof -> exact scan of unproven slots; both MFMA shapes of the ring kernel) and the exact-f32 MFMA candidate path are independent routes to the same contract, so
     indices and distances must agree bit for bit; duplicates must resolve to the lowest row at distance 0."""
     import torch
     _, dev = gpu
@@ -618,8 +618,9 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
     wn = words.numpy()
     off = np.arange(n_words + 1, dtype=np.uint32)
     res = {}
-    for mode in ("f16", "f32"):
-        monkeypatch.setenv("ISMHIP_KNN_MODE", mode)
+    for mode in ("f16", "f16-ring32", "f32"):
+        monkeypatch.setenv("ISMHIP_KNN_MODE", mode.split("-")[0])
+        monkeypatch.setenv("ISMHIP_KNN_RING32", "1" if mode.endswith("ring32") else "0")     # the 32x32x16 variant of the ring kernel
         ctx = pkg.capi.Ctx(0)
         cb = pkg.capi.Codebook(ctx, wn, off, np.zeros((n_words, 3), np.float32), np.zeros(n_words, np.uint32), np.zeros(n_words, np.uint32), 1,
                                np.ones(1, np.float32))
@@ -627,8 +628,9 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
         idx, dist = pkg.capi.knn(ctx, cb, 0, q.to(dev), 2)
         res[mode] = (idx.cpu().numpy(), dist.cpu().numpy(), _knn_flagged(ctx))
         cb.close()
-    assert np.array_equal(res["f16"][0], res["f32"][0])
-    assert np.array_equal(res["f16"][1], res["f32"][1])
+    for m in ("f16", "f16-ring32"):
+        assert np.array_equal(res[m][0], res["f32"][0]), m
+        assert np.array_equal(res[m][1], res["f32"][1]), m
     i16, d16, flagged = res["f16"]
     assert np.array_equal(i16[:20, 0], np.arange(20)) and (d16[:20, 0] == 0).all()
     assert np.array_equal(i16[10:20, 1], np.arange(50000, 50010)) and (d16[10:20, 1] == 0).all()    # the duplicate is the second neighbour
