@@ -651,3 +651,12 @@ def test_errors_are_loud(pkg, gpu):
     _, cb = _cb(pkg, gpu, words)
     with pytest.raises(pkg.capi.IsmHipError):
         pkg.capi.knn(ctx, cb, 0, T(words, dev), 5)          # k > 4 is not built -> ISMHIP_ERR_UNSUPPORTED, not a silent fallback
+    x = T(np.arange(8, dtype=np.float32), dev)
+    with pytest.raises(pkg.capi.IsmHipError, match="bad argument"):
+        pkg.capi.voxel_keypoints(ctx, [0, 8], x, x, x, 0.0)                     # leaf must be positive
+    with pytest.raises(pkg.capi.IsmHipError, match="start at 0"):
+        pkg.capi.voxel_keypoints(ctx, [1, 8], x, x, x, 0.5)
+    with pytest.raises(pkg.capi.IsmHipError, match="leaf too small"):
+        pkg.capi.voxel_keypoints(ctx, [0, 8], x * 1e9, x, x, 1e-3)             # PCL: "leaf size is too small for the input dataset"
+    ko, kx, _, _, _ = pkg.capi.voxel_keypoints(ctx, [0, 0, 8], x, x, x, 100.0)  # empty object first, one voxel for the rest
+    assert ko.tolist() == [0, 0, 1] and abs(float(kx[0]) - 3.5) < 1e-6
