@@ -172,6 +172,39 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     v += dpp_mov0<0x143>(v);
     return __builtin_amdgcn_readlane(v, 63);
 }
+// the same data path for wave-wide minima (lanes without a source see the identity) and for an inclusive prefix sum
+// (row_shr 1,2,4,8 scan the 16-lane rows; row_bcast:15 / :31 with row masks 0xa / 0xc carry the row totals forward)
+template <int CTRL>
+__device__ __forceinline__ int dpp_movi(int ident, int v) { return __builtin_amdgcn_update_dpp(ident, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float wave_min_f(float v) {        // NaN-free inputs or NaN-last semantics of fminf
+    const int inf = 0x7f800000;
+    v = fminf(v, __int_as_float(dpp_movi<0xb1>(inf, __float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_movi<0x4e>(inf, __float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_movi<0x114>(inf, __float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_movi<0x118>(inf, __float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_movi<0x142>(inf, __float_as_int(v))));
+    v = fminf(v, __int_as_float(dpp_movi<0x143>(inf, __float_as_int(v))));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)dpp_movi<CTRL>(-1, (int)(unsigned)(v & 0xffffffffull)), hi = (unsigned)dpp_movi<CTRL>(-1, (int)(unsigned)(v >> 32));
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    v = dpp_min_u64<0xb1>(v); v = dpp_min_u64<0x4e>(v); v = dpp_min_u64<0x114>(v);
+    v = dpp_min_u64<0x118>(v); v = dpp_min_u64<0x142>(v); v = dpp_min_u64<0x143>(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    int x = (int)v;
+    x += dpp_mov0<0x111>(x); x += dpp_mov0<0x112>(x); x += dpp_mov0<0x114>(x); x += dpp_mov0<0x118>(x);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)x;
+}
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov0_d(double v) {
     const long long b = __double_as_longlong(v);
@@ -258,12 +291,10 @@ __device__ __forceinline__ void ball_for_each(const GridMeta& m, const uint32_t*
                 s = cs[rb + xl]; len = cs[rb + xh + 1] - s;
             }
         }
-        uint32_t inc = len;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += t; }
+        const uint32_t inc = wave_incl_scan_u32(len);
         wr.off[lane + 1] = inc; wr.start[lane] = s;
         if (lane == 0) wr.off[0] = 0;
-        const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         uint32_t jc = 0;                                     // LDS traffic of one wave is ordered: no barrier needed
         auto locate = [&](uint32_t idx, bool v) -> uint32_t {
             if (!v) return 0u;

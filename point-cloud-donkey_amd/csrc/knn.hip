@@ -1057,8 +1057,7 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
     // |q|^2 by a wave sum (needed by the error bounds below)
     float qn2 = 0.f;
     for (int i = lane; i < dim; i += 64) { const float v = qp[i]; qn2 += v * v; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) qn2 += __shfl_xor(qn2, o, 64);
+    qn2 = wave_sum_f(qn2);
     // n_cand <= 64 by construction (host): one candidate per lane. Only candidates whose approximate score is within twice the
     // error bound of the k-th best approximate score can be among the exact k best; the others skip the functor.
     int id = -1; float av = __builtin_inff();
@@ -1068,9 +1067,7 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
     {
         float cur = av;                       // k-th smallest approximate score (k <= 4) by k rounds of wave-min
         for (int j = 0; j < k; ++j) {
-            float mn = cur;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
+            const float mn = wave_min_f(cur);
             kth = mn;
             const unsigned long long eq = __ballot(cur == mn);
             if (eq && lane == __ffsll((long long)eq) - 1) cur = __builtin_inff();      // retire one instance
@@ -1097,9 +1094,7 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
     if (lane < n_bound) bnd = cand_bound[(size_t)qi * n_bound + lane];
     float dk = 0.f; bool have_k = true;
     for (int j = 0; j < k; ++j) {
-        unsigned long long mn = key;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(mn, o, 64); mn = t < mn ? t : mn; }
+        const unsigned long long mn = wave_min_u64(key);
         if (lane == 0) {
             if (mn == ~0ull) { idx_out[(size_t)qi * k + j] = -1; dist_out[(size_t)qi * k + j] = __builtin_nanf(""); }
             else { idx_out[(size_t)qi * k + j] = (int)(mn & 0xffffffffull); dist_out[(size_t)qi * k + j] = __uint_as_float((unsigned)(mn >> 32)); }
