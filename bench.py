@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="objects per step per GPU (sized for 288 GB of HBM: big launches amortise the latency-bound stages)")
+    ap.add_argument("--batch", type=int, default=512, help="objects per step per GPU (sized for 288 GB of HBM: big launches amortise the latency-bound stages)")
     ap.add_argument("--train-per-class", type=int, default=10, help="training objects per class (codebook ~ 1024 words each)")
     ap.add_argument("--resident-batches", type=int, default=2, help="distinct input batches kept in HBM and cycled")
     ap.add_argument("--cpu-objects", type=int, default=24, help="objects of the bounded CPU-baseline sample, ~0.5 s each on 16 threads (0 = skip)")
@@ -162,7 +162,7 @@ def main():
         roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 3), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_note": "bytes beyond the XCD L2s (Infinity Cache + HBM) per launch, PMC; the kernel is MFMA-bound: its "
-                                    "algorithmic bytes (f16 codebook + queries once) are 0.26 GB, the rest is tile re-streaming served by the Infinity Cache",
+                                    "algorithmic bytes (f16 codebook + queries once) are 0.44 GB, the rest is tile re-streaming served by the Infinity Cache",
                     "attainable_note": "bare MFMA loops (tools/mfma_shape_bench.hip, operands in registers, random f16) sustain 1.96 PFLOP/s with 16x16x32 and 1.63 with 32x32x16 on this chip under DVFS",
                     "flop_per_launch": flop * mult, "ms_per_launch": round(ms_knn, 4),
                     "note": "candidate stage of the exact kNN: 16-bit MFMA scores rank the codewords, every returned neighbour is "
