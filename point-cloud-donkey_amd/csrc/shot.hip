@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
     const float r12sq_f = a.r12sq_f;
     const uint32_t* cs = a.cell_start + (size_t)o * ISM_GRID_STRIDE;
     const uint32_t base = a.pt_off[o];
-    uint32_t qn = 0, total = 0;
+    uint32_t qn = 0, qh = 0, total = 0;
     struct P3 { float x, y, z; };
     ball_for_each(m, cs, cr, cx, cy, cz, a.radius, lane, sm.rows[wv],
                   [&](uint32_t i, bool v) { P3 p = {0.f, 0.f, 0.f}; if (v) { p.x = a.sx[base + i]; p.y = a.sy[base + i]; p.z = a.sz[base + i]; } return p; },
@@ -246,26 +246,24 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
         }
         const unsigned long long mask = __ballot(pass);
         if (pass) {
-            const uint32_t pos = qn + __popcll(mask & ((1ull << lane) - 1ull));
+            const uint32_t pos = (qh + qn + __popcll(mask & ((1ull << lane) - 1ull))) & 127u;      // 128-entry circular queue
             sm.qd[wv][pos] = make_float4(dx, dy, dz, d2); sm.qi[wv][pos] = base + i;
         }
         const uint32_t c = __popcll(mask);
         qn += c; total += c;
         if (qn >= 64) {
             // a full wave of neighbours (LDS traffic of one wave is ordered; no barrier needed)
-            const float4 e = sm.qd[wv][lane];
-            shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][lane], e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq_f, LRef, aRef, bRef);
-            const uint32_t rem = qn - 64;
-            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f); uint32_t t0i = 0;
-            if ((uint32_t)lane < rem) { t4 = sm.qd[wv][64 + lane]; t0i = sm.qi[wv][64 + lane]; }
-            if ((uint32_t)lane < rem) { sm.qd[wv][lane] = t4; sm.qi[wv][lane] = t0i; }
-            qn = rem;
+            const uint32_t at = (qh + lane) & 127u;
+            const float4 e = sm.qd[wv][at];
+            shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][at], e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq_f, LRef, aRef, bRef);
+            qh = (qh + 64) & 127u; qn -= 64;
         }
     });
     if (qn > 0) {
         const bool act = (uint32_t)lane < qn;
-        const float4 e = sm.qd[wv][lane];
-        shot_neighbour<COLOR>(a, hist, act, act ? sm.qi[wv][lane] : 0u, e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq_f, LRef, aRef, bRef);
+        const uint32_t at = (qh + lane) & 127u;
+        const float4 e = sm.qd[wv][at];
+        shot_neighbour<COLOR>(a, hist, act, act ? sm.qi[wv][at] : 0u, e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq_f, LRef, aRef, bRef);
     }
     if (a.count && lane == 0) a.count[k] = total;
     if (total < 5) {                                    // computePointSHOT: fewer than 5 neighbours -> NaN descriptor
