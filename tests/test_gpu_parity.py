@@ -597,6 +597,41 @@ def test_end_to_end_full_size_properties_and_oracle_sample(pkg, gpu, ora):
     np.testing.assert_allclose(mx["pos"][0, :n], out["pos"][0, :n].cpu().numpy(), atol=2e-3)
 
 
+def test_shot_is_invariant_under_rigid_motion_full_size(pkg, gpu):
+    """Size-independent property at BASELINE configs[1] sizes: SHOT-352 is built in the local reference frame, so moving the whole
+    object (points, normals, keypoints) by a rigid motion rotates the frames and leaves the descriptors where they were. Rounding of
+    the moved coordinates may carry a neighbour across a hard bin or shell boundary, so a small fraction of entries may move."""
+    import torch
+    ctx, dev = gpu
+    capi, synthetic = pkg.capi, pkg.synthetic
+    nb = synthetic.Dataset(4, 4, split=1).batch(range(4))
+    rng = np.random.default_rng(5)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    R = q.astype(np.float32); tvec = np.array([0.3, -1.1, 0.7], np.float32)
+
+    def run(xyz, nrm, kp):
+        x, y, z = (T(xyz[:, i].copy(), dev) for i in range(3)); nx, ny, nz = (T(nrm[:, i].copy(), dev) for i in range(3))
+        kx, ky, kz = (T(kp[:, i].copy(), dev) for i in range(3))
+        cloud = capi.Cloud(ctx, nb["pt_off"], x, y, z, nx, ny, nz, 0.15)
+        lrf = capi.shot_lrf(ctx, cloud, nb["kp_off"], kx, ky, kz, 0.3)
+        desc, cnt = capi.shot352(ctx, cloud, nb["kp_off"], kx, ky, kz, lrf, 0.4, want_counts=True)
+        return lrf.cpu().numpy().reshape(-1, 3, 3), desc.cpu().numpy(), cnt.cpu().numpy()
+
+    l0, d0, c0 = run(nb["xyz"], nb["normals"], nb["kp"])
+    l1, d1, c1 = run(nb["xyz"] @ R.T + tvec, nb["normals"] @ R.T, nb["kp"] @ R.T + tvec)
+    ok = ~(np.isnan(d0).any(1) | np.isnan(d1).any(1))
+    assert ok.mean() > 0.99
+    assert (np.abs(c0.astype(np.int64) - c1.astype(np.int64)) <= 2).mean() > 0.99            # a point on the sphere may fall either side
+    # frames rotate with the object: axes' = axes R^T (row vectors); a near-degenerate covariance may flip an axis for a few keypoints
+    fr = np.abs(l1[ok] - l0[ok] @ R.T).max((1, 2))
+    good = fr < 1e-3
+    assert good.mean() > 0.98, good.mean()
+    dd = np.abs(d1[ok][good] - d0[ok][good])
+    assert (dd < 2e-3).mean() > 0.999 and np.median(dd.max(1)) < 1e-4, ((dd < 2e-3).mean(), np.median(dd.max(1)))
+
+
 def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
     """BASELINE configs[1] scale without an oracle: 102 400 codewords x 352, 32 768 queries of clustered, descriptor-like unit
     vectors (plus exact duplicates of codewords and duplicated codewords). The default path (f16 MFMA candidates -> exact re-rank ->
