@@ -1,24 +1,39 @@
 #!/usr/bin/env python
 """bench.py — objects/sec classified on the ModelNet10-like SHOT-352 workload (BASELINE.json configs[1]).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL. Either the driver starts the ranks (`python -m torch.distributed.run ... bench.py --gpus N`:
+RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the environment) or, when RANK is unset, this script starts them itself as a CHILD
+`torch.distributed.run` process BEFORE anything in this process touches a GPU (a process that has initialised the GPU is never
+re-exec'ed) and exits with the child's code. A WORLD_SIZE that differs from --gpus, or fewer visible GPUs than --gpus, is an error.
 
 A step = one pass of the recognition hot path (grid -> LRF -> SHOT-352 -> NaN compaction -> exact kNN -> vote casting ->
-mean-shift maxima) over one batch of --batch synthetic objects per GPU, inputs already resident in HBM, followed by the
-path's one exchange: an all-gather of the per-object class-score records (RCCL). Per-GPU work is fixed (weak scaling);
-value = objects processed by all ranks / max-over-ranks time of the K timed steps.
+mean-shift maxima) over the FIXED test split of --objects objects (908 = ModelNet10's test split), inputs already resident in
+HBM, followed by the path's one exchange: an all-gather of the per-object class-score records (RCCL). The split is cut into
+contiguous per-rank shards (shard.shard_range; the reference loops over the objects serially, eval_classification.cpp:347-356),
+so the total work is fixed as N grows: STRONG scaling. value = objects classified by all ranks / max-over-ranks time.
 
 The JSON line also carries
   roofline      : the dominant kernel (k_knn_l2_ring16, the f16-MFMA candidate stage of the exact kNN, MFMA-bound): algorithmic
-                  flop per launch (2 * queries * codewords * 352) / mean launch time, measured with HIP events on the stream
-                  the kernel runs on (ismhip timers), vs the dense F16/BF16 MFMA peak
-  roofline_shot : descriptor extraction (k_shot<false>, HBM-bound, gather model bytes of SURVEY.md §8d)
+                  flop (2 * queries * codewords * 352) / launch time, measured with HIP events on the stream the kernel runs on
+                  (ismhip timers), vs the dense F16/BF16 MFMA peak
+  roofline_shot : descriptor extraction (k_shot<false>, HBM-bound, gather-model bytes of SURVEY.md §8d)
+  value_end_to_end : the same step with every input batch coming from pinned host memory (H2D on a copy stream, double-buffered)
+                  and the class scores copied back (D2H) inside the clock — SURVEY §8d's "first H2D -> last result D2H";
+                  reported beside `value`, never instead of it
   cpu_baseline  : the CPU oracle (kind "port": the reference itself cannot be built here) timed on this host's cores on a
                   bounded sample of the same workload; checker/baseline only, never on the measured path.
+
+--config {1,2,3,4} selects BASELINE.json configs[1..4] (1 = default headline; 2 = 2048 keypoints + 10k-word codebook;
+3 = CSHOT-1344 chi-squared partial views; 4 = FPFH-33 + SHOT-352 dual models, 50k-word codebooks), each with its own roofline.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,84 +41,169 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import __graft_entry__ as ge  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (ISMHIP_KNN_MODE=f32)
-PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense (v_mfma_f32_32x32x16_f16)
+PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 vector peak (k_knn_chi2)
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="objects per step per GPU (sized for 288 GB of HBM: big launches amortise the latency-bound stages)")
-    ap.add_argument("--train-per-class", type=int, default=10, help="training objects per class (codebook ~ 1024 words each)")
-    ap.add_argument("--resident-batches", type=int, default=2, help="distinct input batches kept in HBM and cycled")
-    ap.add_argument("--cpu-objects", type=int, default=24, help="objects of the bounded CPU-baseline sample, ~0.5 s each on 16 threads (0 = skip)")
-    ap.add_argument("--points", type=int, default=16384)
-    ap.add_argument("--keypoints", type=int, default=1024)
-    ap.add_argument("--classes", type=int, default=10)
-    args = ap.parse_args()
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE.json configs[i]")
+    ap.add_argument("--objects", type=int, default=0, help="objects of the test split classified per step by ALL ranks together (0 = the config's default; 908 for config 1)")
+    ap.add_argument("--batch", type=int, default=512, help="largest launch: a rank's shard is processed in chunks of at most this many objects")
+    ap.add_argument("--train-per-class", type=int, default=0, help="training objects per class (0 = the config's default)")
+    ap.add_argument("--cpu-objects", type=int, default=24, help="objects of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--points", type=int, default=0)
+    ap.add_argument("--keypoints", type=int, default=0)
+    ap.add_argument("--classes", type=int, default=0)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive (value_end_to_end) leg")
+    return ap.parse_args(argv)
+
+
+CONFIGS = {
+    # objects: the real split sizes are 908 / 2468 / 153 / 2468; configs 2-4 default to a bounded part of the split so that the
+    # default run finishes within minutes (name: what the line says it measured)
+    1: dict(name="configs[1]: ModelNet10-like test split, 16384 pts, 1024 uniform keypoints/object, SHOT-352 (Radius 0.4, LRF 0.3), "
+                 "exact kNN K=1 squared-L2, mean-shift bandwidth 0.6",
+            classes=10, objects=908, points=16384, keypoints=1024, train_per_class=10, models=[dict(feature="SHOT")]),
+    2: dict(name="configs[2]: ModelNet40-like, 2048 keypoints/object, SHOT-352, 10k-word codebook (seeded random subset of the training "
+                 "features, the reference's UseRandomCodebook mechanism), exact kNN K=1 squared-L2",
+            classes=40, objects=256, points=16384, keypoints=2048, train_per_class=1,
+            models=[dict(feature="SHOT", use_random_codebook=True, random_codebook_size=10000)]),
+    3: dict(name="configs[3]: Washington-like coloured partial views, CSHOT-1344, Radius/LRF 0.05, LeafSize 0.02, bandwidth 0.045, "
+                 "chi-squared exact kNN K=1, 10k-word codebook",
+            classes=51, objects=48, points=8192, keypoints=0, train_per_class=1, dataset=dict(leaf=0.02, scale=0.15, with_color=True, partial_view=True),
+            models=[dict(feature="CSHOT", radius=0.05, lrf_radius=0.05, distance="ChiSquared", bandwidth=0.045,
+                         use_random_codebook=True, random_codebook_size=10000)]),
+    4: dict(name="configs[4]: ModelNet40-like, 2048 keypoints/object, FPFH-33 + SHOT-352 as two models (class scores summed), 50k-word "
+                 "codebooks, exact kNN K=1 squared-L2",
+            classes=40, objects=256, points=16384, keypoints=2048, train_per_class=1,
+            models=[dict(feature="FPFH", radius=0.3, use_random_codebook=True, random_codebook_size=50000),
+                    dict(feature="SHOT", use_random_codebook=True, random_codebook_size=50000)]),
+}
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as a child torch.distributed.run BEFORE this process touches a GPU."""
+    import torch                                   # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible; refusing to run fewer ranks than asked\n")
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def latest_traffic_json():
+    """beyond-L2 bytes per launch from the newest committed PMC pass of this very command (profiles/round*_pmc_traffic.json)"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))
+    for f in reversed(files):
+        try:
+            return os.path.relpath(f, ROOT), json.load(open(f))
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
+def main():
+    args = parse_args()
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ        # started by torch.distributed.run
+    if args.gpus > 1 and not launched:
+        sys.exit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start one rank per GPU\n")
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
+    import __graft_entry__ as ge
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ        # launched by torch.distributed.run
-    if distributed:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the hot path has no CPU fallback"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    distributed = launched
+    if distributed:
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == world
 
     pkg = ge.load_package()
     capi, pipeline, synthetic, shard = pkg.capi, pkg.pipeline, pkg.synthetic, pkg.shard
     ctx = capi.Ctx(local_rank)            # on torch's current stream
-    C = args.classes
-    cfg = pipeline.IsmConfig(feature="SHOT", radius=0.4, lrf_radius=0.3, distance="Euclidean", k=1, bandwidth=0.6,
-                             n_classes=C, max_maxima=16)
-    rec = pipeline.Recognizer(ctx, cfg)
+    cdef = CONFIGS[args.config]
+    C = args.classes or cdef["classes"]
+    G = args.objects or cdef["objects"]
+    n_points = args.points or cdef["points"]
+    n_kp = args.keypoints or cdef["keypoints"]
+    tpc = args.train_per_class or cdef["train_per_class"]
+    ds_kw = dict(cdef.get("dataset", {}))
+    if n_kp:
+        ds_kw["n_keypoints"] = n_kp
 
-    # ---- model: codebook trained the reference's way from a subset of the synthetic training split (replicated per rank)
+    # ---- models: codebooks trained the reference's way from the synthetic training split (replicated per rank)
     t0 = time.time()
-    n_train = args.train_per_class * C
-    train = synthetic.Dataset(C, n_train, split=0, n_points=args.points, n_keypoints=args.keypoints)
+    n_train = tpc * C
+    train = synthetic.Dataset(C, n_train, split=0, n_points=n_points, **ds_kw)
     order = sorted(range(n_train), key=lambda i: (train.label(i), i))
-    tb = []
-    for s in range(0, n_train, 32):
-        tb.append(pipeline.DeviceBatch(train.batch(order[s:s + 32]), dev))
-    cb = rec.train(tb)
+    recs, cbs, cfgs = [], [], []
+    tb = [pipeline.DeviceBatch(train.batch(order[s:s + 32]), dev) for s in range(0, n_train, 32)]
+    for m in cdef["models"]:
+        cfg = pipeline.IsmConfig(k=1, n_classes=C, max_maxima=16, **m)
+        rec = pipeline.Recognizer(ctx, cfg)
+        cbs.append(rec.train(tb))
+        recs.append(rec); cfgs.append(cfg)
     del tb
-    n_words = cb["words"].shape[0]
+    n_words = [int(cb["words"].shape[0]) for cb in cbs]
     t_train = time.time() - t0
 
-    # ---- inputs: this rank's shard of the test split, resident in HBM before the clock starts
-    B = args.batch
-    test = synthetic.Dataset(C, 908, split=1, n_points=args.points, n_keypoints=args.keypoints)
-    n_res = max(1, args.resident_batches)
-    batches, batch_ids = [], []
-    for j in range(n_res):
-        ids = [((rank * n_res + j) * B + i) % 908 for i in range(B)]
-        batches.append(pipeline.DeviceBatch(test.batch(ids), dev))
-        batch_ids.append(torch.as_tensor(ids, device=dev))
+    # ---- inputs: this rank's shard of the fixed test split, resident in HBM before the clock starts
+    test = synthetic.Dataset(C, G, split=1, n_points=n_points, **ds_kw)
+    lo, hi = shard.shard_range(G, rank, world)
+    pad = shard.shard_range(G, 0, world)[1]                  # records per rank in the all-gather (largest shard)
+    n_chunks = max(1, -(-(hi - lo) // args.batch))
+    bounds = [lo + (hi - lo) * j // n_chunks for j in range(n_chunks + 1)]
+    chunks_h, chunks, chunk_ids = [], [], []
+    for j in range(n_chunks):
+        ids = list(range(bounds[j], bounds[j + 1]))
+        if not ids:
+            continue
+        nb = test.batch(ids)
+        chunks_h.append(nb)
+        chunks.append(pipeline.DeviceBatch(nb, dev))
+        chunk_ids.append(torch.as_tensor(ids, device=dev))
     torch.cuda.synchronize()
 
-    def step(i):
-        b = batches[i % n_res]
-        out = rec.detect(b)
-        recs = shard.pack_records(batch_ids[i % n_res], out["class_score"], B)
-        gathered = shard.all_gather_records(recs, world)
-        return out, gathered
+    def classify(b):
+        outs = [r.detect(b) for r in recs]
+        score = outs[0]["class_score"] if len(outs) == 1 else sum(o["class_score"] for o in outs)   # configs[4]: harness-level score fusion
+        return score, outs
 
-    correct = total = 0
+    def step(batches):
+        keep, rows, n = [], torch.full((pad, 2 + C), -1.0, dtype=torch.float32, device=dev), 0
+        for b, ids in zip(batches, chunk_ids):
+            score, outs = classify(b)
+            rows[n:n + len(ids)] = shard.pack_records(ids, score, len(ids))
+            n += len(ids)
+            keep.append(outs)
+        return shard.all_gather_records(rows, world), keep
+
     for i in range(args.warmup):
-        out, g = step(i)
+        g, _ = step(chunks)
     torch.cuda.synchronize()
     ctx.timers_enable(True)
     ctx.timers_reset()
@@ -112,7 +212,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out, g = step(args.warmup + i)
+        g, _ = step(chunks)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -123,66 +223,97 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- accuracy of the last gathered step (sanity, not part of the metric)
+    # ---- accuracy of the last gathered step (sanity, not part of the metric): every object of the split must be there once
     oi, best, _ = shard.unpack_records(g)
+    assert oi.tolist() == list(range(G)), "the all-gather did not return every object of the split exactly once"
     labels = torch.as_tensor([test.label(int(k)) for k in oi.tolist()], device=best.device)
     correct, total = int((best == labels).sum().item()), int(len(oi))
 
-    # ---- per-kernel device time (HIP events on the ctx stream, timed region only)
-    tm = {n: ctx.timer(n) for n in ["grid", "lrf", "shot352", "knn", "knn_l2_mfma", "knn_fallback", "cast_votes", "maxima"]}
+    # ---- per-kernel device time (HIP events on the ctx stream, timed region only; this rank)
+    names = ["grid", "lrf", "shot352", "cshot1344", "fpfh33", "knn", "knn_l2_mfma", "knn_chi2", "knn_fallback", "cast_votes", "maxima"]
+    tm = {n: ctx.timer(n) for n in names}
     knn_fb = {"queries": int(ctx.timer("knn_flagged_queries")[0]), "slot_items": int(ctx.timer("knn_flagged_items")[0])}
     ctx.timers_enable(False)
-    nq_per_launch = None
-    roofline = roofline_shot = None
-    if tm["knn_l2_mfma"][1] > 0:
-        # features actually searched per launch (NaN rows removed) and neighbour visits come from one extra, untimed pass
-        b = batches[0]
-        f = rec.compute_features(b, want_counts=True)
-        nq_per_launch = int(f["off"][-1])
-        m_sum = int(f["counts"].to(torch.int64).sum().item())
-        nkp = int(b.kp_off[-1])
-        ms_knn = tm["knn_l2_mfma"][0] / tm["knn_l2_mfma"][1]
-        flop = 2.0 * nq_per_launch * n_words * cfg.dim
-        ach = flop / (ms_knn * 1e-3) / 1e12
-        knn_mode = os.environ.get("ISMHIP_KNN_MODE", "f16")
-        # f16: one MFMA per product -> executed = algorithmic flop; bf16x3 executes 3x the algorithmic flop, priced as executed
-        kname, peak, mult = {"f16": ("k_knn_l2_ring" if os.environ.get("ISMHIP_KNN_RING32") == "1" else "k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0),
-                             "bf16x3": ("k_knn_l2_mfma16<bf16x3>", PEAK_F16_MFMA_TFLOPS, 3.0),
-                             "f32": ("k_knn_l2_mfma", PEAK_FP32_MFMA_TFLOPS, 1.0)}.get(knn_mode, ("k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0))
-        ach *= mult
-        # beyond-L2 bytes per launch of this kernel from the committed PMC passes of this very command (separate FETCH_SIZE /
-        # WRITE_SIZE runs, gfx950 correction applied: profiles/round1_pmc_traffic.json); null for any other workload shape
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
-            if tj.get("batch") == B and knn_mode == "f16" and args.points == 16384 and args.keypoints == 1024:
-                traffic = tj["k_knn_l2_ring16"]["bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
-        roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 3), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                    "traffic_note": "bytes beyond the XCD L2s (Infinity Cache + HBM) per launch, PMC; the kernel is MFMA-bound: its "
-                                    "algorithmic bytes (f16 codebook + queries once) are 0.44 GB, the rest is tile re-streaming served by the Infinity Cache",
-                    "attainable_note": "bare MFMA loops (tools/mfma_shape_bench.hip, operands in registers, random f16) sustain 1.96 PFLOP/s with 16x16x32 and 1.63 with 32x32x16 on this chip under DVFS",
-                    "flop_per_launch": flop * mult, "ms_per_launch": round(ms_knn, 4),
-                    "note": "candidate stage of the exact kNN: 16-bit MFMA scores rank the codewords, every returned neighbour is "
-                            "re-ranked with the exact f32 FLANN functor and proven (see DESIGN.md)"}
-        ms_shot = tm["shot352"][0] / max(1, tm["shot352"][1])
-        bytes_shot = m_sum * 24.0 + nkp * (12 + 36 + 352 * 4)
-        gbs = bytes_shot / (ms_shot * 1e-3) / 1e9
-        traffic_shot = None
-        try:
-            if traffic is not None:
-                traffic_shot = tj["k_shot<false>"]["bytes_per_launch"]
-        except (KeyError, NameError):
-            traffic_shot = None
-        roofline_shot = {"kernel": "k_shot<false>", "bound": "hbm", "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_shot, "bytes_per_launch": bytes_shot,
-                         "ms_per_launch": round(ms_shot, 4), "mean_neighbours": round(m_sum / max(1, nkp), 1)}
+    rooflines = {}
+    if rank == 0:
+        # features actually searched (NaN rows removed) and neighbour visits come from one extra, untimed pass over the shard
+        for rec, cfg, nw in zip(recs, cfgs, n_words):
+            nq_sum = m_sum = nkp = 0
+            for b in chunks:
+                f = rec.compute_features(b, want_counts=True)
+                nq_sum += int(f["off"][-1]); m_sum += int(f["counts"].to(torch.int64).sum().item()); nkp += int(b.kp_off[-1])
+            launches = len(chunks) * args.steps
+            if cfg.distance == "Euclidean" and tm["knn_l2_mfma"][1] > 0 and len(recs) == 1:
+                ms_knn = tm["knn_l2_mfma"][0] / tm["knn_l2_mfma"][1]
+                flop = 2.0 * nq_sum / len(chunks) * nw * cfg.dim
+                knn_mode = os.environ.get("ISMHIP_KNN_MODE", "f16")
+                kname, peak, mult = {"f16": ("k_knn_l2_ring" if os.environ.get("ISMHIP_KNN_RING32") == "1" else "k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0),
+                                     "bf16x3": ("k_knn_l2_mfma16<bf16x3>", PEAK_F16_MFMA_TFLOPS, 3.0),
+                                     "f32": ("k_knn_l2_mfma", PEAK_FP32_MFMA_TFLOPS, 1.0)}.get(knn_mode, ("k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0))
+                ach = flop * mult / (ms_knn * 1e-3) / 1e12
+                rooflines["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                                         "frac": round(ach / peak, 4), "traffic": None, "flop_per_launch": flop * mult,
+                                         "ms_per_launch": round(ms_knn, 4), "queries_per_launch": nq_sum / len(chunks),
+                                         "note": "candidate stage of the exact kNN: 16-bit MFMA scores rank the codewords, every returned "
+                                                 "neighbour is re-ranked with the exact f32 FLANN functor and proven (DESIGN.md §4.1)"}
+            if cfg.distance == "ChiSquared" and tm["knn_chi2"][1] > 0:
+                ms = tm["knn_chi2"][0] / tm["knn_chi2"][1]
+                flop = 5.0 * nq_sum / len(chunks) * nw * cfg.dim
+                ach = flop / (ms * 1e-3) / 1e12
+                rooflines["roofline"] = {"kernel": "k_knn_chi2", "bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+                                         "flop_per_launch": flop, "ms_per_launch": round(ms, 4), "queries_per_launch": nq_sum / len(chunks),
+                                         "note": "5 flop per (query, word, dim) element: sub, add, mul, rcp, fma (SURVEY §8d)"}
+            tname = {"SHOT": "shot352", "CSHOT": "cshot1344", "FPFH": "fpfh33"}[cfg.feature]
+            if tm[tname][1] > 0 and cfg.feature != "FPFH":
+                ms_d = tm[tname][0] / tm[tname][1]
+                per_nb, per_kp = (24.0, 12 + 36 + 352 * 4) if cfg.feature == "SHOT" else (28.0, 12 + 36 + 4 + 1344 * 4)
+                bytes_d = (m_sum * per_nb + nkp * per_kp) / len(chunks)
+                gbs = bytes_d / (ms_d * 1e-3) / 1e9
+                rooflines["roofline_shot"] = {"kernel": "k_shot<%s>" % ("true" if cfg.feature == "CSHOT" else "false"), "bound": "hbm",
+                                              "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                              "traffic": None, "bytes_per_launch": bytes_d, "ms_per_launch": round(ms_d, 4),
+                                              "mean_neighbours": round(m_sum / max(1, nkp), 1),
+                                              "lrf_plus_descriptor_ms_per_512_objects": round((tm["lrf"][0] + tm[tname][0]) / args.steps / max(1, hi - lo) * 512, 3)}
+        # beyond-L2 bytes per launch come from the committed PMC passes of this very command (separate FETCH_SIZE / WRITE_SIZE
+        # runs, gfx950 correction applied); they are NOT measured in the run that prints this line, and are null for other shapes
+        tf, tj = latest_traffic_json()
+        if tj and args.config == 1 and world == 1 and tj.get("objects") == G and tj.get("batch") == args.batch and not args.points and not args.keypoints:
+            for key in ("roofline", "roofline_shot"):
+                r = rooflines.get(key)
+                if r and r["kernel"] in tj:
+                    r["traffic"] = tj[r["kernel"]]["bytes_per_launch"]
+                    r["traffic_source"] = f"committed PMC pass of this command ({tf}); bytes beyond the XCD L2s (Infinity Cache + HBM) per launch"
 
-    # ---- CPU baseline: the oracle on a bounded sample (rank 0, N = 1 only)
+    # ---- PCIe-inclusive leg (rank-local, N = 1): pinned host inputs -> H2D on a copy stream, double-buffered; scores D2H
+    e2e = None
+    if world == 1 and not args.no_e2e:
+        stager = pipeline.HostStager(chunks_h, dev)
+        score_h = torch.empty((G, C), dtype=torch.float32).pin_memory()
+
+        def step_e2e():
+            n = 0
+            stager.begin()
+            for j, ids in enumerate(chunk_ids):
+                b = stager.get(j)                      # waits (on the compute stream) for chunk j's upload, starts chunk j+1's
+                score, outs = classify(b)
+                score_h[n:n + len(ids)].copy_(score, non_blocking=True)
+                stager.release(j)
+                n += len(ids)
+            torch.cuda.synchronize()                   # last result D2H done
+        step_e2e()
+        t0 = time.perf_counter()
+        n_e2e = max(2, min(args.steps, 4))
+        for _ in range(n_e2e):
+            step_e2e()
+        dte = time.perf_counter() - t0
+        e2e = {"value": round(G * n_e2e / dte, 3), "unit": "objects/s", "ms_per_step": round(dte / n_e2e * 1e3, 3), "steps": n_e2e,
+               "h2d_bytes_per_step": stager.bytes_per_pass, "note": "first H2D -> last class-score D2H (SURVEY §8d); uploads double-buffered on a copy stream"}
+
+    # ---- CPU baseline: the oracle on a bounded sample (rank 0, N = 1, headline config only)
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_objects > 0:
+    if rank == 0 and world == 1 and args.cpu_objects > 0 and args.config == 1:
+        cfg, cb = cfgs[0], cbs[0]
         ora = ge.load_oracle()
         n_thr = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16)     # the GPU box's CPU share for one GPU
         ora.set_num_threads(n_thr)
@@ -199,23 +330,28 @@ def main():
         ora.find_maxima(keep_off.astype(np.uint32), votes, C, cfg.bandwidth, max_maxima=cfg.max_maxima)
         t_cpu = time.perf_counter() - t0
         cpu = {"value": round(args.cpu_objects / t_cpu, 4), "unit": "objects/s", "cores": ora.get_num_threads(), "kind": "port",
-               "sample": f"{args.cpu_objects} objects of the same workload (oracle: SHOT LRF+SHOT-352+exact kNN over {n_words} words"
-                         f"+votes+mean-shift), {t_cpu:.1f} s, OpenMP over keypoints/queries as the reference"}
+               "sample": f"{args.cpu_objects} objects of the same workload (oracle: SHOT LRF+SHOT-352+exact linear-search kNN over {n_words[0]} words"
+                         f"+votes+mean-shift), {t_cpu:.1f} s, OpenMP over keypoints/queries as the reference; the reference's default "
+                         "kNN is an approximate 4-tree FLANN forest, so this is the exact-match (FLANNExactMatch) CPU cost"}
 
-    n_objects = B * args.steps * world
+    n_objects = G * args.steps
     if rank == 0:
+        cfg0 = cfgs[0]
         line = {
-            "metric": "objects/sec classified (ModelNet10-like, SHOT-352)", "value": round(n_objects / dt, 3), "unit": "objects/s",
+            "metric": "objects/sec classified (ModelNet10-like, SHOT-352)" if args.config == 1 else f"objects/sec classified (BASELINE configs[{args.config}])",
+            "value": round(n_objects / dt, 3), "unit": "objects/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": "results are the exact f32 values of the reference's functors; the kNN candidate filter runs on f16 MFMA",
-            "config": {"workload": "configs[1]: ModelNet10-like test objects, 16384 pts, 1024 uniform keypoints/object, SHOT-352 "
-                                   "(Radius 0.4, LRF 0.3), exact kNN K=1 squared-L2, mean-shift bandwidth 0.6",
-                       "objects_per_step_per_gpu": B, "points_per_object": args.points, "keypoints_per_object": args.keypoints,
-                       "classes": C, "codebook_words": int(n_words), "descriptor_dim": cfg.dim, "parallelism": f"objects sharded over {world} GPU(s), codebook replicated, 1 all-gather/step"},
-            "roofline": roofline, "roofline_shot": roofline_shot, "cpu_baseline": cpu,
-            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in tm.items()},
-            "knn_exact_fallback_last_step": knn_fb, "accuracy_last_step": round(correct / max(1, total), 4), "train_seconds": round(t_train, 1),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "results are the exact f32 values of the reference's functors; the squared-L2 kNN candidate filter runs on f16 MFMA",
+            "config": {"workload": cdef["name"], "objects_per_step_all_gpus": G, "objects_per_step_this_rank": hi - lo,
+                       "launches_per_step_per_gpu": len(chunks), "points_per_object": n_points, "keypoints_per_object": n_kp or "VoxelGrid leaf",
+                       "classes": C, "codebook_words": n_words if len(n_words) > 1 else n_words[0], "descriptor_dim": [c.dim for c in cfgs] if len(cfgs) > 1 else cfg0.dim,
+                       "parallelism": f"fixed {G}-object split sharded over {world} GPU(s) (contiguous blocks), codebook replicated, 1 RCCL all-gather/step",
+                       "collective_world_size": dist.get_world_size() if distributed else 1},
+            "roofline": rooflines.get("roofline"), "roofline_shot": rooflines.get("roofline_shot"),
+            "value_end_to_end": e2e, "cpu_baseline": cpu,
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in tm.items() if v[1] > 0},
+            "knn_exact_fallback_last_launch": knn_fb, "accuracy_last_step": round(correct / max(1, total), 4), "train_seconds": round(t_train, 1),
         }
         print(json.dumps(line))
     if distributed:

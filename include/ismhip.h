@@ -80,7 +80,7 @@ int  ismhip_timer_get(ismhip_ctx* ctx, const char* name, double* ms_out, int64_t
 
 /* ---- search surface (replaces pcl::search::KdTree built at implicit_shape_model.cpp:823-831) ---
  * Takes the NaN-free surface cloud of n_obj objects as SoA and builds a per-object uniform grid
- * (cell edge = cell_size, use max(Radius, ReferenceFrameRadius)/2) with the points counting-sorted
+ * (y/z cell edge = cell_size, x cells three times finer; use 0.4 * min(Radius, ReferenceFrameRadius)) with the points counting-sorted
  * by cell. rgba may be NULL (needed only by cshot1344): packed as PCL does, 0x00RRGGBB. */
 int  ismhip_cloud_create(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_h,
                          const float* x, const float* y, const float* z,

@@ -14,10 +14,14 @@
 #define ISM_GRID_MAXCELLS (ISM_GRID_MAXDIM * ISM_GRID_MAXDIM * ISM_GRID_MAXDIM)
 #define ISM_GRID_STRIDE (ISM_GRID_MAXCELLS + 1) // cell_start entries reserved per object
 
+// The grid is ANISOTROPIC: a ball query walks one contiguous x-run of points per (y,z) cell row, so the y/z edge sets the
+// number of rows (per-row set-up, ragged row ends) while the x edge only sets how tightly the chord of the ball clips a row.
+// x cells are therefore ISM_GRID_XFRAC times finer than y/z cells: fewer, longer rows AND less over-fetch at their ends.
+#define ISM_GRID_XFRAC 3
 struct GridMeta {
     float minv[3];
-    float cell;       // edge actually used (>= requested)
-    float inv_cell;
+    float cell[3];      // edge actually used per axis (>= requested)
+    float inv_cell[3];
     int   dim[3];
     float centroid[3];
     uint32_t n_finite;
@@ -32,12 +36,14 @@ struct ismhip_cloud {
     // caller's arrays (borrowed, original order)
     const float *x = nullptr, *y = nullptr, *z = nullptr, *nx = nullptr, *ny = nullptr, *nz = nullptr;
     const uint32_t* rgba = nullptr;
-    // cell-sorted SoA copies (owned)
-    float *sx = nullptr, *sy = nullptr, *sz = nullptr, *snx = nullptr, *sny = nullptr, *snz = nullptr;
-    float *sL = nullptr, *sa = nullptr, *sb = nullptr;   // normalised CIELab (only with rgba)
-    uint32_t* sorig = nullptr;            // object-local original index of every sorted point
+    // cell-sorted packed copies (owned): one 16-byte record per point and array, so that a candidate costs ONE coalesced
+    // global_load_dwordx4 (and a queued neighbour one 16-byte gather for its normal) instead of three dword loads
+    float4* sp4 = nullptr;                // (x, y, z, bits of the object-local original index)
+    float4* sn4 = nullptr;                // (nx, ny, nz, 0)
+    float4* slab4 = nullptr;              // normalised CIELab (L, a, b, 0), only with rgba
     uint32_t* cell_of_pt = nullptr;       // scratch: cell id per original point
     uint32_t* rank_of_pt = nullptr;       // scratch: arrival rank inside the cell
+    uint32_t* members = nullptr;          // scratch: object-local original indices grouped by cell in arrival order
     GridMeta* meta = nullptr;             // [n_obj]
     uint32_t* cell_start = nullptr;       // [n_obj * ISM_GRID_STRIDE]
     float requested_cell = 0.f;
@@ -100,6 +106,9 @@ struct ismhip_ctx {
     int knn_dbg = 0;             // env ISMHIP_KNN_DBG: timing experiments on k_knn_l2_ring (1 no epilogue, 2 no MFMA, 3 no DMA); results invalid
     bool knn_no_ring = false;    // env ISMHIP_KNN_NORING=1: f16 candidates by the register-staged kernel instead of the LDS-DMA ring (A/B runs)
     bool knn_kb32 = false;       // env ISMHIP_KNN_KB32=1: f16 candidates with 32-deep LDS slices instead of 64 (A/B runs)
+    bool xcd_map = true;         // env ISMHIP_XCD_MAP=0: per-object kernels on the plain object-major block order instead of the XCD-local map (A/B runs)
+    float grid_xfrac = 0.f;      // env ISMHIP_GRID_XFRAC: x cells this many times finer than y/z cells (default ISM_GRID_XFRAC; A/B runs)
+    int shot_var = 0;            // env ISMHIP_SHOT_VAR=2: k_shot on the contiguous candidate sweep instead of 16 interleaved segments (A/B runs; same histogram)
     int knn_mode = 0;            // env ISMHIP_KNN_MODE = f16 (0, default) | bf16x3 (1) | f32 (2): squared-L2 candidate kernel (A/B runs, tests)
 };
 
@@ -223,6 +232,22 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// XCD-local block map for the per-object kernels. The hardware deals consecutive workgroup ids round-robin over the 8 XCDs
+// (blocks b and b + 8 share one, MI355X_MICROARCH "Workgroup dispatch"), each with its own 4 MiB L2. With a (blocks, objects) 2-D
+// grid the blocks of ONE object land on all eight XCDs and every L2 pulls every object's cloud from beyond (measured round 1:
+// 8x the compulsory fetch). Here the grid is 1-D, 8 * nbx * ceil(n_obj / 8) blocks: the blocks with id = xcd (mod 8) walk the
+// objects xcd, xcd + 8, ... one after the other, so an object's ~400 KB cloud is fetched once, into one L2. Speed only: the
+// result does not depend on the placement. Returns false for the padding blocks of the last object group.
+// Fewer than 8 objects (single-object detect()): plain object-major order, so that all XCDs work.
+__device__ __forceinline__ bool xcd_object_block(int nbx, int n_obj, int& o, int& bx) {
+    if (n_obj < 8) { o = blockIdx.x / nbx; bx = blockIdx.x % nbx; return true; }
+    const int slot = blockIdx.x >> 3;
+    o = (slot / nbx) * 8 + (blockIdx.x & 7);
+    bx = slot % nbx;
+    return o < n_obj;
+}
+static inline unsigned xcd_object_grid(unsigned nbx, int n_obj) { return n_obj < 8 ? nbx * (unsigned)n_obj : 8u * nbx * (unsigned)((n_obj + 7) / 8); }
+
 // cell coordinate of a value along one axis, clamped (monotone in v)
 __device__ __forceinline__ int cell_coord(float v, float minv, float inv_cell, int dim) {
     int c = (int)floorf((v - minv) * inv_cell);
@@ -236,8 +261,8 @@ __device__ __forceinline__ bool ball_cells(const GridMeta& m, float qx, float qy
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float pad = r * 1e-5f + fabsf(q[a]) * 4e-7f + 1e-30f;   // absorbs the rounding of q±r and of the binning
-        const float lo = (q[a] - r - pad - m.minv[a]) * m.inv_cell;
-        const float hi = (q[a] + r + pad - m.minv[a]) * m.inv_cell;
+        const float lo = (q[a] - r - pad - m.minv[a]) * m.inv_cell[a];
+        const float hi = (q[a] + r + pad - m.minv[a]) * m.inv_cell[a];
         int l = (int)floorf(lo), h = (int)floorf(hi);
         if (h < 0 || l > m.dim[a] - 1) return false;
         cr.lo[a] = l < 0 ? 0 : l;
@@ -251,14 +276,14 @@ __device__ __forceinline__ bool ball_cells(const GridMeta& m, float qx, float qy
 __device__ __forceinline__ bool row_cells(const GridMeta& m, const CellRange& cr, int gy, int gz,
                                           float qx, float qy, float qz, float r, int& lo, int& hi) {
     const float pad = r * 2e-5f + (fabsf(qx) + fabsf(qy) + fabsf(qz)) * 1e-6f + 1e-30f;
-    const float y0 = m.minv[1] + (float)gy * m.cell, z0 = m.minv[2] + (float)gz * m.cell;
-    const float dy = fmaxf(fmaxf(y0 - qy, qy - (y0 + m.cell)) - pad, 0.f);
-    const float dz = fmaxf(fmaxf(z0 - qz, qz - (z0 + m.cell)) - pad, 0.f);
+    const float y0 = m.minv[1] + (float)gy * m.cell[1], z0 = m.minv[2] + (float)gz * m.cell[2];
+    const float dy = fmaxf(fmaxf(y0 - qy, qy - (y0 + m.cell[1])) - pad, 0.f);
+    const float dz = fmaxf(fmaxf(z0 - qz, qz - (z0 + m.cell[2])) - pad, 0.f);
     const float rr = r + pad;
     const float rem = rr * rr - (dy * dy + dz * dz);
     if (!(rem > 0.f)) return false;
     const float hc = sqrtf(rem) + pad;
-    int l = (int)floorf((qx - hc - m.minv[0]) * m.inv_cell), h = (int)floorf((qx + hc - m.minv[0]) * m.inv_cell);
+    int l = (int)floorf((qx - hc - m.minv[0]) * m.inv_cell[0]), h = (int)floorf((qx + hc - m.minv[0]) * m.inv_cell[0]);
     lo = l < cr.lo[0] ? cr.lo[0] : l;
     hi = h > cr.hi[0] ? cr.hi[0] : h;
     return lo <= hi;
@@ -267,16 +292,28 @@ __device__ __forceinline__ bool row_cells(const GridMeta& m, const CellRange& cr
 // ---- flattened ball traversal ---------------------------------------------------------------------------------------------
 // A ball query touches (2R/cell+1)^2 cell rows; walking them one after the other costs, per row, the chord arithmetic on all 64
 // lanes, two dependent cell_start loads and a mostly half-empty wave of points. Here the lanes first take one row EACH (chord,
-// start, length: one round trip for up to 64 rows), a wave prefix sum lays the rows end to end, and the wave then sweeps the
-// concatenated candidate list 64 at a time with every lane busy; a lane finds its row by walking a cursor through the prefix
-// table (rows are visited in order, so the cursor only moves forward). f(i, valid) gets the object-local sorted point index.
+// start, length: one round trip for up to 64 rows), a wave prefix sum lays the non-empty rows end to end, and the wave then sweeps
+// the concatenated candidate list 64 at a time with every lane busy.
+// Candidate -> row without a search: every non-empty row marks its LAST candidate in a bit mask (one ds_or_b64 per row batch);
+// for the 64 candidates of a block the row of lane l is (rows that ended before the block: a running popcount) + (marks below l:
+// v_mbcnt on the block's 64-bit word, which is wave-uniform and read one block ahead), and ONE per-lane LDS read of the row's
+// (start - offset) turns the flat index into the sorted point index. Round 1 walked a per-lane cursor through a prefix table:
+// three to four dependent LDS round trips per block.
+#define ISM_ROWS_CAP 4096                  // candidates per window of the mark mask (64 words); longer row batches take several windows
 struct WaveRows {
-    uint32_t off[65];      // exclusive prefix of the row lengths
-    uint32_t start[64];    // first sorted index of each row
+    unsigned long long last[ISM_ROWS_CAP / 64];   // bit i of last[b]: candidate 64 b + i (window-relative) is the last one of its row
+    int delta[64];                                // per non-empty row: first sorted index - flat offset
+    uint32_t rows_before[ISM_ROWS_CAP / 64];      // NG > 1 only: rows that ended before block b (window-relative)
 };
 // L(i, valid) loads and returns the point record (issued one sweep AHEAD of its use, so the next 64 candidates are in flight
-// while the current ones are processed); F(record, i, valid) consumes it.
-template <class L, class F>
+// while the current ones are processed); F(record, i, valid) consumes it. i = object-local sorted point index.
+// NG = 1: the wave sweeps the flat list 64 consecutive candidates at a time (fully coalesced: 1 KB per load instruction).
+// NG = 8: the list is cut into 8 contiguous segments and every group of 8 lanes walks its own segment (128 B per group and
+//         load: still whole cache lines). The 64 candidates a wave looks at together then come from 8 DISTANT parts of the ball
+//         instead of one short stretch of one cell row -- for k_shot this is what matters: neighbours that are adjacent in the
+//         cell-sorted order fall into the same (sector, cosine) bin, and same-address LDS atomics of one wave instruction
+//         serialise (measured: SHOT got SLOWER with finer x cells, i.e. with FEWER candidates but a more coherent order).
+template <int NG = 1, bool IL = false, class L, class F>
 __device__ __forceinline__ void ball_for_each(const GridMeta& m, const uint32_t* __restrict__ cs, const CellRange& cr,
                                               float qx, float qy, float qz, float r, int lane, WaveRows& wr, L&& load, F&& f) {
     const int ny = cr.hi[1] - cr.lo[1] + 1, nrows = ny * (cr.hi[2] - cr.lo[2] + 1);
@@ -291,28 +328,78 @@ __device__ __forceinline__ void ball_for_each(const GridMeta& m, const uint32_t*
                 s = cs[rb + xl]; len = cs[rb + xh + 1] - s;
             }
         }
-        const uint32_t inc = wave_incl_scan_u32(len);
-        wr.off[lane + 1] = inc; wr.start[lane] = s;
-        if (lane == 0) wr.off[0] = 0;
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        uint32_t jc = 0;                                     // LDS traffic of one wave is ordered: no barrier needed
-        auto locate = [&](uint32_t idx, bool v) -> uint32_t {
-            if (!v) return 0u;
-            while (idx >= wr.off[jc + 1]) ++jc;
-            return wr.start[jc] + (idx - wr.off[jc]);
-        };
+        const uint32_t end = wave_incl_scan_u32(len);                            // flat offset one past this row's last candidate
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
         if (total == 0) continue;
-        bool vn = (uint32_t)lane < total;
-        uint32_t in = locate((uint32_t)lane, vn);
-        auto rn = load(in, vn);
-        for (uint32_t c = 0; c < total; c += 64) {
-            const bool v = vn; const uint32_t i = in; const auto rec = rn;
-            if (c + 64 < total) {
-                vn = c + 64 + lane < total;
-                in = locate(c + 64 + lane, vn);
-                rn = load(in, vn);
+        const unsigned long long ne = __ballot(len != 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                   // the previous batch's table reads are done
+        if (len != 0) wr.delta[__popcll(ne & ((1ull << lane) - 1ull))] = (int)s - (int)(end - len);
+        for (uint32_t w0 = 0; w0 < total; w0 += ISM_ROWS_CAP) {                  // one window unless a row batch holds > 4096 candidates
+            const uint32_t wn = min(total - w0, (uint32_t)ISM_ROWS_CAP);
+            wr.last[lane] = 0ull;                                               // LDS traffic of one wave is ordered: no barrier needed
+            if (len != 0 && end > w0 && end <= w0 + wn) atomicOr(&wr.last[(end - 1 - w0) >> 6], 1ull << ((end - 1 - w0) & 63));
+            // The marks are read back by OTHER lanes. The hardware keeps the LDS operations of a wave in order, but the compiler
+            // reasons per thread: without this (instruction-free) wavefront fence it forwards the 0 a lane has just stored to
+            // that lane's own read of last[lane], as if no other lane could have written in between.
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            uint32_t row_base = (uint32_t)__popcll(__ballot(len != 0 && end <= w0));   // rows that ended before this window
+            if (NG == 1) {
+                auto mask_of = [&](uint32_t b) -> unsigned long long {             // wave-uniform word -> SGPR pair
+                    const unsigned long long v = wr.last[b];
+                    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffull));
+                };
+                auto locate = [&](unsigned long long mk, uint32_t rb, uint32_t flat, bool v) -> uint32_t {
+                    if (!v) return 0u;
+                    const uint32_t row = rb + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                    return (uint32_t)(wr.delta[row] + (int)flat);
+                };
+                unsigned long long mk = mask_of(0);
+                bool vn = (uint32_t)lane < wn;
+                uint32_t in = locate(mk, row_base, w0 + lane, vn);
+                auto rn = load(in, vn);
+                for (uint32_t c = 0; c < wn; c += 64) {
+                    const bool v = vn; const uint32_t i = in; const auto rec = rn;
+                    if (c + 64 < wn) {
+                        row_base += (uint32_t)__popcll(mk);
+                        mk = mask_of((c >> 6) + 1);
+                        vn = c + 64 + lane < wn;
+                        in = locate(mk, row_base, w0 + c + 64 + lane, vn);
+                        rn = load(in, vn);
+                    }
+                    f(rec, i, v);
+                }
+            } else {
+                constexpr int GL = 64 / NG;                                      // lanes per group
+                {   // rows that ended before every 64-candidate block: exclusive prefix of the blocks' mark counts
+                    const uint32_t pc = (uint32_t)__popcll(wr.last[lane]);
+                    wr.rows_before[lane] = row_base + wave_incl_scan_u32(pc) - pc;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                const uint32_t seg = ((wn + NG - 1) / NG + GL - 1) / GL * GL;   // segment length, a multiple of the group width
+                // IL: lane l walks segment l % NG (the 8 regions alternate from lane to lane) instead of segment l / GL
+                const uint32_t grp = IL ? (uint32_t)(lane % NG) : (uint32_t)(lane / GL), sub = IL ? (uint32_t)(lane / NG) : (uint32_t)(lane % GL);
+                const uint32_t g0 = grp * seg + sub;
+                const uint32_t gend = min((grp + 1u) * seg, wn);
+                auto locate = [&](uint32_t flat, bool v) -> uint32_t {          // flat: window-relative
+                    if (!v) return 0u;
+                    const unsigned long long mk = wr.last[flat >> 6];
+                    const uint32_t row = wr.rows_before[flat >> 6] + (uint32_t)__popcll(mk & ((1ull << (flat & 63u)) - 1ull));
+                    return (uint32_t)(wr.delta[row] + (int)(w0 + flat));
+                };
+                bool vn = g0 < gend;
+                uint32_t in = locate(g0, vn);
+                auto rn = load(in, vn);
+                for (uint32_t c = 0; c < seg; c += GL) {
+                    const bool v = vn; const uint32_t i = in; const auto rec = rn;
+                    if (c + GL < seg) {
+                        vn = g0 + c + GL < gend;
+                        in = locate(g0 + c + GL, vn);
+                        rn = load(in, vn);
+                    }
+                    f(rec, i, v);
+                }
             }
-            f(rec, i, v);
         }
     }
 }

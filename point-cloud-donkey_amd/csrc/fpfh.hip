@@ -15,7 +15,7 @@ namespace {
 
 struct FpfhArgs {
     const uint32_t* pt_off; const GridMeta* meta; const uint32_t* cell_start;
-    const float *sx, *sy, *sz, *snx, *sny, *snz;
+    const float4 *sp4, *sn4;
     const uint32_t* kp_off; const float *kx, *ky, *kz;
     float radius, r2;
     uint8_t* flag;      // [n_pts] sorted index space
@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void k_fpfh_mark(FpfhArgs a) {
                 const int rb = (gz * m.dim[1] + gy) * m.dim[0];
                 const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
                 for (uint32_t t = s + lane; t < e; t += 64) {
-                    const float d2 = sqdist3(a.sx[base + t], a.sy[base + t], a.sz[base + t], cx, cy, cz);
+                    const float4 q = a.sp4[base + t];
+                    const float d2 = sqdist3(q.x, q.y, q.z, cx, cy, cz);
                     if (d2 < a.r2) { a.flag[base + t] = 1; total++; }
                 }
             }
@@ -91,8 +92,9 @@ __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
     unsigned int* hist = s_hist[wv];
     if (lane < 36) hist[lane] = 0u;
     __builtin_amdgcn_wave_barrier();
-    const float px = a.sx[base + p], py = a.sy[base + p], pz = a.sz[base + p];
-    const float pnx = a.snx[base + p], pny = a.sny[base + p], pnz = a.snz[base + p];
+    const float4 pp = a.sp4[base + p], pn = a.sn4[base + p];
+    const float px = pp.x, py = pp.y, pz = pp.z;
+    const float pnx = pn.x, pny = pn.y, pnz = pn.z;
     const GridMeta m = a.meta[o];
     CellRange cr;
     ball_cells(m, px, py, pz, a.radius, cr);
@@ -106,13 +108,15 @@ __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
             const int rb = (gz * m.dim[1] + gy) * m.dim[0];
             const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
             for (uint32_t t = s + lane; t < e; t += 64) {
-                const float qx = a.sx[base + t], qy = a.sy[base + t], qz = a.sz[base + t];
+                const float4 qq = a.sp4[base + t];
+                const float qx = qq.x, qy = qq.y, qz = qq.z;
                 const float d2 = sqdist3(qx, qy, qz, px, py, pz);
                 if (!(d2 < a.r2)) continue;
                 total++;
                 if (t == p) continue;
                 float f1, f2, f3;
-                if (!pair_features(px, py, pz, pnx, pny, pnz, qx, qy, qz, a.snx[base + t], a.sny[base + t], a.snz[base + t], f1, f2, f3)) continue;
+                const float4 qn = a.sn4[base + t];
+                if (!pair_features(px, py, pz, pnx, pny, pnz, qx, qy, qz, qn.x, qn.y, qn.z, f1, f2, f3)) continue;
                 // the three bin formulas are evaluated in double as in PCL (float operands, double constants)
                 const int h1 = clamp_bin((int)floor(11 * (((double)f1 + 3.14159265358979323846) * (double)d_pi)));
                 const int h2 = clamp_bin((int)floor(11 * (((double)f2 + 1.0) * 0.5)));
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256) void k_fpfh_sum(FpfhArgs a) {
             for (uint32_t t0 = s; t0 < e; t0 += 64) {
                 const uint32_t i = t0 + lane;
                 bool pass = false; float d2 = 0.f;
-                if (i < e) { d2 = sqdist3(a.sx[base + i], a.sy[base + i], a.sz[base + i], cx, cy, cz); pass = d2 < a.r2; }
+                if (i < e) { const float4 q = a.sp4[base + i]; d2 = sqdist3(q.x, q.y, q.z, cx, cy, cz); pass = d2 < a.r2; }
                 const unsigned long long mask = __ballot(pass);
                 total += __popcll(mask);
                 const bool use = pass && d2 != 0.f;                      // "minus the query point itself"
@@ -207,7 +211,7 @@ extern "C" int ismhip_fpfh33(ismhip_ctx* ctx, const ismhip_cloud* cloud, const u
     if (!flag || !spfh) return ISMHIP_ERR_NOMEM;
     FpfhArgs a;
     a.pt_off = cloud->pt_off; a.meta = cloud->meta; a.cell_start = cloud->cell_start;
-    a.sx = cloud->sx; a.sy = cloud->sy; a.sz = cloud->sz; a.snx = cloud->snx; a.sny = cloud->sny; a.snz = cloud->snz;
+    a.sp4 = cloud->sp4; a.sn4 = cloud->sn4;
     a.kp_off = ko; a.kx = kpx; a.ky = kpy; a.kz = kpz;
     a.radius = radius; a.r2 = (float)((double)radius * (double)radius);
     a.flag = flag; a.spfh = spfh; a.desc = desc_out; a.count = neighbour_count_out; a.max_pts = cloud->max_pts;

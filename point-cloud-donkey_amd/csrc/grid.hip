@@ -2,9 +2,10 @@
 // Replaces the pcl::search::KdTree the reference builds per object (implicit_shape_model.cpp:823-831):
 // an exact fixed-radius search over a grid is equivalent up to neighbour order.
 //
-// HBM layout: points of all objects are concatenated SoA (x|y|z|nx|ny|nz, 4-byte floats). The sorted copy
-// orders every object's points by cell id (x fastest), so the 2r-wide x-run of cells a query ball touches
-// in one (y,z) row is ONE contiguous, coalesced span of each array.
+// HBM layout: points of all objects are concatenated SoA (x|y|z|nx|ny|nz, 4-byte floats) as the caller hands them over. The
+// sorted copy orders every object's points by cell id (x fastest, original index inside a cell) and packs them as 16-byte
+// records (x,y,z,index | nx,ny,nz,0 | L,a,b,0), so the 2r-wide x-run of cells a query ball touches in one (y,z) row is ONE
+// contiguous span read with one coalesced global_load_dwordx4 per candidate.
 #include "common.h"
 #include <cfloat>
 
@@ -12,7 +13,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void k_bbox_meta(const uint32_t* __restrict__ pt_off,
                                                    const float* __restrict__ x, const float* __restrict__ y,
-                                                   const float* __restrict__ z, float req_cell,
+                                                   const float* __restrict__ z, float req_cell, float x_frac,
                                                    GridMeta* __restrict__ meta, uint32_t* __restrict__ cell_start) {
     const int o = blockIdx.x;
     const uint32_t b = pt_off[o], e = pt_off[o + 1];
@@ -55,18 +56,16 @@ __global__ __launch_bounds__(256) void k_bbox_meta(const uint32_t* __restrict__ 
             for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], s_mn[k][a]); hi[a] = fmaxf(hi[a], s_mx[k][a]); ss[a] += s_s[k][a]; }
         }
         if (c == 0) { for (int a = 0; a < 3; ++a) { lo[a] = 0.f; hi[a] = 0.f; } }
-        float cell = req_cell > 0.f ? req_cell : 1.f;
-        for (int it = 0; it < 64; ++it) {
-            bool ok = true;
-            for (int a = 0; a < 3; ++a) if ((hi[a] - lo[a]) / cell >= (float)(ISM_GRID_MAXDIM - 1)) ok = false;
-            if (ok) break;
-            cell *= 2.f;
-        }
-        m.cell = cell; m.inv_cell = 1.0f / cell;
+        // requested edge = the y/z edge; x cells are ISM_GRID_XFRAC times finer. An axis that would need more than
+        // ISM_GRID_MAXDIM cells gets the smallest edge that fits.
         int ncell = 1;
         for (int a = 0; a < 3; ++a) {
+            float cell = req_cell > 0.f ? req_cell : 1.f;
+            if (a == 0) cell *= x_frac;
+            if (!((hi[a] - lo[a]) / cell < (float)(ISM_GRID_MAXDIM - 1))) cell = fmaxf(cell, (hi[a] - lo[a]) / ((float)ISM_GRID_MAXDIM - 1.5f));
+            m.cell[a] = cell; m.inv_cell[a] = 1.0f / cell;
             m.minv[a] = lo[a];
-            int d = (int)floorf((hi[a] - lo[a]) * m.inv_cell) + 1;
+            int d = (int)floorf((hi[a] - lo[a]) * m.inv_cell[a]) + 1;
             d = d < 1 ? 1 : (d > ISM_GRID_MAXDIM ? ISM_GRID_MAXDIM : d);
             m.dim[a] = d; ncell *= d;
             m.centroid[a] = c ? (float)(ss[a] / (double)c) : 0.f;   // pcl::compute3DCentroid (double accumulate)
@@ -92,9 +91,9 @@ __global__ __launch_bounds__(256) void k_count(const uint32_t* __restrict__ pt_o
     const GridMeta m = meta[o];
     const float px = x[i], py = y[i], pz = z[i];
     if (!(isfinite(px) && isfinite(py) && isfinite(pz))) { cell_of_pt[i] = 0xffffffffu; return; }
-    const int cx = cell_coord(px, m.minv[0], m.inv_cell, m.dim[0]);
-    const int cy = cell_coord(py, m.minv[1], m.inv_cell, m.dim[1]);
-    const int cz = cell_coord(pz, m.minv[2], m.inv_cell, m.dim[2]);
+    const int cx = cell_coord(px, m.minv[0], m.inv_cell[0], m.dim[0]);
+    const int cy = cell_coord(py, m.minv[1], m.inv_cell[1], m.dim[1]);
+    const int cz = cell_coord(pz, m.minv[2], m.inv_cell[2], m.dim[2]);
     const uint32_t c = (uint32_t)((cz * m.dim[1] + cy) * m.dim[0] + cx);
     cell_of_pt[i] = c;
     rank_of_pt[i] = atomicAdd(&cell_start[(size_t)o * ISM_GRID_STRIDE + c], 1u);
@@ -133,6 +132,22 @@ __global__ __launch_bounds__(1024) void k_scan(const GridMeta* __restrict__ meta
     if (threadIdx.x == 0) cs[ncell] = s_carry;
 }
 
+// members[b + cell_start[c] + arrival rank] = object-local index: the points of every cell, grouped (arrival order)
+__global__ __launch_bounds__(256) void k_members(const uint32_t* __restrict__ pt_off, const uint32_t* __restrict__ cell_start,
+                                                 const uint32_t* __restrict__ cell_of_pt, const uint32_t* __restrict__ rank_of_pt,
+                                                 uint32_t* __restrict__ members) {
+    const int o = blockIdx.y;
+    const uint32_t b = pt_off[o], e = pt_off[o + 1];
+    const uint32_t i = b + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e) return;
+    const uint32_t c = cell_of_pt[i];
+    if (c == 0xffffffffu) return;
+    members[b + cell_start[(size_t)o * ISM_GRID_STRIDE + c] + rank_of_pt[i]] = i - b;
+}
+
+// Scatter into the cell-sorted packed arrays. The position of a point inside its cell is its rank BY ORIGINAL INDEX among the
+// cell's members (a stable counting sort), not the atomic arrival rank of k_count: the sorted copy, and with it the order of
+// every floating-point accumulation over a neighbourhood (LRF covariance, FPFH sums), is the same from run to run.
 template <bool COLOR>
 __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ pt_off,
                                                  const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
@@ -140,21 +155,21 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ pt
                                                  const uint32_t* __restrict__ rgba,
                                                  const float* __restrict__ lut_srgb, const float* __restrict__ lut_sxyz,
                                                  const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ cell_of_pt,
-                                                 const uint32_t* __restrict__ rank_of_pt,
-                                                 float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz,
-                                                 float* __restrict__ snx, float* __restrict__ sny, float* __restrict__ snz,
-                                                 float* __restrict__ sL, float* __restrict__ sa, float* __restrict__ sb,
-                                                 uint32_t* __restrict__ sorig) {
+                                                 const uint32_t* __restrict__ members,
+                                                 float4* __restrict__ sp4, float4* __restrict__ sn4, float4* __restrict__ slab4) {
     const int o = blockIdx.y;
     const uint32_t b = pt_off[o], e = pt_off[o + 1];
     const uint32_t i = b + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= e) return;
     const uint32_t c = cell_of_pt[i];
     if (c == 0xffffffffu) return;
-    const uint32_t d = b + cell_start[(size_t)o * ISM_GRID_STRIDE + c] + rank_of_pt[i];
-    sx[d] = x[i]; sy[d] = y[i]; sz[d] = z[i];
-    snx[d] = nx[i]; sny[d] = ny[i]; snz[d] = nz[i];
-    sorig[d] = i - b;
+    const uint32_t* cs = cell_start + (size_t)o * ISM_GRID_STRIDE;
+    const uint32_t m0 = cs[c], m1 = cs[c + 1], me = i - b;
+    uint32_t rank = 0;
+    for (uint32_t t = m0; t < m1; ++t) rank += members[b + t] < me;
+    const uint32_t d = b + m0 + rank;
+    sp4[d] = make_float4(x[i], y[i], z[i], __uint_as_float(me));
+    sn4[d] = make_float4(nx[i], ny[i], nz[i], 0.f);
     if (COLOR) {
         // RGB2CIELAB, reference: features/features_short_cshot.cpp:651-687 (PCL cshot.hpp); normalised L/100, a/120, b/120
         const uint32_t c4 = rgba[i];
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ pt
         float L = 116.0f * vy - 16.0f; if (L > 100) L = 100.0f;
         float A = 500.0f * (vx - vy); if (A > 120) A = 120.0f; else if (A < -120) A = -120.0f;
         float B = 200.0f * (vy - vz); if (B > 120) B = 120.0f; else if (B < -120) B = -120.0f;
-        sL[d] = L / 100.0f; sa[d] = A / 120.0f; sb[d] = B / 120.0f;
+        slab4[d] = make_float4(L / 100.0f, A / 120.0f, B / 120.0f, 0.f);
     }
 }
 
@@ -235,12 +250,12 @@ int ismhip_cloud_create(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_h
     auto fail = [&](int code, const char* msg) { c->cap_pts = 0; ismhip_cloud_destroy(ctx, c); return ism_set_err(ctx, code, msg); };
     if (fresh) {
         const size_t capp = np + np / 8;
-        const int n_arr = rgba ? 9 : 6;
-        float* block = nullptr;
-        if (hipMalloc((void**)&block, capp * sizeof(float) * n_arr) != hipSuccess) return fail(ISMHIP_ERR_NOMEM, "cloud_create: hipMalloc sorted arrays");
-        c->sx = block; c->sy = block + capp; c->sz = block + 2 * capp; c->snx = block + 3 * capp; c->sny = block + 4 * capp; c->snz = block + 5 * capp;
-        if (rgba) { c->sL = block + 6 * capp; c->sa = block + 7 * capp; c->sb = block + 8 * capp; }
-        if (hipMalloc((void**)&c->sorig, capp * 4) != hipSuccess || hipMalloc((void**)&c->cell_of_pt, capp * 4) != hipSuccess ||
+        const int n_arr = rgba ? 3 : 2;
+        float4* block = nullptr;
+        if (hipMalloc((void**)&block, capp * sizeof(float4) * n_arr) != hipSuccess) return fail(ISMHIP_ERR_NOMEM, "cloud_create: hipMalloc sorted arrays");
+        c->sp4 = block; c->sn4 = block + capp;
+        if (rgba) c->slab4 = block + 2 * capp;
+        if (hipMalloc((void**)&c->members, capp * 4) != hipSuccess || hipMalloc((void**)&c->cell_of_pt, capp * 4) != hipSuccess ||
             hipMalloc((void**)&c->rank_of_pt, capp * 4) != hipSuccess || hipMalloc((void**)&c->pt_off, (size_t)(n_obj + 1) * 4) != hipSuccess ||
             hipMalloc((void**)&c->meta, (size_t)n_obj * sizeof(GridMeta)) != hipSuccess ||
             hipMalloc((void**)&c->cell_start, (size_t)n_obj * ISM_GRID_STRIDE * 4) != hipSuccess)
@@ -252,16 +267,17 @@ int ismhip_cloud_create(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_h
     {
         TimerScope ts(ctx, "grid");
         // non-finite points are dropped: an object's sorted span holds its n_finite points first, the tail is never read
-        hipLaunchKernelGGL(k_bbox_meta, dim3(n_obj), dim3(256), 0, ctx->stream, c->pt_off, x, y, z, cell_size, c->meta, c->cell_start);
+        hipLaunchKernelGGL(k_bbox_meta, dim3(n_obj), dim3(256), 0, ctx->stream, c->pt_off, x, y, z, cell_size, ctx->grid_xfrac > 0.f ? 1.0f / ctx->grid_xfrac : 1.0f / (float)ISM_GRID_XFRAC, c->meta, c->cell_start);
         const dim3 g((c->max_pts + 255) / 256 ? (c->max_pts + 255) / 256 : 1, n_obj);
         hipLaunchKernelGGL(k_count, g, dim3(256), 0, ctx->stream, c->pt_off, x, y, z, c->meta, c->cell_start, c->cell_of_pt, c->rank_of_pt);
         hipLaunchKernelGGL(k_scan, dim3(n_obj), dim3(1024), 0, ctx->stream, c->meta, c->cell_start);
+        hipLaunchKernelGGL(k_members, g, dim3(256), 0, ctx->stream, c->pt_off, c->cell_start, c->cell_of_pt, c->rank_of_pt, c->members);
         if (rgba)
             hipLaunchKernelGGL(k_scatter<true>, g, dim3(256), 0, ctx->stream, c->pt_off, x, y, z, nx, ny, nz, rgba, ctx->lut_srgb, ctx->lut_sxyz,
-                               c->cell_start, c->cell_of_pt, c->rank_of_pt, c->sx, c->sy, c->sz, c->snx, c->sny, c->snz, c->sL, c->sa, c->sb, c->sorig);
+                               c->cell_start, c->cell_of_pt, c->members, c->sp4, c->sn4, c->slab4);
         else
             hipLaunchKernelGGL(k_scatter<false>, g, dim3(256), 0, ctx->stream, c->pt_off, x, y, z, nx, ny, nz, rgba, ctx->lut_srgb, ctx->lut_sxyz,
-                               c->cell_start, c->cell_of_pt, c->rank_of_pt, c->sx, c->sy, c->sz, c->snx, c->sny, c->snz, c->sL, c->sa, c->sb, c->sorig);
+                               c->cell_start, c->cell_of_pt, c->members, c->sp4, c->sn4, c->slab4);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ISMHIP_ERR_HIP, hipGetErrorString(e));
@@ -270,8 +286,8 @@ int ismhip_cloud_create(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_h
 }
 
 static void cloud_free(ismhip_cloud* c) {
-    if (c->sx) (void)hipFree(c->sx);
-    if (c->sorig) (void)hipFree(c->sorig);
+    if (c->sp4) (void)hipFree(c->sp4);
+    if (c->members) (void)hipFree(c->members);
     if (c->cell_of_pt) (void)hipFree(c->cell_of_pt);
     if (c->rank_of_pt) (void)hipFree(c->rank_of_pt);
     if (c->pt_off) (void)hipFree(c->pt_off);

@@ -1513,6 +1513,7 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
     // T = candidates kept per slot. The bf16x3 candidate scores carry a larger error bound, so more are kept (T = 4): the proof
     // then compares against the 5th best of every slot and almost never fails.
     const bool wide = k > 2 || (metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi && ctx->knn_mode <= 1);
+    if (ctx->knn_t == 1 && k <= 1) return run_knn<1>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
     if (ctx->knn_t == 3 && k <= 3) return run_knn<3>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
     if (ctx->knn_t == 2 && k <= 2) return run_knn<2>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
     return wide ? run_knn<4>(ctx, cb, metric, nq, q, k, idx_out, dist_out) : run_knn<2>(ctx, cb, metric, nq, q, k, idx_out, dist_out);

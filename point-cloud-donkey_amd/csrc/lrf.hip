@@ -19,8 +19,6 @@ uint32_t* ism_upload_offsets(ismhip_ctx* ctx, int slot, const uint32_t* off_h, i
 
 namespace {
 
-struct P3 { float x, y, z; };
-struct P3o { float x, y, z; uint32_t orig; };
 
 struct TieRec {
     double v1[3], v3[3];
@@ -31,8 +29,9 @@ struct TieRec {
 
 struct CloudView {
     const uint32_t* pt_off; const GridMeta* meta; const uint32_t* cell_start;
-    const float *sx, *sy, *sz; const uint32_t* sorig;
+    const float4* sp4;        // cell-sorted (x, y, z, original index bits)
     const float *x, *y, *z;   // original order (tie kernel)
+    int n_obj, nbx;           // XCD-local block map (common.h)
 };
 
 __device__ __forceinline__ void write_lrf(float* out, const double v1[3], const double v3[3]) {
@@ -57,8 +56,9 @@ __device__ __forceinline__ double sqrt_f32_as_f64(float d2) {
 __global__ __launch_bounds__(256) void k_lrf_cov(CloudView cv, const uint32_t* __restrict__ kp_off,
                                                  const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ kz,
                                                  float radius, float r2, double* __restrict__ cov_out) {
-    const int o = blockIdx.y;
-    const uint32_t k = kp_off[o] + blockIdx.x * 4 + (threadIdx.x >> 6);
+    int o, bx;
+    if (!xcd_object_block(cv.nbx, cv.n_obj, o, bx)) return;
+    const uint32_t k = kp_off[o] + bx * 4 + (threadIdx.x >> 6);
     if (k >= kp_off[o + 1]) return;
     const int lane = lane_id();
     const float cx = kx[k], cy = ky[k], cz = kz[k];
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void k_lrf_cov(CloudView cv, const uint32_t* _
     const double rd = (double)radius;
     __shared__ WaveRows s_rows[4];
     ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6],
-                  [&](uint32_t t, bool v) { P3 p = {0.f, 0.f, 0.f}; if (v) { p.x = cv.sx[base + t]; p.y = cv.sy[base + t]; p.z = cv.sz[base + t]; } return p; },
-                  [&](const P3& p, uint32_t, bool v) {
+                  [&](uint32_t t, bool v) { return v ? cv.sp4[base + t] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                  [&](const float4& p, uint32_t, bool v) {
         if (!v) return;
         const float px = p.x, py = p.y, pz = p.z;
         const float d2 = sqdist3(px, py, pz, cx, cy, cz);
@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256, 4) void k_lrf_sign(CloudView cv, const uint32_
                                                   const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ kz,
                                                   float radius, float r2, const double* __restrict__ cov, const double* __restrict__ axes,
                                                   float* __restrict__ lrf_out, uint32_t* __restrict__ tie_count, TieRec* __restrict__ tie_rec) {
-    const int o = blockIdx.y;
-    const uint32_t k = kp_off[o] + blockIdx.x * 4 + (threadIdx.x >> 6);
+    int o, bx;
+    if (!xcd_object_block(cv.nbx, cv.n_obj, o, bx)) return;
+    const uint32_t k = kp_off[o] + bx * 4 + (threadIdx.x >> 6);
     if (k >= kp_off[o + 1]) return;
     const double* a = axes + (size_t)k * 6;
     if (isnan(a[0]) || cov[(size_t)k * 8 + 7] < 5.0) return;             // frame already written as NaN
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(256, 4) void k_lrf_sign(CloudView cv, const uint32_
     int plusT = 0, plusN = 0;
     __shared__ WaveRows s_rows[4];
     ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6],
-                  [&](uint32_t t, bool v) { P3 p = {0.f, 0.f, 0.f}; if (v) { p.x = cv.sx[base + t]; p.y = cv.sy[base + t]; p.z = cv.sz[base + t]; } return p; },
-                  [&](const P3& p, uint32_t, bool v) {
+                  [&](uint32_t t, bool v) { return v ? cv.sp4[base + t] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                  [&](const float4& p, uint32_t, bool v) {
         if (!v) return;
         const float px = p.x, py = p.y, pz = p.z;
         const float d2 = sqdist3(px, py, pz, cx, cy, cz);
@@ -202,13 +203,13 @@ __global__ __launch_bounds__(64) void k_lrf_tie(CloudView cv, const float* __res
         const uint32_t cap = r.valid <= TIE_LDS_KEYS ? (uint32_t)TIE_LDS_KEYS : key_cap;
         uint32_t n = 0;
         ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6],
-                      [&](uint32_t i, bool v) { P3o p = {0.f, 0.f, 0.f, 0u}; if (v) { p.x = cv.sx[base + i]; p.y = cv.sy[base + i]; p.z = cv.sz[base + i]; p.orig = cv.sorig[base + i]; } return p; },
-                      [&](const P3o& p, uint32_t, bool v) {
+                      [&](uint32_t i, bool v) { return v ? cv.sp4[base + i] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                      [&](const float4& p, uint32_t, bool v) {
             bool pass = false; float d2 = 0.f; uint32_t orig = 0;
             if (v) {
                 d2 = sqdist3(p.x, p.y, p.z, cx, cy, cz);
                 pass = d2 < r2 && !(p.x == cx && p.y == cy && p.z == cz);
-                orig = p.orig;
+                orig = __float_as_uint(p.w);
             }
             const unsigned long long mask = __ballot(pass);
             if (pass) {
@@ -316,11 +317,12 @@ extern "C" int ismhip_shot_lrf(ismhip_ctx* ctx, const ismhip_cloud* cloud, const
     unsigned long long* keys = (unsigned long long*)ism_scratch(ctx, SCR_TIE_KEYS, (size_t)tie_blocks * key_cap * 8);
     if (!tie_count || !tie_rec || !keys || !cov) return ISMHIP_ERR_NOMEM;
     double* axes = cov + (size_t)nkp * 8;
-    CloudView cv{cloud->pt_off, cloud->meta, cloud->cell_start, cloud->sx, cloud->sy, cloud->sz, cloud->sorig, cloud->x, cloud->y, cloud->z};
+    CloudView cv{cloud->pt_off, cloud->meta, cloud->cell_start, cloud->sp4, cloud->x, cloud->y, cloud->z,
+                 ctx->xcd_map ? n_obj : 0, (int)((maxk + 3) / 4)};
     const float r2 = (float)((double)radius * (double)radius);   // PCL: static_cast<float>(radius*radius) with double radius
     TimerScope ts(ctx, "lrf");
     ISM_HIP(ctx, hipMemsetAsync(tie_count, 0, 4, ctx->stream));
-    const dim3 grid((maxk + 3) / 4, n_obj);
+    const dim3 grid(ctx->xcd_map ? xcd_object_grid((maxk + 3) / 4, n_obj) : ((maxk + 3) / 4) * (unsigned)n_obj);
     hipLaunchKernelGGL(k_lrf_cov, grid, dim3(256), 0, ctx->stream, cv, ko, kpx, kpy, kpz, radius, r2, cov);
     ISM_CHECK_LAUNCH(ctx, "k_lrf_cov");
     hipLaunchKernelGGL(k_lrf_eig, dim3((nkp + 255) / 256), dim3(256), 0, ctx->stream, nkp, cov, axes, lrf9_out);
@@ -348,15 +350,15 @@ __global__ __launch_bounds__(256) void k_normals_from_lrf(uint32_t n, const floa
     const float q = __builtin_nanf("");
     nx[i] = ok ? -f[6] : q; ny[i] = ok ? -f[7] : q; nz[i] = ok ? -f[8] : q;
 }
-// the cloud's cell-sorted normal copies follow (sorted position s of object o holds original point sorig[s])
-__global__ __launch_bounds__(256) void k_sorted_normals(const uint32_t* __restrict__ pt_off, const GridMeta* __restrict__ meta, const uint32_t* __restrict__ sorig,
+// the cloud's cell-sorted normal copies follow (sorted position s of object o holds the original point in sp4[s].w)
+__global__ __launch_bounds__(256) void k_sorted_normals(const uint32_t* __restrict__ pt_off, const GridMeta* __restrict__ meta, const float4* __restrict__ sp4,
                                                         const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz,
-                                                        float* __restrict__ snx, float* __restrict__ sny, float* __restrict__ snz) {
+                                                        float4* __restrict__ sn4) {
     const int o = blockIdx.y;
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s >= meta[o].n_finite) return;
-    const uint32_t base = pt_off[o], src = base + sorig[base + s];
-    snx[base + s] = nx[src]; sny[base + s] = ny[src]; snz[base + s] = nz[src];
+    const uint32_t base = pt_off[o], src = base + __float_as_uint(sp4[base + s].w);
+    sn4[base + s] = make_float4(nx[src], ny[src], nz[src], 0.f);
 }
 }  // namespace
 
@@ -370,8 +372,8 @@ extern "C" int ismhip_estimate_normals(ismhip_ctx* ctx, ismhip_cloud* cloud, flo
     if (rc != ISMHIP_OK) return rc;
     hipLaunchKernelGGL(k_normals_from_lrf, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, lrf, nx_out, ny_out, nz_out);
     ISM_CHECK_LAUNCH(ctx, "k_normals_from_lrf");
-    hipLaunchKernelGGL(k_sorted_normals, dim3((cloud->max_pts + 255) / 256, cloud->n_obj), dim3(256), 0, ctx->stream, cloud->pt_off, cloud->meta, cloud->sorig,
-                       nx_out, ny_out, nz_out, cloud->snx, cloud->sny, cloud->snz);
+    hipLaunchKernelGGL(k_sorted_normals, dim3((cloud->max_pts + 255) / 256, cloud->n_obj), dim3(256), 0, ctx->stream, cloud->pt_off, cloud->meta, cloud->sp4,
+                       nx_out, ny_out, nz_out, cloud->sn4);
     ISM_CHECK_LAUNCH(ctx, "k_sorted_normals");
     cloud->nx = nx_out; cloud->ny = ny_out; cloud->nz = nz_out;
     return ISMHIP_OK;

@@ -25,11 +25,12 @@ namespace {
 
 struct ShotArgs {
     const uint32_t* pt_off; const GridMeta* meta; const uint32_t* cell_start;
-    const float *sx, *sy, *sz, *snx, *sny, *snz, *sL, *sa, *sb;
+    const float4 *sp4, *sn4, *slab4;
     const uint32_t* kp_off; const float *kx, *ky, *kz; const uint32_t* kp_rgba;
     const float* lrf; float radius, r2, r12sq_f;
     const float *lut_srgb, *lut_sxyz;
     float* desc; uint32_t* count;
+    int n_obj, nbx;
 };
 
 // The per-wave LDS histogram is kept in 64-bit FIXED POINT (2^-28 units) and updated with ds_add_u64.
@@ -95,14 +96,15 @@ __device__ __forceinline__ void shot_dep(shot_bin_t* hist, int bin, float v) {
 }
 
 // Per-neighbour SHOT update. All 64 lanes call it; 'act' marks lanes that hold a neighbour.
-template <bool COLOR>
+template <bool COLOR, int VAR>
 __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hist, bool act, uint32_t gi,
                                                float dx, float dy, float dz, float d2,
                                                const float fx[3], const float fy[3], const float fz[3],
                                                float r12, float r14, float r34, float inv_r12, float r12sq_f,
                                                float LRef, float aRef, float bRef) {
     if (!act) return;
-    const float nxv = a.snx[gi], nyv = a.sny[gi], nzv = a.snz[gi];
+    const float4 nrm = a.sn4[gi];
+    const float nxv = nrm.x, nyv = nrm.y, nzv = nrm.z;
     if (!(isfinite(nxv) && isfinite(nyv) && isfinite(nzv))) return;              // createBinDistanceShape: NaN normal -> skipped
     float cosd = (nxv * fz[0] + nyv * fz[1]) + nzv * fz[2];
     cosd = fminf(1.0f, fmaxf(-1.0f, cosd));
@@ -143,7 +145,8 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
     }
     int step_c = 0, vol_c = 0; float w_col = 0.f;
     if (COLOR) {
-        const float L = a.sL[gi], A = a.sa[gi], B = a.sb[gi];
+        const float4 lab = a.slab4[gi];
+        const float L = lab.x, A = lab.y, B = lab.z;
         float cd = (fabsf(LRef - L) + ((fabsf(aRef - A) + fabsf(bRef - B)) * 0.5f)) / 3.0f;   // feeds a hard bin: exact division
         cd = fminf(1.0f, fmaxf(0.0f, cd));
         float bc;
@@ -181,9 +184,15 @@ __device__ __forceinline__ void shot_neighbour(const ShotArgs& a, shot_bin_t* hi
         winc += 1.f - wa;
         sec_a = (ad > 0.f ? di + 4 : di - 4) & 31;
     }
+    if (VAR & 1) {
+        // unconditional deposits (measured SLOWER, 4.44 vs 4.06 ms: more lanes in every atomic = more same-address serialisation)
+        shot_dep(hist, sec_r * 11 + step, wr_); shot_dep(hist, sec_e * 11 + step, we); shot_dep(hist, sec_a * 11 + step, wa);
+        if (COLOR) { shot_dep(hist, 352 + sec_r * 31 + step_c, wr_); shot_dep(hist, 352 + sec_e * 31 + step_c, we); shot_dep(hist, 352 + sec_a * 31 + step_c, wa); }
+    } else {
     if (wr_ != 0.f) { shot_dep(hist, sec_r * 11 + step, wr_); if (COLOR) shot_dep(hist, 352 + sec_r * 31 + step_c, wr_); }
     if (we != 0.f) { shot_dep(hist, sec_e * 11 + step, we); if (COLOR) shot_dep(hist, 352 + sec_e * 31 + step_c, we); }
     if (wa != 0.f) { shot_dep(hist, sec_a * 11 + step, wa); if (COLOR) shot_dep(hist, 352 + sec_a * 31 + step_c, wa); }
+    }
     shot_dep(hist, vol + step, w_shape + winc);
     if (COLOR) shot_dep(hist, vol_c + step_c, w_col + winc);
 }
@@ -203,14 +212,16 @@ __device__ __forceinline__ void rgb2lab_norm(const float* lut_srgb, const float*
     L /= 100.0f; A /= 120.0f; B /= 120.0f;
 }
 
-template <bool COLOR>
-__global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
+// 6 workgroups (24 waves) per CU: the LDS budget (24.5 KB per workgroup) allows it, so the register allocation must too (<= 80)
+template <bool COLOR, int VAR>
+__global__ __launch_bounds__(256, COLOR ? 2 : 6) void k_shot(ShotArgs a) {
     constexpr int D = COLOR ? 1344 : 352;
     __shared__ ShotSmem<COLOR> sm;
-    const int o = blockIdx.y;
+    int o, bx;
+    if (!xcd_object_block(a.nbx, a.n_obj, o, bx)) return;
     const int wv = threadIdx.x >> 6;
     const int lane = lane_id();
-    const uint32_t k = a.kp_off[o] + blockIdx.x * 4 + wv;
+    const uint32_t k = a.kp_off[o] + bx * 4 + wv;
     if (k >= a.kp_off[o + 1]) return;          // wave-uniform; no block-level barrier below
     shot_bin_t* hist = sm.hist[wv];
     float* out = a.desc + (size_t)k * D;
@@ -233,10 +244,10 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
     const uint32_t* cs = a.cell_start + (size_t)o * ISM_GRID_STRIDE;
     const uint32_t base = a.pt_off[o];
     uint32_t qn = 0, qh = 0, total = 0;
-    struct P3 { float x, y, z; };
-    ball_for_each(m, cs, cr, cx, cy, cz, a.radius, lane, sm.rows[wv],
-                  [&](uint32_t i, bool v) { P3 p = {0.f, 0.f, 0.f}; if (v) { p.x = a.sx[base + i]; p.y = a.sy[base + i]; p.z = a.sz[base + i]; } return p; },
-                  [&](const P3& p, uint32_t i, bool v) {
+    // 16 interleaved segments: measured 4.18 (contiguous) -> 3.27 (8 segments) -> 2.96 ms (16 interleaved) per 256 objects; 32 lose to coalescing
+    ball_for_each<(VAR & 2) ? 1 : 16, true>(m, cs, cr, cx, cy, cz, a.radius, lane, sm.rows[wv],
+                  [&](uint32_t i, bool v) { return v ? a.sp4[base + i] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                  [&](const float4& p, uint32_t i, bool v) {
         bool pass = false; float dx = 0, dy = 0, dz = 0, d2 = 0;
         if (v) {
             const float px = p.x, py = p.y, pz = p.z;
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
             // a full wave of neighbours (LDS traffic of one wave is ordered; no barrier needed)
             const uint32_t at = (qh + lane) & 127u;
             const float4 e = sm.qd[wv][at];
-            shot_neighbour<COLOR>(a, hist, true, sm.qi[wv][at], e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq_f, LRef, aRef, bRef);
+            shot_neighbour<COLOR, VAR>(a, hist, true, sm.qi[wv][at], e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq_f, LRef, aRef, bRef);
             qh = (qh + 64) & 127u; qn -= 64;
         }
     });
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(256) void k_shot(ShotArgs a) {
         const bool act = (uint32_t)lane < qn;
         const uint32_t at = (qh + lane) & 127u;
         const float4 e = sm.qd[wv][at];
-        shot_neighbour<COLOR>(a, hist, act, act ? sm.qi[wv][at] : 0u, e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq_f, LRef, aRef, bRef);
+        shot_neighbour<COLOR, VAR>(a, hist, act, act ? sm.qi[wv][at] : 0u, e.x, e.y, e.z, e.w, fx, fy, fz, r12, r14, r34, inv_r12, r12sq_f, LRef, aRef, bRef);
     }
     if (a.count && lane == 0) a.count[k] = total;
     if (total < 5) {                                    // computePointSHOT: fewer than 5 neighbours -> NaN descriptor
@@ -296,8 +307,7 @@ int launch_shot(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_o
     if (!ko) return ISMHIP_ERR_HIP;
     ShotArgs a;
     a.pt_off = cloud->pt_off; a.meta = cloud->meta; a.cell_start = cloud->cell_start;
-    a.sx = cloud->sx; a.sy = cloud->sy; a.sz = cloud->sz; a.snx = cloud->snx; a.sny = cloud->sny; a.snz = cloud->snz;
-    a.sL = cloud->sL; a.sa = cloud->sa; a.sb = cloud->sb;
+    a.sp4 = cloud->sp4; a.sn4 = cloud->sn4; a.slab4 = cloud->slab4;
     a.kp_off = ko; a.kx = kpx; a.ky = kpy; a.kz = kpz; a.kp_rgba = kp_rgba; a.lrf = lrf9;
     a.radius = radius; a.r2 = (float)((double)radius * (double)radius);
     {   // largest float <= (radius/2)^2 taken in double: the shell test (double)d2 > r12sq of the reference, as a float compare
@@ -308,8 +318,11 @@ int launch_shot(ismhip_ctx* ctx, const ismhip_cloud* cloud, const uint32_t* kp_o
     }
     a.lut_srgb = ctx->lut_srgb; a.lut_sxyz = ctx->lut_sxyz;
     a.desc = desc_out; a.count = count_out;
+    a.n_obj = ctx->xcd_map ? n_obj : 0; a.nbx = (int)((maxk + 3) / 4);
     TimerScope ts(ctx, name);
-    hipLaunchKernelGGL(k_shot<COLOR>, dim3((maxk + 3) / 4, n_obj), dim3(256), 0, ctx->stream, a);
+    const dim3 grid(ctx->xcd_map ? xcd_object_grid((unsigned)a.nbx, n_obj) : (unsigned)a.nbx * (unsigned)n_obj);
+    if (ctx->shot_var & 2) hipLaunchKernelGGL((k_shot<COLOR, 2>), grid, dim3(256), 0, ctx->stream, a);      // contiguous sweep (A/B runs)
+    else hipLaunchKernelGGL((k_shot<COLOR, 0>), grid, dim3(256), 0, ctx->stream, a);
     ISM_CHECK_LAUNCH(ctx, name);
     return ISMHIP_OK;
 }

@@ -789,7 +789,7 @@ std::shared_ptr<DeviceFeatures> ImplicitShapeModel::computeFeatures(const std::v
         }
     }
     const float cell = std::min(m_feature_descriptor->getRadius(), m_feature_descriptor->getType() == "FPFH" ? m_feature_descriptor->getRadius()
-                                                                                                           : m_feature_descriptor->getReferenceFrameRadius()) * 0.5f;
+                                                                                                           : m_feature_descriptor->getReferenceFrameRadius()) * 0.4f;
     // VoxelGrid keypoints are taken on the device with the batch (ismhip_voxel_keypoints); any other detector, or
     // ISM3D_HOST_KEYPOINTS=1, runs the host implementation per object and uploads its result
     const auto* vg = dynamic_cast<const KeypointsVoxelGrid*>(m_keypoints_detector.get());

@@ -7,6 +7,7 @@ Reference call stack mirrored here (paths relative to /root/reference/src/implic
 All heavy work is inside libismhip.so; this file only sequences the calls and keeps every intermediate on the device
 (one host sync per batch, for the NaN-feature compaction counts). torch is device memory + streams, nothing else.
 """
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -73,6 +74,66 @@ class DeviceBatch:
         self.n_obj = len(self.pt_off) - 1
 
 
+class HostStager:
+    """Inputs that start in (pinned) HOST memory: uploads run on a copy stream into one of two device buffer sets while the
+    previous chunk computes on the ctx stream (double buffering). Used by bench.py's PCIe-inclusive leg and by callers that
+    stream a test list through detect(); the resident path (DeviceBatch) is unchanged."""
+    FIELDS = ("x", "y", "z", "nx", "ny", "nz", "kx", "ky", "kz", "rgba", "kp_rgba")
+
+    def __init__(self, np_batches, device):
+        import torch
+        self.device = device
+        self.host, self.meta = [], []
+        for nb in np_batches:
+            xyz, nrm, kp = nb["xyz"], nb["normals"], nb["kp"]
+            h = dict(x=xyz[:, 0], y=xyz[:, 1], z=xyz[:, 2], nx=nrm[:, 0], ny=nrm[:, 1], nz=nrm[:, 2], kx=kp[:, 0], ky=kp[:, 1], kz=kp[:, 2])
+            if "rgba" in nb:
+                h["rgba"] = nb["rgba"].astype(np.int64).astype(np.int32); h["kp_rgba"] = nb["kp_rgba"].astype(np.int64).astype(np.int32)
+            self.host.append({k: torch.as_tensor(np.ascontiguousarray(v)).pin_memory() for k, v in h.items()})
+            self.meta.append((np.asarray(nb["pt_off"], np.uint32), np.asarray(nb["kp_off"], np.uint32), np.asarray(nb.get("labels", np.zeros(len(nb["pt_off"]) - 1)), np.int32)))
+        self.bytes_per_pass = int(sum(t.numel() * t.element_size() for h in self.host for t in h.values()))
+        cap = {k: max((h[k].numel() for h in self.host if k in h), default=0) for k in self.FIELDS}
+        self.slots = [{k: torch.empty((n,), dtype=torch.int32 if "rgba" in k else torch.float32, device=device) for k, n in cap.items() if n}
+                      for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device)
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.free = [torch.cuda.Event(), torch.cuda.Event()]
+        self._used = [False, False]
+
+    def _upload(self, j):
+        import torch
+        s = j % 2
+        with torch.cuda.stream(self.copy_stream):
+            if self._used[s]:
+                self.copy_stream.wait_event(self.free[s])          # the compute stream is done with this buffer set
+            for k, t in self.host[j].items():
+                self.slots[s][k][:t.numel()].copy_(t, non_blocking=True)
+            self.ready[s].record(self.copy_stream)
+
+    def begin(self):
+        self._upload(0)
+
+    def get(self, j):
+        import torch
+        s = j % 2
+        torch.cuda.current_stream(self.device).wait_event(self.ready[s])
+        if j + 1 < len(self.host):
+            self._upload(j + 1)
+        b = DeviceBatch.__new__(DeviceBatch)
+        b.pt_off, b.kp_off, b.labels = self.meta[j]
+        b.n_obj = len(b.pt_off) - 1
+        h = self.host[j]
+        for k in self.FIELDS:
+            setattr(b, k, self.slots[s][k][:h[k].numel()] if k in h else None)
+        return b
+
+    def release(self, j):
+        import torch
+        s = j % 2
+        self.free[s].record(torch.cuda.current_stream(self.device))
+        self._used[s] = True
+
+
 class Recognizer:
     def __init__(self, ctx, cfg: IsmConfig):
         self.ctx, self.cfg = ctx, cfg
@@ -81,7 +142,7 @@ class Recognizer:
     # -- ImplicitShapeModel::computeFeatures step f + removeNaNFeatures -------------------------------------
     def compute_features(self, b: DeviceBatch, want_counts=False):
         c, ctx = self.cfg, self.ctx
-        cell = min(c.radius, c.lrf_radius if c.feature != "FPFH" else c.radius) * 0.5
+        cell = min(c.radius, c.lrf_radius if c.feature != "FPFH" else c.radius) * float(os.environ.get("ISMHIP_CELL_SCALE", "0.4"))
         cloud = capi.Cloud(ctx, b.pt_off, b.x, b.y, b.z, b.nx, b.ny, b.nz, cell, rgba=b.rgba if c.feature == "CSHOT" else None)
         lrf = capi.shot_lrf(ctx, cloud, b.kp_off, b.kx, b.ky, b.kz, c.lrf_radius)   # Features::operator() always computes LRFs
         if c.feature == "SHOT":

@@ -138,10 +138,273 @@ def knn_ties():
     return dict(words=words, q=q, k=3, expected_idx=[[1, 3, 4], [4, 0, 1]], expected_l2=[[0, 0, 0.5], [1.5, 2, 2]])
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round-2 vectors: the parts of the path a common-mode misreading could hide behind the sector-centre vector above.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _lut_srgb(i):
+    f = f32(i) / f32(255.0)
+    return f32(np.power(f32((f + f32(0.055)) / f32(1.055)), f32(2.4))) if f > 0.04045 else f32(f / f32(12.92))
+
+
+def _lut_xyz(v):
+    i = min(3999, max(0, int(f32(v) * f32(4000))))
+    f = f32(i) / f32(4000.0)
+    return f32(np.power(f, f32(0.3333))) if f > 0.008856 else f32(7.787 * float(f) + 16.0 / 116.0)
+
+
+def _lab_norm(rgb):
+    """normalised CIELab (L/100, a/120, b/120) of an 8-bit RGB triple, float32 as the reference's LUT code (Appendix A.3)"""
+    r, g, b = rgb
+    fr, fg, fb = _lut_srgb(r), _lut_srgb(g), _lut_srgb(b)
+    x = f32(f32(fr * f32(0.412453)) + f32(fg * f32(0.357580))) + f32(fb * f32(0.180423))
+    y = f32(f32(fr * f32(0.212671)) + f32(fg * f32(0.715160))) + f32(fb * f32(0.072169))
+    z = f32(f32(fr * f32(0.019334)) + f32(fg * f32(0.119193))) + f32(fb * f32(0.950227))
+    vx, vy, vz = _lut_xyz(f32(x) / f32(0.95047)), _lut_xyz(y), _lut_xyz(f32(z) / f32(1.08883))
+    L = min(f32(100.0), f32(f32(116.0) * vy - f32(16.0)))
+    A = max(f32(-120.0), min(f32(120.0), f32(f32(500.0) * f32(vx - vy))))
+    B = max(f32(-120.0), min(f32(120.0), f32(f32(200.0) * f32(vy - vz))))
+    return f32(L / f32(100.0)), f32(A / f32(120.0)), f32(B / f32(120.0))
+
+
+def _shot_one_neighbour(p, n, radius, colour=None):
+    """Deposits of ONE neighbour p (float32 xyz relative to a keypoint at the origin, IDENTITY frame) with normal n, following
+    SURVEY Appendix A.2 / A.3 term by term in float64. Returns ({bin: weight} for the 352 shape bins, {bin: weight} for the 992
+    colour bins or None, parts) where parts names the four interpolation deposits so that the caller can assert they are all
+    non-zero and land in distinct bins. colour = (rgb of the keypoint, rgb of the neighbour)."""
+    p = np.asarray(p, np.float32).astype(np.float64); n = np.asarray(n, np.float32).astype(np.float64)
+    r12, r14, r34 = radius / 2, radius / 4, radius * 3 / 4
+    c = min(1.0, max(-1.0, float(n[2])))                       # n . z with z = (0,0,1)
+    b = (1.0 + c) * 10 / 2
+    d = float(np.sqrt(f32(p @ p)))
+    xl, yl, zl = p
+    bit4 = 1 if (yl > 0 or (yl == 0 and xl < 0)) else 0
+    bit3 = (1 - bit4) if (xl > 0 or (xl == 0 and yl > 0)) else bit4
+    s = ((bit4 << 3) + (bit3 << 2)) << 1
+    if xl * yl > 0 or xl == 0:
+        s += 0 if abs(xl) >= abs(yl) else 4
+    else:
+        s += 4 if abs(xl) > abs(yl) else 0
+    s += 1 if zl > 0 else 0
+    s += 2 if d > r12 else 0
+    step = int(np.floor(b + 0.5)); b -= step
+    shape, parts = {}, {}
+    add = lambda h, k, v: h.__setitem__(k, h.get(k, 0.0) + v)
+    wgt = 1 - abs(b)
+    cos_bin = s * 11 + ((step + 1) % 10 if b > 0 else (step - 1 + 10) % 10)
+    add(shape, cos_bin, abs(b)); parts["cosine"] = (cos_bin, abs(b))
+    inc_w, nb = 0.0, []                                          # spatial increments shared by the shape and colour channels
+    if d > r12:
+        rd = (d - r34) / r12
+        if d > r34: inc_w += 1 - rd
+        else: inc_w += 1 + rd; nb.append(("radial", s - 2, -rd))
+    else:
+        rd = (d - r14) / r12
+        if d < r14: inc_w += 1 + rd
+        else: inc_w += 1 - rd; nb.append(("radial", s + 2, rd))
+    inc = float(np.arccos(min(1.0, max(-1.0, zl / d))))
+    if inc > np.pi / 2 or (abs(inc - np.pi / 2) < 1e-30 and zl <= 0):
+        idd = (inc - 3 * np.pi / 4) / (np.pi / 2)
+        if inc > 3 * np.pi / 4: inc_w += 1 - idd
+        else: inc_w += 1 + idd; nb.append(("elevation", s + 1, -idd))
+    else:
+        idd = (inc - np.pi / 4) / (np.pi / 2)
+        if inc < np.pi / 4: inc_w += 1 + idd
+        else: inc_w += 1 - idd; nb.append(("elevation", s - 1, idd))
+    if yl != 0 or xl != 0:
+        az = float(np.arctan2(yl, xl)); sel = s >> 2
+        ad = min(0.5, max(-0.5, (az - (-7 * np.pi / 8 + sel * np.pi / 4)) / (np.pi / 4)))
+        if ad > 0: inc_w += 1 - ad; nb.append(("azimuth", (s + 4) % 32, ad))
+        else: inc_w += 1 + ad; nb.append(("azimuth", (s - 4 + 32) % 32, -ad))
+    for name, sec, w in nb:
+        add(shape, sec * 11 + step, w); parts[name] = (sec * 11 + step, w)
+    add(shape, s * 11 + step, wgt + inc_w); parts["main"] = (s * 11 + step, wgt + inc_w)
+    col = None
+    if colour is not None:
+        (Lr, ar, br), (L, a, bb) = _lab_norm(colour[0]), _lab_norm(colour[1])
+        cd = f32((f32(abs(f32(Lr - L))) + f32(f32(abs(f32(ar - a)) + abs(f32(br - bb))) / f32(2))) / f32(3))
+        cd = min(1.0, max(0.0, float(cd)))
+        bc = cd * 30
+        step_c = int(np.floor(bc + 0.5)); bc -= step_c
+        col = {}
+        add(col, s * 31 + ((step_c + 1) % 30 if bc > 0 else (step_c - 1 + 30) % 30), abs(bc))
+        for name, sec, w in nb:
+            add(col, sec * 31 + step_c, w)
+        add(col, s * 31 + step_c, (1 - abs(bc)) + inc_w)
+        parts["colour"] = (step_c, bc)
+    return shape, col, parts
+
+
+def _sph(d, polar_deg, az_deg):
+    t, a = np.radians(polar_deg), np.radians(az_deg)
+    return [d * np.sin(t) * np.cos(a), d * np.sin(t) * np.sin(a), d * np.cos(t)]
+
+
+def shot_off_centre():
+    """KAT 10: ONE off-centre neighbour (x 5 copies so the >= 5-neighbour rule passes; the L2 normalisation cancels the factor):
+    identity frame, r = 1, d = 0.6 (outer shell, below 3r/4 -> radial neighbour s-2), polar angle 60 deg (upper hemisphere,
+    above 45 deg -> elevation neighbour s-1), azimuth 76.5 deg (sector 5, centre 67.5 deg -> ad = +0.2 -> azimuth neighbour
+    s+4), n.z = 0.36 -> b = 6.8 -> step 7, offset -0.2 -> cosine neighbour step 6. All four interpolation deposits are non-zero
+    and land in four distinct bins besides the main one. A second neighbour exercises the opposite branch of every ladder:
+    inner shell above r/4, lower hemisphere below 135 deg, negative azimuth offset, positive cosine offset."""
+    cases = []
+    for p, c in ((_sph(0.6, 60.0, 76.5), 0.36), (_sph(0.4, 120.0, -140.0), -0.47)):
+        n = [np.sqrt(1 - c * c), 0.0, c]
+        shape, _, parts = _shot_one_neighbour(np.asarray(p, np.float32), np.asarray(n, np.float32), 1.0)
+        bins = [parts[k][0] for k in ("main", "cosine", "radial", "elevation", "azimuth")]
+        assert len(set(bins)) == 5 and all(parts[k][1] > 0.05 for k in ("cosine", "radial", "elevation", "azimuth")), parts
+        v = np.zeros(352)
+        for k, w in shape.items():
+            v[k] = w
+        cases.append(dict(point=np.asarray(p, np.float32).astype(float).tolist(), normal=np.asarray(n, np.float32).astype(float).tolist(),
+                          copies=5, radius=1.0, parts={k: [int(b), float(w)] for k, (b, w) in parts.items()},
+                          expected=(v / np.linalg.norm(v)).tolist()))
+    assert cases[0]["parts"]["main"][0] == 23 * 11 + 7 and cases[0]["parts"]["azimuth"][0] == 27 * 11 + 7
+    return dict(cases=cases, tol=3e-6)
+
+
+def cshot_colour_pairs():
+    """KAT 11: the colour channel of CSHOT-1344 (Appendix A.3) for two (keypoint rgb, neighbour rgb) pairs on the geometry of
+    KAT 10's first neighbour: colour distance -> bin 30 cd, its own hard step + neighbour step (modulo 30), the SAME
+    radial / elevation / azimuth increments and neighbour sectors as the shape channel, joint L2 norm over all 1344 values."""
+    p = np.asarray(_sph(0.6, 60.0, 76.5), np.float32)
+    n = np.asarray([np.sqrt(1 - 0.36 ** 2), 0.0, 0.36], np.float32)
+    cases = []
+    for ref, nb in (((200, 30, 30), (150, 90, 40)), ((12, 200, 99), (200, 240, 10))):      # steps 2 (+0.164) and 5 (-0.106)
+        shape, col, parts = _shot_one_neighbour(p, n, 1.0, colour=(ref, nb))
+        assert abs(parts["colour"][1]) > 0.05                     # a real colour-neighbour deposit
+        v = np.zeros(1344)
+        for k, w in shape.items():
+            v[k] = w
+        for k, w in col.items():
+            v[352 + k] = w
+        cases.append(dict(point=p.astype(float).tolist(), normal=n.astype(float).tolist(), copies=5, radius=1.0,
+                          kp_rgba=(ref[0] << 16) | (ref[1] << 8) | ref[2], rgba=(nb[0] << 16) | (nb[1] << 8) | nb[2],
+                          colour_step=int(parts["colour"][0]), colour_offset=float(parts["colour"][1]),
+                          expected=(v / np.linalg.norm(v)).tolist()))
+    assert cases[0]["colour_step"] != cases[1]["colour_step"]
+    return dict(cases=cases, tol=3e-6)
+
+
+def _ogre_quat(M):
+    """Utils::matrix2Quat (utils.cpp:342-380, Ogre's algorithm) on the 3x3 whose ROWS are the frame axes; returns (w, x, y, z)"""
+    m = np.asarray(M, np.float64).reshape(3, 3)
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    q = [0.0] * 4                                                # x, y, z, w
+    if tr > 0:
+        root = np.sqrt(tr + 1); q[3] = 0.5 * root; root = 0.5 / root
+        q[0] = (m[2, 1] - m[1, 2]) * root; q[1] = (m[0, 2] - m[2, 0]) * root; q[2] = (m[1, 0] - m[0, 1]) * root
+    else:
+        i = 0
+        if m[1, 1] > m[0, 0]: i = 1
+        if m[2, 2] > m[i, i]: i = 2
+        j = (i + 1) % 3; k = (j + 1) % 3
+        root = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1); q[i] = 0.5 * root; root = 0.5 / root
+        q[3] = (m[k, j] - m[j, k]) * root; q[j] = (m[j, i] + m[i, j]) * root; q[k] = (m[k, i] + m[i, k]) * root
+    return np.array([q[3], q[0], q[1], q[2]])
+
+
+def _qmul(a, b):
+    w1, x1, y1, z1 = a; w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def cast_votes_vector():
+    """KAT 12: CodewordDistribution::castVotes / castVote (codeword_distribution.cpp:73-167). Two codewords (two and one stored
+    votes), class variances sigma^2 = {0: 0.04, 1: 0.5}; six (feature, codeword, functor distance) activations that walk the
+    gate |dist| > 2 sigma^2 on both sides and AT the boundary, the weight < FLT_EPSILON cut, the Gaussian matching weight
+    N(dist; 0, sigma^2) = exp(-dist^2 / (2 sigma^2)) / sqrt(2 pi sigma^2), the vote geometry centre = keypoint + u0 x + u1 y + u2 z
+    (rows of the frame are the axes) and the bounding-box quaternion stored (x) q(frame) (boost product order, Ogre conversion)."""
+    c, s_ = np.cos(0.7), np.sin(0.7)
+    R1 = np.array([[c, s_, 0], [-s_, c, 0], [0, 0, 1]])
+    c2, s2 = np.cos(-1.1), np.sin(-1.1)
+    R = np.array([[1, 0, 0], [0, c2, s2], [0, -s2, c2]]) @ R1
+    flip = np.array([[-1, 0, 0], [0, -1, 0], [0, 0, 1]]) @ R      # negative trace: the other branch of matrix2Quat
+    frames = [np.eye(3), R, flip]
+    cb = dict(words=[[0.0, 0.0], [1.0, 0.0]], vote_offsets=[0, 2, 3],
+              vote_xyz=[[0.5, -0.25, 1.0], [-1.0, 0.5, 0.25], [0.1, 0.2, -0.3]], vote_class=[0, 1, 0], vote_instance=[3, 4, 5],
+              vote_weight=[0.5, 1e-8, 2e-7], vote_class_weight=[0.25, 0.75, 0.25], word_weight=[2.0, 3.0],
+              vote_bbox_quat=[[1, 0, 0, 0], [np.cos(0.4), np.sin(0.4), 0, 0], [np.cos(0.9), 0, 0, np.sin(0.9)]],
+              vote_bbox_size=[[1, 2, 3], [4, 5, 6], [7, 8, 9]], class_sigma=[0.04, 0.5])
+    acts = [  # (frame, keypoint, codeword, dist)
+        (0, [0.0, 0.0, 0.0], 0, 0.07), (1, [1.0, -2.0, 0.5], 0, 0.08), (2, [0.3, 0.1, -0.2], 0, 0.09),
+        (1, [0.0, 1.0, 0.0], 1, 0.01), (2, [2.0, 0.0, 1.0], 1, 0.0), (0, [0.0, 0.0, 1.0], -1, 0.0)]
+    flagsets = [0, 1, 2, 4, 8, 15]
+    eps, out = float(np.finfo(np.float32).eps), {}
+    for flags in flagsets:
+        rows = []
+        for f, kp, w, dist in acts:
+            for v in range(2):                                   # max votes per word = 2 -> two slots per activation
+                if w < 0 or cb["vote_offsets"][w] + v >= cb["vote_offsets"][w + 1]:
+                    rows.append(dict(cls=-1)); continue
+                vi = cb["vote_offsets"][w] + v
+                cls = cb["vote_class"][vi]; sig = float(f32(cb["class_sigma"][cls])); d = float(f32(dist))
+                wt = 1.0
+                if flags & 1: wt *= cb["vote_class_weight"][vi]
+                if flags & 2: wt *= float(f32(cb["vote_weight"][vi]))
+                if flags & 4: wt *= float(f32(np.exp(-d * d / (2 * sig)) / np.sqrt(2 * np.pi * sig)))
+                if flags & 8: wt *= cb["word_weight"][w]
+                if abs(d) > float(f32(2) * f32(sig)) or float(f32(wt)) < eps:
+                    rows.append(dict(cls=-1)); continue
+                F = frames[f]
+                centre = np.asarray(kp) + F.T @ np.asarray(cb["vote_xyz"][vi])
+                rows.append(dict(cls=int(cls), inst=int(cb["vote_instance"][vi]), codeword=int(w), weight=float(wt), pos=centre.tolist(),
+                                 bbox_quat=_qmul(np.asarray(cb["vote_bbox_quat"][vi], float), _ogre_quat(F)).tolist(),
+                                 bbox_size=cb["vote_bbox_size"][vi]))
+        out[str(flags)] = rows
+    n_kept = {k: sum(r["cls"] >= 0 for r in v) for k, v in out.items()}
+    # 8 stored votes are reached (2+2+2+1+1); the gate drops the class-0 vote at dist 0.09 (not the one AT 2 sigma^2 = 0.08, not the
+    # class-1 vote of the same codeword); with UseVoteWeight the 1e-8 vote of codeword 0 drops three more, the 2e-7 one stays
+    assert n_kept["0"] == 7 and n_kept["2"] == 4 and n_kept["4"] == 7 and n_kept["15"] == 4, n_kept
+    cb = {k: np.asarray(v, float).tolist() if k not in ("vote_offsets", "vote_class", "vote_instance") else v for k, v in cb.items()}
+    return dict(codebook=cb, frames=[F.reshape(-1).tolist() for F in frames], activations=[dict(frame=f, kp=kp, word=w, dist=d) for f, kp, w, d in acts],
+                expected=out, tol=2e-6)
+
+
+def knn_rule_table():
+    """KAT 13: ActivationStrategyKnnRule at detection time (activation_strategy_knn_rule.h:79-118): the four class patterns of
+    the 3 nearest codewords x both outcomes of the ratio test. Query j sits at x = 100 j; its three codewords at x + 1,
+    x + a, x + b, so the squared-L2 distances are (1, a^2, b^2) (float32 arithmetic reproduced here)."""
+    thr = 0.9
+    far, near = (2.0, 3.0), (1.02, 1.04)                           # d1/d2, d1/d3 = .25, .11 | .961, .925
+    table = [  # (classes of k1 k2 k3, offsets of k2 k3, accepted neighbour: 0 = k1, 1 = k2, -1 = none)
+        ((0, 0, 0), near, 0), ((0, 0, 1), far, 0), ((0, 0, 1), near, -1), ((0, 1, 1), near, 1), ((0, 1, 1), far, -1),
+        ((0, 1, 2), far, 0), ((0, 1, 2), near, -1), ((0, 1, 0), far, 0), ((0, 1, 0), near, -1)]
+    words, wcls, q, exp_idx, exp_d = [], [], [], [], []
+    for j, (cls, (a, b), acc) in enumerate(table):
+        x0 = f32(100.0 * j)
+        row0 = len(words)
+        for off, c in zip((1.0, a, b), cls):
+            words.append([float(f32(x0 + f32(off))), 0.0]); wcls.append(c)
+        q.append([float(x0), 0.0])
+        d = [float(f32(f32(f32(words[row0 + t][0]) - x0) ** 2)) for t in range(3)]
+        assert d[0] < d[1] < d[2]
+        r12, r13 = d[0] / d[1], d[0] / d[2]
+        assert (r12 < thr) == (a == far[0]) and (r13 < thr) == (b == far[1])
+        exp_idx.append(row0 + acc if acc >= 0 else -1); exp_d.append(d[acc] if acc >= 0 else None)
+    return dict(words=words, word_class=wcls, q=q, threshold=thr, expected_idx=exp_idx, expected_dist=exp_d)
+
+
+def maxima_thresholds():
+    """KAT 14: Voting::findMaxima tail (voting.cpp:296-323, 441-462): three classes, every vote of a class at ONE point (so the
+    Gaussian mean-shift mode is that point and the reweighting factor e^{-u/2} is 1): class weights 6, 3, 1 -> normalised
+    0.6, 0.3, 0.1; MinThreshold > 0 is absolute, < 0 relative to the best; BestK > 0 keeps the first BestK."""
+    pos = [[0, 0, 0]] * 4 + [[10, 0, 0]] * 3 + [[0, 10, 0]] * 2
+    w = [1.5, 1.5, 2.0, 1.0, 1.0, 1.0, 1.0, 0.5, 0.5]
+    cls = [0] * 4 + [1] * 3 + [2] * 2
+    inst = [7, 7, 8, 8, 1, 1, 2, 5, 5]
+    cases = [dict(min_threshold=0.0, best_k=-1, n=3), dict(min_threshold=0.2, best_k=-1, n=2), dict(min_threshold=0.31, best_k=-1, n=1),
+             dict(min_threshold=-0.4, best_k=-1, n=2), dict(min_threshold=-0.6, best_k=-1, n=1), dict(min_threshold=0.0, best_k=1, n=1),
+             dict(min_threshold=0.0, best_k=2, n=2), dict(min_threshold=0.0, best_k=5, n=3)]
+    return dict(pos=pos, w=w, cls=cls, inst=inst, bandwidth=1.0, n_classes=3, cases=cases, weights=[0.6, 0.3, 0.1], classes=[0, 1, 2],
+                instances=[7, 1, 5], instance_weights=[3.0 / 5.0, 2.0 / 5.0, 1.0 / 5.0], n_votes=[4, 3, 2], tol=1e-6)
+
+
 def main():
     kat = dict(shot_sector_centres=shot_sector_centres(), lrf_paraboloid=lrf_paraboloid(), rgb2lab=rgb2lab_cases(),
                fpfh_two_points=fpfh_two_points(), distances=distances(), rotations=rotations(), seeds_order=seeds_order(),
-               voxel_grid=voxel_grid(), knn_ties=knn_ties())
+               voxel_grid=voxel_grid(), knn_ties=knn_ties(), shot_off_centre=shot_off_centre(), cshot_colour_pairs=cshot_colour_pairs(),
+               cast_votes_vector=cast_votes_vector(), knn_rule_table=knn_rule_table(), maxima_thresholds=maxima_thresholds())
     with open(OUT, "w") as f:
         json.dump(kat, f, indent=1)
     print("wrote", OUT)

@@ -1,0 +1,92 @@
+"""Round-2 known-answer vectors (tests/golden/kat.json: shot_off_centre, cshot_colour_pairs, cast_votes_vector, knn_rule_table,
+maxima_thresholds), written once against an abstract back end so that the SAME checks run on the CPU oracle
+(tests/test_oracle_kat.py) and on the HIP path through the C ABI (tests/test_gpu_parity.py). The expected values come from
+closed-form numpy in tests/golden/make_golden.py, not from the oracle and not from the HIP library."""
+import json
+import os
+
+import numpy as np
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+
+
+def shot_off_centre(shot352):
+    """shot352(points[n,3], normals[n,3], radius) -> descriptor of a keypoint at the origin with the identity frame"""
+    k = KAT["shot_off_centre"]
+    for c in k["cases"]:
+        pts = np.tile(np.asarray(c["point"], np.float32), (c["copies"], 1))
+        nrm = np.tile(np.asarray(c["normal"], np.float32), (c["copies"], 1))
+        d = shot352(pts, nrm, c["radius"])
+        exp = np.asarray(c["expected"], np.float32)
+        np.testing.assert_allclose(d, exp, atol=k["tol"])
+        for name, (b, w) in c["parts"].items():          # every interpolation deposit sits in ITS bin with ITS share
+            if name != "colour":
+                assert abs(d[b] - w / np.sqrt(sum(v[1] ** 2 for kk, v in c["parts"].items() if kk != "colour"))) < 1e-5, name
+
+
+def cshot_colour_pairs(cshot1344):
+    """cshot1344(points, normals, rgba[n], kp_rgba, radius) -> 1344 values"""
+    k = KAT["cshot_colour_pairs"]
+    for c in k["cases"]:
+        n = c["copies"]
+        pts = np.tile(np.asarray(c["point"], np.float32), (n, 1)); nrm = np.tile(np.asarray(c["normal"], np.float32), (n, 1))
+        d = cshot1344(pts, nrm, np.full(n, c["rgba"], np.uint32), c["kp_rgba"], c["radius"])
+        np.testing.assert_allclose(d, np.asarray(c["expected"], np.float32), atol=k["tol"])
+        assert abs(np.linalg.norm(d) - 1) < 1e-5
+        col = d[352:].reshape(32, 31)
+        assert col[:, c["colour_step"]].sum() > 0.5 * col.sum()       # the hard colour step holds most of the colour mass
+
+
+def cast_votes_vector(cast_votes):
+    """cast_votes(cb dict, flags, lrf[nq,9], kp[nq,3], idx[nq,1], dist[nq,1]) -> dict of slot arrays (2 slots per activation)"""
+    k = KAT["cast_votes_vector"]
+    cb = {kk: np.asarray(v, np.float32) for kk, v in k["codebook"].items()}
+    for kk in ("vote_offsets", "vote_class", "vote_instance"):
+        cb[kk] = np.asarray(k["codebook"][kk], np.uint32)
+    acts = k["activations"]
+    lrf = np.asarray([k["frames"][a["frame"]] for a in acts], np.float32)
+    kp = np.asarray([a["kp"] for a in acts], np.float32)
+    idx = np.asarray([[a["word"]] for a in acts], np.int32)
+    dist = np.asarray([[a["dist"]] for a in acts], np.float32)
+    for flags, rows in k["expected"].items():
+        got = cast_votes(cb, int(flags), lrf, kp, idx, dist)
+        assert len(got["cls"]) == len(rows) == 2 * len(acts)
+        for s, r in enumerate(rows):
+            assert got["cls"][s] == r["cls"], (flags, s)
+            if r["cls"] < 0:
+                continue
+            assert got["inst"][s] == r["inst"] and got["codeword"][s] == r["codeword"], (flags, s)
+            assert abs(got["weight"][s] - r["weight"]) <= k["tol"] * max(1.0, r["weight"]), (flags, s, got["weight"][s], r["weight"])
+            np.testing.assert_allclose(got["pos"][s], r["pos"], atol=5e-6)
+            np.testing.assert_allclose(got["bbox_quat"][s], r["bbox_quat"], atol=5e-6)
+            np.testing.assert_allclose(got["bbox_size"][s], r["bbox_size"], atol=0)
+
+
+def knn_rule_table(knn_rule):
+    """knn_rule(metric, words, word_class, q, thr) -> (idx[nq], dist[nq])"""
+    k = KAT["knn_rule_table"]
+    idx, dist = knn_rule(0, np.asarray(k["words"], np.float32), np.asarray(k["word_class"], np.uint32), np.asarray(k["q"], np.float32), k["threshold"])
+    idx = np.asarray(idx).reshape(-1); dist = np.asarray(dist).reshape(-1)
+    assert idx.tolist() == k["expected_idx"]
+    for g, e in zip(dist, k["expected_dist"]):
+        assert (np.isnan(g) if e is None else g == np.float32(e)), (g, e)
+
+
+def maxima_thresholds(find_maxima):
+    """find_maxima(slot_offsets, votes dict, **kw) -> dict as oracle_py.find_maxima"""
+    k = KAT["maxima_thresholds"]
+    v = dict(pos=np.asarray(k["pos"], np.float32), weight=np.asarray(k["w"], np.float32), cls=np.asarray(k["cls"], np.int32),
+             inst=np.asarray(k["inst"], np.int32))
+    for c in k["cases"]:
+        out = find_maxima([0, len(v["weight"])], v, n_classes=k["n_classes"], bandwidth=k["bandwidth"], max_maxima=8,
+                           min_threshold=c["min_threshold"], best_k=c["best_k"])
+        n = int(np.asarray(out["n"])[0])
+        assert n == c["n"], (c, n)
+        np.testing.assert_allclose(np.asarray(out["weight"])[0, :n], k["weights"][:n], atol=k["tol"])
+        assert np.asarray(out["cls"])[0, :n].tolist() == k["classes"][:n]
+        assert np.asarray(out["inst"])[0, :n].tolist() == k["instances"][:n]
+        assert np.asarray(out["n_votes"])[0, :n].tolist() == k["n_votes"][:n]
+        np.testing.assert_allclose(np.asarray(out["pos"])[0, :n], np.asarray(k["pos"], np.float32)[[0, 4, 7]][:n], atol=1e-5)
+        score = np.zeros(k["n_classes"], np.float32)
+        score[k["classes"][:n]] = k["weights"][:n]
+        np.testing.assert_allclose(np.asarray(out["class_score"])[0], score, atol=k["tol"])

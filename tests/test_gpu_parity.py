@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import make_cloud
+import kat_checks
 
 pytestmark = pytest.mark.gpu
 KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
@@ -671,6 +672,64 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
     assert np.array_equal(i16[10:20, 1], np.arange(50000, 50010)) and (d16[10:20, 1] == 0).all()    # the duplicate is the second neighbour
     assert (d16[:, 0] <= d16[:, 1]).all()
     assert flagged[0] < nq // 20, flagged                                                   # the proof carries the bulk, the scan the rest
+
+
+# ------------------------------------------------------------------------------------------------ round-2 known-answer vectors
+# the same closed-form vectors the oracle is held to (tests/kat_checks.py), here through the C ABI on the GPU
+def test_kat_shot_off_centre_interpolation(pkg, gpu):
+    ctx, dev = gpu
+
+    def f(pts, nrm, radius):
+        s = Scene(pkg, gpu, [(pts, nrm)], [np.zeros((1, 3), np.float32)], 0.4 * radius)
+        d, cnt = pkg.capi.shot352(ctx, s.cloud, s.kp_off, *s.tk, T(np.eye(3, dtype=np.float32).reshape(1, 9), dev), radius, want_counts=True)
+        assert int(cnt.cpu().numpy()[0]) == len(pts)
+        return d.cpu().numpy()[0]
+    kat_checks.shot_off_centre(f)
+
+
+def test_kat_cshot_colour_channel(pkg, gpu):
+    ctx, dev = gpu
+
+    def f(pts, nrm, rgba, kp_rgba, radius):
+        s = Scene(pkg, gpu, [(pts, nrm)], [np.zeros((1, 3), np.float32)], 0.4 * radius, rgba=[rgba], kp_rgba=[np.asarray([kp_rgba], np.uint32)])
+        d = pkg.capi.cshot1344(ctx, s.cloud, s.kp_off, *s.tk, s.t_kp_rgba, T(np.eye(3, dtype=np.float32).reshape(1, 9), dev), radius)
+        return d.cpu().numpy()[0]
+    kat_checks.cshot_colour_pairs(f)
+
+
+def test_kat_cast_votes_vector(pkg, gpu):
+    ctx, dev = gpu
+
+    def f(cb, flags, lrf, kp, idx, dist):
+        dcb = pkg.capi.Codebook(ctx, cb["words"], cb["vote_offsets"], cb["vote_xyz"], cb["vote_class"], cb["vote_instance"], 2, cb["class_sigma"],
+                                word_weight=cb["word_weight"], vote_weight=cb["vote_weight"], vote_class_weight=cb["vote_class_weight"],
+                                vote_bbox_quat=cb["vote_bbox_quat"], vote_bbox_size=cb["vote_bbox_size"])
+        got = pkg.capi.cast_votes(ctx, dcb, flags, T(lrf, dev), T(kp[:, 0], dev), T(kp[:, 1], dev), T(kp[:, 2], dev), T(idx, dev), T(dist, dev), want_bbox=True)
+        out = {k: v.cpu().numpy() for k, v in got.items() if v is not None}
+        dcb.close()
+        return out
+    kat_checks.cast_votes_vector(f)
+
+
+def test_kat_knn_rule_truth_table(pkg, gpu):
+    ctx, dev = gpu
+
+    def f(metric, words, wcls, q, thr):
+        n = len(words)
+        cb = pkg.capi.Codebook(ctx, words, np.arange(n + 1, dtype=np.uint32), np.zeros((n, 3), np.float32), wcls, np.zeros(n, np.uint32),
+                               int(wcls.max()) + 1, np.ones(int(wcls.max()) + 1, np.float32))
+        i, d = pkg.capi.knn_rule(ctx, cb, metric, T(q, dev), thr)
+        return i.cpu().numpy(), d.cpu().numpy()
+    kat_checks.knn_rule_table(f)
+
+
+def test_kat_maxima_thresholds_and_bestk(pkg, gpu):
+    ctx, dev = gpu
+
+    def f(off, v, **kw):
+        out = pkg.capi.find_maxima(ctx, off, {k: T(a, dev) for k, a in v.items()}, **kw)
+        return {k: a.cpu().numpy() for k, a in out.items()}
+    kat_checks.maxima_thresholds(f)
 
 
 def test_errors_are_loud(pkg, gpu):

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import make_cloud
+import kat_checks
 
 KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
 
@@ -267,3 +268,38 @@ def test_class_sigmas_match_harness(ora, pkg):
         a = ora.class_sigmas(metric, feats, cls, model, act, feats, 3)
         b = pkg.pipeline.class_sigmas_numpy(metric, feats, cls, model, act, 3)
         np.testing.assert_allclose(a, b, rtol=2e-4)
+
+
+# ---- round-2 vectors (kat_checks.py runs the same checks on the HIP path in test_gpu_parity.py) ---------------------------
+def _ora_shot(ora):
+    def f(pts, nrm, radius):
+        x, y, z = _soa(pts); nx, ny, nz = _soa(nrm)
+        d, cnt = ora.shot352([0, len(pts)], x, y, z, nx, ny, nz, [0, 1], [0], [0], [0], np.eye(3, dtype=np.float32).reshape(1, 9), radius)
+        assert cnt[0] == len(pts)
+        return d[0]
+    return f
+
+
+def test_shot_off_centre_interpolation(ora):
+    kat_checks.shot_off_centre(_ora_shot(ora))
+
+
+def test_cshot_colour_channel(ora):
+    def f(pts, nrm, rgba, kp_rgba, radius):
+        x, y, z = _soa(pts); nx, ny, nz = _soa(nrm)
+        d, _ = ora.cshot1344([0, len(pts)], x, y, z, nx, ny, nz, rgba, [0, 1], [0], [0], [0], np.asarray([kp_rgba], np.uint32),
+                             np.eye(3, dtype=np.float32).reshape(1, 9), radius)
+        return d[0]
+    kat_checks.cshot_colour_pairs(f)
+
+
+def test_cast_votes_vector(ora):
+    kat_checks.cast_votes_vector(lambda cb, flags, lrf, kp, idx, dist: ora.cast_votes(cb, flags, lrf, kp[:, 0], kp[:, 1], kp[:, 2], idx, dist))
+
+
+def test_knn_rule_truth_table(ora):
+    kat_checks.knn_rule_table(ora.knn_rule)
+
+
+def test_maxima_thresholds_and_bestk_vector(ora):
+    kat_checks.maxima_thresholds(ora.find_maxima)
