@@ -65,6 +65,7 @@ static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out)
     { const char* e = getenv("ISMHIP_XCD_MAP"); ctx->xcd_map = !(e && e[0] == '0'); }
     { const char* e = getenv("ISMHIP_GRID_XFRAC"); ctx->grid_xfrac = e ? (float)atof(e) : 0.f; }
     { const char* e = getenv("ISMHIP_SHOT_VAR"); ctx->shot_var = e ? atoi(e) : 0; }
+    { const char* e = getenv("ISMHIP_KNN_TWOSTAGE"); ctx->knn_two_stage = !(e && e[0] == '0'); }
     { const char* e = getenv("ISMHIP_KNN_RING32"); ctx->knn_ring32 = e && e[0] == '1'; }
     { const char* e = getenv("ISMHIP_KNN_SPLITS"); ctx->knn_splits = e ? atoi(e) : 0; }
     { const char* e = getenv("ISMHIP_KNN_T"); ctx->knn_t = e ? atoi(e) : 0; }
@@ -147,6 +148,7 @@ int ismhip_timers_reset(ismhip_ctx* ctx) {
 int ismhip_timer_get(ismhip_ctx* ctx, const char* name, double* ms_out, int64_t* launches_out) {
     if (!ctx || !name) return ISMHIP_ERR_INVALID;
     resolve_timers(ctx);
+    if (std::strcmp(name, "knn_stage2_queries") == 0) { if (ms_out) *ms_out = (double)ctx->knn_stage2_queries; if (launches_out) *launches_out = 1; return ISMHIP_OK; }
     if (std::strcmp(name, "knn_flagged_queries") == 0 || std::strcmp(name, "knn_flagged_items") == 0) {     // counters, not times
         if (ms_out) *ms_out = (double)ctx->knn_stats[name[12] == 'q' ? 0 : 1];
         if (launches_out) *launches_out = 1;

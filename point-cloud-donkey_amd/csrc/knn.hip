@@ -994,6 +994,47 @@ __device__ __forceinline__ float flann_chi2(const float* a, const float* b, int 
     return result;
 }
 
+// Folds the candidates of MANY codebook splits into one slot. A wave per query keeps the KNN_MERGE_KEEP smallest approximate
+// scores of all splits' candidates; the merged bound is the smallest score anything dropped: every split slot's own bound and the
+// best candidate this merge leaves out. (A NaN bound stays NaN, so that the proof fails and the query takes the exact scan.)
+#define KNN_MERGE_KEEP 16
+__device__ __forceinline__ unsigned knn_sortable(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__global__ __launch_bounds__(256) void k_knn_merge_splits(int nq, const float* __restrict__ cand_val, const int* __restrict__ cand_idx, int n_cand,
+                                                          const float* __restrict__ cand_bound, int n_bound,
+                                                          float* __restrict__ out_val, int* __restrict__ out_idx, float* __restrict__ out_bound) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const int lane = lane_id();
+    const float* v = cand_val + (size_t)qi * n_cand; const int* id = cand_idx + (size_t)qi * n_cand;
+    unsigned long long prev = 0ull;                                    // keys are > 0: bit 63 or the complement of a negative float
+    bool first = true;
+    float dropped = __builtin_inff();
+    for (int r = 0; r <= KNN_MERGE_KEEP; ++r) {
+        unsigned long long best = ~0ull;
+        for (int i = lane; i < n_cand; i += 64) {
+            if (id[i] < 0) continue;                                   // empty slot entry
+            const unsigned long long key = ((unsigned long long)knn_sortable(v[i]) << 32) | (unsigned)i;
+            if ((first || key > prev) && key < best) best = key;
+        }
+        best = wave_min_u64(best);
+        if (r < KNN_MERGE_KEEP) {
+            if (lane == 0) {
+                const bool have = best != ~0ull;
+                const int i = have ? (int)(best & 0xffffffffull) : 0;
+                out_val[(size_t)qi * KNN_MERGE_KEEP + r] = have ? v[i] : __builtin_inff();
+                out_idx[(size_t)qi * KNN_MERGE_KEEP + r] = have ? id[i] : -1;
+            }
+        } else if (best != ~0ull) dropped = v[(int)(best & 0xffffffffull)];
+        if (best == ~0ull) { for (int rr = r + 1; rr < KNN_MERGE_KEEP; ++rr) if (lane == 0) { out_val[(size_t)qi * KNN_MERGE_KEEP + rr] = __builtin_inff(); out_idx[(size_t)qi * KNN_MERGE_KEEP + rr] = -1; } break; }
+        prev = best; first = false;
+    }
+    float b = dropped;
+    for (int i = lane; i < n_bound; i += 64) { const float x = cand_bound[(size_t)qi * n_bound + i]; if (x < b || x != x) b = x; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float x = __shfl_xor(b, o, 64); if (x < b || x != x) b = x; }
+    if (lane == 0) out_bound[qi] = b;
+}
+
 struct VerifyParams {
     float ku;         // 1.01 * K * u : relative error bound of a K-term fp32 functor sum (u = 2^-24)
     float dot_rel;    // bound on |approx(q.c) - q.c| / (|q||c|) of the candidate kernel (f32 fma chain: ku; bf16x3: see k_knn_l2_mfma16)
@@ -1166,8 +1207,9 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
     const int g = lane >> 4, l16 = lane & 15;
     const uint32_t n_items = flag_count[1];
     const bool l2 = metric != ISMHIP_METRIC_CHI2;
-    const bool lay16 = l2 && wr_rows < 0;                         // k_knn_l2_ring16: slot b = split*8 + wr*4 + fq owns rows wr*128 + 16 m + 4 fq + j
-    const int rows_per_tile = lay16 ? 32 : (l2 ? wr_rows / 2 : tile_rows);   // else a lane slot sees half of its wave-row block (bit 2 of the row == h)
+    const bool lay_all = l2 && wr_rows == -2;                     // merged splits (k_knn_merge_splits): the one slot owns every row
+    const bool lay16 = l2 && wr_rows == -1;                       // k_knn_l2_ring16: slot b = split*8 + wr*4 + fq owns rows wr*128 + 16 m + 4 fq + j
+    const int rows_per_tile = lay_all ? tile_rows : (lay16 ? 32 : (l2 ? wr_rows / 2 : tile_rows));   // else a lane slot sees half of its wave-row block (bit 2 of the row == h)
     const int nj = dim_pad / 16;
     const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     // With few items a wave per item would leave the chip idle behind a handful of long scans: every item is cut into P row
@@ -1178,7 +1220,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
         const uint32_t it = u / P, part_i = u % P;
         const int qi = (int)items[2 * (size_t)it], b = (int)items[2 * (size_t)it + 1];
         const float* qp = q + (size_t)qi * ldq;
-        const int split = lay16 ? (b >> 3) : (l2 ? (b >> 2) : b);
+        const int split = lay_all ? 0 : (lay16 ? (b >> 3) : (l2 ? (b >> 2) : b));
         const int wr = lay16 ? (b >> 2) & 1 : (b >> 1) & 1, h = b & 1, fq = b & 3;
         const int mt0 = split * tiles_per_split, mt1 = min(n_tiles, mt0 + tiles_per_split);
         const int total = (mt1 - mt0) * rows_per_tile;
@@ -1195,7 +1237,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
             int r = n_words;                                  // out of range = idle group
             if (e < e_end) {
                 const int tile = mt0 + e / rows_per_tile, y = e % rows_per_tile;
-                const int x = lay16 ? (wr * 128 + ((y >> 2) << 4) + (fq << 2) + (y & 3)) : (l2 ? (wr * wr_rows + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y);
+                const int x = lay_all ? y : (lay16 ? (wr * 128 + ((y >> 2) << 4) + (fq << 2) + (y & 3)) : (l2 ? (wr * wr_rows + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y));
                 r = tile * tile_rows + x;
             }
             float part = 0.f;
@@ -1297,9 +1339,13 @@ __global__ void k_rule(int nq, float thr, const int32_t* __restrict__ idx3, cons
     idx_out[i] = id; dist_out[i] = dd;
 }
 
+// stage1 != nullptr: FIRST stage of the two-stage search -- candidates + exact re-rank + proof only; the unproven queries are
+// left in the queue (*stage1 = {flag_count, qrec}) for the caller instead of going to the exact scan. tname: timer of the
+// candidate kernel.
+struct KnnStage1 { uint32_t* flag_count; uint32_t* qrec; };
 template <int T>
 int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q, int k,
-            int32_t* idx_out, float* dist_out) {
+            int32_t* idx_out, float* dist_out, KnnStage1* stage1 = nullptr, const char* tname = nullptr, bool many_splits = false) {
     if (cb->dim_pad / 16 > KNN_FB_MAXJ) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: descriptor longer than 1344 not built");
     const float* qq = q; int ldq = cb->dim;
     if (cb->dim_pad != cb->dim) {
@@ -1323,6 +1369,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     const bool ring16 = use_ring && !ctx->knn_ring32;                  // 16x16x32 MFMA shape: 8 lane slots per query and split instead of 4
     const int slots = ring16 ? 8 : 4;
     const int ring_nk = ((cb->dim + 15) / 16 + 1) / 2;                 // 32-k slices per row in the tiled images
+    const bool merged = many_splits && metric == ISMHIP_METRIC_L2SQ && use_lp && !big_tile;
     if (metric == ISMHIP_METRIC_L2SQ) {
         const int n_qt = (nq + BNq - 1) / BNq, n_mt = cb->n_words_pad / BM;
         const int max_s = 64 / (slots * T);
@@ -1330,6 +1377,9 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         // re-read per codeword tile) and fall out of its 4 MB L2; two splits halve that working set (measured 21.0 -> 19.9 ms at 262144 queries)
         n_splits = std::max(1, std::min(std::min(max_s, n_mt), std::max(2, (1024 + n_qt - 1) / n_qt)));
         if (ctx->knn_splits > 0) n_splits = std::max(1, std::min(std::min(max_s, n_mt), ctx->knn_splits));
+        // few queries (stage 2 of the two-stage search): cut the codebook into as many splits as it takes to fill the chip; the
+        // candidates of all splits are then folded into one slot of KNN_MERGE_KEEP by k_knn_merge_splits
+        if (merged) n_splits = std::max(1, std::min(n_mt, (1024 + 8 * ((n_qt + 7) / 8) - 1) / (8 * ((n_qt + 7) / 8))));
         tiles_per_split = (n_mt + n_splits - 1) / n_splits;
         n_splits = (n_mt + tiles_per_split - 1) / tiles_per_split;
         cand_per_split = slots * T;
@@ -1342,9 +1392,9 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         cand_per_split = T;
     }
     n_cand = n_splits * cand_per_split;
-    const int n_bound = metric == ISMHIP_METRIC_L2SQ ? n_splits * slots : n_splits;
-    float* cand_val = (float*)ism_scratch(ctx, SCR_KNN_CAND_VAL, (size_t)nq * (n_cand + n_bound) * sizeof(float));
-    int* cand_idx = (int*)ism_scratch(ctx, SCR_KNN_CAND_IDX, (size_t)nq * n_cand * sizeof(int));
+    int n_bound = metric == ISMHIP_METRIC_L2SQ ? n_splits * slots : n_splits;
+    float* cand_val = (float*)ism_scratch(ctx, SCR_KNN_CAND_VAL, (size_t)nq * (n_cand + n_bound + (merged ? KNN_MERGE_KEEP + 1 : 0)) * sizeof(float));
+    int* cand_idx = (int*)ism_scratch(ctx, SCR_KNN_CAND_IDX, (size_t)nq * (n_cand + (merged ? KNN_MERGE_KEEP : 0)) * sizeof(int));
     // queue of unproven work: 16 counters | query records [nq*3] | items [nq*n_bound*2] | item results [nq*n_bound*4] u64
     const size_t q_items = (size_t)nq * n_bound;
     uint32_t* flags = (uint32_t*)ism_scratch(ctx, SCR_KNN_FLAGS, (16 + 3 * (size_t)nq + 2 * q_items) * sizeof(uint32_t) + 8 + (q_items + KNN_FB_UNITS) * 4 * sizeof(unsigned long long));
@@ -1373,7 +1423,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         }
     }
     {
-        TimerScope ts(ctx, metric == ISMHIP_METRIC_L2SQ ? "knn_l2_mfma" : "knn_chi2");
+        TimerScope ts(ctx, tname ? tname : (metric == ISMHIP_METRIC_L2SQ ? "knn_l2_mfma" : "knn_chi2"));
         if (use_lp) {
             const int n_qt = (nq + BNq - 1) / BNq;
             const dim3 grid(8 * ((n_qt + 7) / 8) * n_splits);
@@ -1445,6 +1495,13 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
             ISM_CHECK_LAUNCH(ctx, "k_knn_chi2");
         }
     }
+    if (merged) {
+        float* m_val = cand_bound + (size_t)nq * n_bound; float* m_bound = m_val + (size_t)nq * KNN_MERGE_KEEP;
+        int* m_idx = cand_idx + (size_t)nq * n_cand;
+        hipLaunchKernelGGL(k_knn_merge_splits, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, nq, cand_val, cand_idx, n_cand, cand_bound, n_bound, m_val, m_idx, m_bound);
+        ISM_CHECK_LAUNCH(ctx, "k_knn_merge_splits");
+        cand_val = m_val; cand_idx = m_idx; cand_bound = m_bound; n_cand = KNN_MERGE_KEEP; n_bound = 1;
+    }
     VerifyParams vp;
     vp.ku = 1.01f * (float)cb->dim_pad * KNN_U;
     // relative part of the candidate kernel's dot error (see the kernels): representation + accumulation (<= 2^-23 per add, any order)
@@ -1458,16 +1515,64 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     hipLaunchKernelGGL(k_knn_rerank, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
                        qq, nq, ldq, metric, cand_idx, cand_val, n_cand, n_cand, cand_bound, n_bound, vp, k, idx_out, dist_out, flag_count, qrec, items);
     ISM_CHECK_LAUNCH(ctx, "k_knn_rerank");
+    if (stage1) { stage1->flag_count = flag_count; stage1->qrec = qrec; return ISMHIP_OK; }
     {
         TimerScope ts(ctx, "knn_fallback");
         hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad,
-                           cb->n_words, qq, ldq, metric, k, tiles_per_split, cb->n_words_pad / BM, BM, ring16 ? -1 : wr_rows,
+                           cb->n_words, qq, ldq, metric, k, merged ? cb->n_words_pad / BM : tiles_per_split, cb->n_words_pad / BM, BM, merged ? -2 : (ring16 ? -1 : wr_rows),
                            flag_count, items, idx_out, dist_out, item_out, q_items);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback");
         hipLaunchKernelGGL(k_knn_fallback_merge, dim3(256), dim3(256), 0, ctx->stream, k, flag_count, qrec, item_out, q_items, idx_out, dist_out);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback_merge");
     }
     if (ctx->timers_on) ISM_HIP(ctx, hipMemcpyAsync(ctx->knn_stats, flag_count, 8, hipMemcpyDeviceToHost, ctx->stream));   // read back after a sync
+    return ISMHIP_OK;
+}
+
+// ---- two-stage search -------------------------------------------------------------------------------------------------------
+// The top-T bookkeeping in the candidate kernel's epilogue costs time in proportion to T (measured, 262144 queries x 102400
+// words: T = 4 18.7 ms, T = 2 16.8 ms, T = 1 16.2 ms), but a small T leaves more queries unproven (T = 2: ~0.1 % of them, T = 1:
+// ~3 %), and the exact scan that finishes an unproven query reads its slots' share of the f32 codebook (24 us per query).
+// So: stage 1 runs T = 2 over all queries; the few queries its proof rejects are gathered and searched again with T = 4 (a
+// launch ~1000x smaller), and only what THAT proof rejects goes to the exact scan. Every answer is still the exact functor
+// minimum, proven or scanned.
+__global__ __launch_bounds__(256) void k_knn_gather_flagged(const uint32_t* __restrict__ qrec, int n2, const float* __restrict__ q, int dim,
+                                                            float* __restrict__ q2, uint32_t* __restrict__ list2) {
+    const int i = blockIdx.x;
+    if (i >= n2) return;
+    const uint32_t qi = qrec[3 * (size_t)i];
+    if (threadIdx.x == 0) list2[i] = qi;
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) q2[(size_t)i * dim + c] = q[(size_t)qi * dim + c];
+}
+__global__ void k_knn_scatter_results(const uint32_t* __restrict__ list2, int n2, int k, const int32_t* __restrict__ idx2, const float* __restrict__ dist2,
+                                      int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n2 * k) return;
+    const size_t o = (size_t)list2[t / k] * k + (t % k);
+    idx_out[o] = idx2[t]; dist_out[o] = dist2[t];
+}
+
+int run_knn_two_stage(ismhip_ctx* ctx, const ismhip_codebook* cb, int nq, const float* q, int k, int32_t* idx_out, float* dist_out) {
+    KnnStage1 s1{nullptr, nullptr};
+    int rc = run_knn<2>(ctx, cb, ISMHIP_METRIC_L2SQ, nq, q, k, idx_out, dist_out, &s1, nullptr);
+    if (rc != ISMHIP_OK) return rc;
+    uint32_t n2u = 0;
+    ISM_HIP(ctx, hipMemcpyAsync(&n2u, s1.flag_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the one host round trip of the call: how many queries need stage 2
+    ctx->knn_stage2_queries = n2u;
+    const int n2 = (int)n2u;
+    if (n2 == 0) { ctx->knn_stats[0] = ctx->knn_stats[1] = 0; return ISMHIP_OK; }
+    float* q2 = (float*)ism_scratch(ctx, SCR_KNN_Q2, (size_t)n2 * cb->dim * sizeof(float));
+    uint32_t* list2 = (uint32_t*)ism_scratch(ctx, SCR_KNN_LIST2, (size_t)n2 * (sizeof(uint32_t) + (size_t)k * (sizeof(int32_t) + sizeof(float))));
+    if (!q2 || !list2) return ISMHIP_ERR_NOMEM;
+    int32_t* idx2 = (int32_t*)(list2 + n2);
+    float* dist2 = (float*)(idx2 + (size_t)n2 * k);
+    hipLaunchKernelGGL(k_knn_gather_flagged, dim3(n2), dim3(256), 0, ctx->stream, s1.qrec, n2, q, cb->dim, q2, list2);
+    ISM_CHECK_LAUNCH(ctx, "k_knn_gather_flagged");
+    rc = run_knn<4>(ctx, cb, ISMHIP_METRIC_L2SQ, n2, q2, k, idx2, dist2, nullptr, "knn_stage2", n2 < 4096);
+    if (rc != ISMHIP_OK) return rc;
+    hipLaunchKernelGGL(k_knn_scatter_results, dim3((n2 * k + 255) / 256), dim3(256), 0, ctx->stream, list2, n2, k, idx2, dist2, idx_out, dist_out);
+    ISM_CHECK_LAUNCH(ctx, "k_knn_scatter_results");
     return ISMHIP_OK;
 }
 
@@ -1513,6 +1618,10 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
     // T = candidates kept per slot. The bf16x3 candidate scores carry a larger error bound, so more are kept (T = 4): the proof
     // then compares against the 5th best of every slot and almost never fails.
     const bool wide = k > 2 || (metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi && ctx->knn_mode <= 1);
+    // default for big squared-L2 launches with k <= 2 (every shipped configuration): the two-stage search (see run_knn_two_stage)
+    if (metric == ISMHIP_METRIC_L2SQ && k <= 2 && ctx->knn_t == 0 && ctx->knn_mode == 0 && ctx->knn_two_stage && cb->words_f16t && nq >= 4096 &&
+        cb->n_words_pad >= 4096 && !ctx->knn_small_tile && !ctx->knn_no_ring)
+        return run_knn_two_stage(ctx, cb, nq, q, k, idx_out, dist_out);
     if (ctx->knn_t == 1 && k <= 1) return run_knn<1>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
     if (ctx->knn_t == 3 && k <= 3) return run_knn<3>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
     if (ctx->knn_t == 2 && k <= 2) return run_knn<2>(ctx, cb, metric, nq, q, k, idx_out, dist_out);

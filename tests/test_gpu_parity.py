@@ -305,6 +305,42 @@ def test_knn_few_unproven_slots_take_the_split_scan(pkg, gpu, ora):
         ctx.timers_enable(False)
 
 
+def test_knn_two_stage_search_matches_oracle(pkg, gpu, ora):
+    """Big squared-L2 launches with k <= 2 take the two-stage search (T = 2 over all queries, T = 4 + merged splits for the
+    queries stage 1 cannot prove, exact scan of ALL rows for what stage 2 cannot prove). The codebook holds clusters of 3, 6
+    and 20 bit-identical / near-identical rows, each inside one stage-1 lane slot: 3 overflow its top-2, 20 also overflow the merged
+    stage-2 slot (16 kept), so all three endings are exercised; answers must be the oracle's, ties to the lowest row."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(2024)
+    words = rng.random((8192, 96)).astype(np.float32)
+    words /= np.linalg.norm(words, axis=1, keepdims=True)
+    # rows 16 m + 4 fq + j (m < 8, j < 4) of a 256-row tile share ONE stage-1 lane slot (wave row 0, slot fq): put every cluster
+    # into one slot of its tile so that it overflows the slot's top-2
+    proto = [260, 1024 + 8, 4096]
+    for p_, n in zip(proto, (3, 6, 20)):
+        rows = np.asarray([p_ + 16 * (i // 4) + (i % 4) for i in range(n)])
+        words[rows] = words[p_]
+        words[rows[1::2]] += (1e-7 * rng.random((len(rows[1::2]), 96))).astype(np.float32)    # half of the copies differ in the last bits
+    q = rng.random((6000, 96)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    for j, p_ in enumerate(proto):
+        q[100 * j:100 * j + 40] = words[p_] + (1e-4 * rng.random((40, 96))).astype(np.float32)
+    q[777] = words[proto[2]]
+    host, cb = _cb(pkg, gpu, words)
+    ctx.timers_enable(True)
+    try:
+        for k in (1, 2):
+            idx, dist = pkg.capi.knn(ctx, cb, 0, T(q, dev), k)
+            gi, gd = idx.cpu().numpy(), dist.cpu().numpy()
+            n2 = int(ctx.timer("knn_stage2_queries")[0]); nfq, _ = _knn_flagged(ctx)
+            widx, wdist = ora.knn(0, words, q, k)
+            assert np.array_equal(gi, widx) and np.array_equal(gd, wdist)
+            assert n2 >= 41 and nfq >= 1, (n2, nfq)                      # stage 2 ran, and it left work for the exact scan
+            assert n2 < 2000                                             # ... but stage 1 proved the bulk
+    finally:
+        ctx.timers_enable(False)
+
+
 @pytest.mark.parametrize("mode", ["f16", "bf16x3", "f32"])
 @pytest.mark.parametrize("scale", [1.0, 1e-30, 3e-6, 250.0, 1e20])
 def test_knn_candidate_modes_and_magnitudes(pkg, gpu, ora, mode, scale, monkeypatch):

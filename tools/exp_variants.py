@@ -28,7 +28,7 @@ cb = rec0.train([pipeline.DeviceBatch(train.batch(order[s:s + 32]), dev) for s i
 b = pipeline.DeviceBatch(nb, dev)
 print(f"setup {time.time() - t0:.1f} s, codebook {cb['words'].shape}", flush=True)
 ref = None
-names = ["grid", "lrf", "shot352", "knn", "knn_l2_mfma", "knn_fallback", "cast_votes", "maxima"]
+names = ["grid", "lrf", "shot352", "knn", "knn_l2_mfma", "knn_stage2", "knn_fallback", "cast_votes", "maxima"]
 for v in args.variants:
     keys = []
     for kv in v.split():
@@ -51,7 +51,7 @@ for v in args.variants:
         ref = (cls, score)
     same = bool((cls == ref[0]).all()) and float(np.abs(score - ref[1]).max()) < 1e-5
     print(f"[{v or 'default'}] wall {wall:.2f} ms/{args.objects} obj | " + " ".join(f"{n} {tm[n][0] / max(1, tm[n][1]):.3f}" for n in names) +
-          f" | fallback queries {fb} | same result {same}", flush=True)
+          f" | stage-2 queries {int(ctx.timer('knn_stage2_queries')[0])} fallback queries {fb} | same result {same}", flush=True)
     ctx.timers_enable(False)
     rec.codebook.close(); ctx.close()
     for k in keys:
