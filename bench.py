@@ -106,6 +106,18 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def plan_shard(n_objects, rank, world, batch):
+    """Strong scaling: the fixed split of n_objects is cut into contiguous per-rank blocks (shard_range of shard.py: rank r owns
+    [r*ceil(n/R), (r+1)*ceil(n/R))), and a rank's block into launches of at most `batch` objects of (almost) equal size.
+    Returns (lo, hi, records per rank in the all-gather, launch boundaries)."""
+    per = (n_objects + world - 1) // world
+    lo = min(n_objects, rank * per)
+    hi = min(n_objects, lo + per)
+    n_chunks = max(1, -(-(hi - lo) // batch))
+    bounds = [lo + (hi - lo) * j // n_chunks for j in range(n_chunks + 1)]
+    return lo, hi, per, bounds
+
+
 def latest_traffic_json():
     """beyond-L2 bytes per launch from the newest committed PMC pass of this very command (profiles/round*_pmc_traffic.json)"""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))
@@ -173,12 +185,10 @@ def main():
 
     # ---- inputs: this rank's shard of the fixed test split, resident in HBM before the clock starts
     test = synthetic.Dataset(C, G, split=1, n_points=n_points, **ds_kw)
-    lo, hi = shard.shard_range(G, rank, world)
-    pad = shard.shard_range(G, 0, world)[1]                  # records per rank in the all-gather (largest shard)
-    n_chunks = max(1, -(-(hi - lo) // args.batch))
-    bounds = [lo + (hi - lo) * j // n_chunks for j in range(n_chunks + 1)]
+    lo, hi, pad, bounds = plan_shard(G, rank, world, args.batch)
+    assert (lo, hi) == shard.shard_range(G, rank, world)
     chunks_h, chunks, chunk_ids = [], [], []
-    for j in range(n_chunks):
+    for j in range(len(bounds) - 1):
         ids = list(range(bounds[j], bounds[j + 1]))
         if not ids:
             continue

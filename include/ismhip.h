@@ -226,6 +226,49 @@ int  ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* slot_offsets
                         float* max_bbox_size_out /* may be NULL */, int32_t* max_n_votes_out,
                         float* class_score_out);
 
+/* ---- training: Codebook::activate (codebook/codebook.cpp:64-368) with one codeword per training feature (clustering_none.cpp:25-35):
+ *      exact kNN activation of every feature in the codebook of all features, class sigma^2 (:94-193), K = 1 clean-up (:201-224),
+ *      vote = rotateInto(centre - keypoint, LRF) (codeword_distribution.cpp:37-71), CodewordDistribution::computeWeights
+ *      (:169-243) and the statistical class weights term1 * term2 * term3 (:226-368, including m_term3 being keyed by class only).
+ *      desc / lrf9 / kp* are device arrays of the n training features in CLASS-MAJOR order (classes ascending, models and
+ *      features in the order the reference iterates them); feat_*_h are host arrays ([n], centre [n*3] = the model's bounding-box
+ *      centre). Outputs are HOST arrays: word_src_out[n] (training feature of every kept codeword, ascending = codeword order),
+ *      vote_offsets_out[n+1] (CSR), vote_feature_out / vote_weight_out / vote_class_weight_out [n*k], vote_xyz_out[n*k*3],
+ *      class_sigma_out[n_classes]. The call synchronises. k <= 4. */
+int  ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim, const float* desc, const float* lrf9,
+                           const float* kpx, const float* kpy, const float* kpz,
+                           const uint32_t* feat_class_h, const uint32_t* feat_model_h, const float* feat_center_h,
+                           int k, int clean_up_single_vote, int n_classes,
+                           int32_t* n_words_out, uint32_t* word_src_out, uint32_t* vote_offsets_out, uint32_t* vote_feature_out,
+                           float* vote_xyz_out, float* vote_weight_out, float* vote_class_weight_out, float* class_sigma_out);
+
+/* ---- discrete Hough space: VotingHough3D::iFindMaxima (voting/voting_hough_3d.cpp:33-95) over pcl::recognition::HoughSpace3D
+ *      (bins ceil((max-min)/bin) per axis; trilinear voteInt; findMaxima(-RelThreshold): bins >= rel * max with no strictly
+ *      greater 26-neighbour, in ascending bin index) followed by the same Voting::findMaxima post-processing as
+ *      ismhip_find_maxima (same outputs). The reference makes the bins cubic: edge = 2 * MaximaHandler::getSearchDistForClass,
+ *      i.e. BinSize[0] for BinOrBandwidthType "Config" (voting_hough_3d.cpp:46-48). */
+typedef struct ismhip_hough_params {
+    int   n_classes;
+    float min_coord[3];             /* Voting.MinCoord */
+    float max_coord[3];             /* Voting.MaxCoord */
+    float bin_size;                 /* Voting.BinSize[0] */
+    const float* class_bin_h;       /* [n_classes] per-class bin edge; NULL -> bin_size for all */
+    int   use_interpolation;        /* Voting.UseInterpolation */
+    float rel_threshold;            /* Voting.RelThreshold */
+    int   min_votes_threshold;      /* Voting.MinVotesThreshold */
+    float min_threshold;            /* Voting.MinThreshold (negative = relative to best) */
+    int   best_k;                   /* Voting.BestK (<=0: all) */
+    int   max_maxima;               /* capacity of the output per object */
+} ismhip_hough_params;
+int  ismhip_hough3d_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* slot_offsets_h,
+                           const float* vote_pos, const float* vote_weight, const int32_t* vote_class,
+                           const int32_t* vote_instance, const float* vote_bbox_size /* may be NULL */,
+                           const ismhip_hough_params* params,
+                           int32_t* n_maxima_out, float* max_pos_out, float* max_weight_out,
+                           int32_t* max_class_out, int32_t* max_instance_out, float* max_instance_weight_out,
+                           float* max_bbox_size_out /* may be NULL */, int32_t* max_n_votes_out,
+                           float* class_score_out);
+
 #ifdef __cplusplus
 }
 #endif

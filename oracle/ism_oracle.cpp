@@ -694,6 +694,67 @@ struct Maximum {
     V3 pos; float weight; int cls; int inst; float inst_weight; V3 bbox; int n_votes;
 };
 
+
+// Voting::findMaxima per-maximum block (voting.cpp:131-236): instance id by the largest summed weight (ties and the map order
+// give the smallest id), weight = sum of the cluster's vote weights, weighted mean bounding-box size.
+void append_maximum(const std::vector<MSVote>& votes, const std::vector<V3>& vbbox, const std::vector<int>& cluster, const V3& pos, int c,
+                    int min_votes_threshold, std::vector<Maximum>& maxima) {
+    if (static_cast<int>(cluster.size()) < min_votes_threshold || cluster.empty()) return;
+    std::map<unsigned, float> instance_weights;
+    for (int vi : cluster) {
+        const float w = votes[vi].w; const unsigned id = static_cast<unsigned>(votes[vi].inst);
+        auto it = instance_weights.find(id);
+        if (it != instance_weights.end()) it->second += w; else instance_weights.insert({id, w});
+    }
+    unsigned max_id = 0; float best = 0; bool have = false;
+    for (auto& it : instance_weights) if (it.second > best) { best = it.second; max_id = it.first; have = true; }
+    Maximum m;
+    m.cls = c; m.inst = have ? static_cast<int>(max_id) : -1;
+    m.inst_weight = have ? instance_weights[max_id] : 0.f;
+    m.pos = pos; m.n_votes = static_cast<int>(cluster.size());
+    float maxWeight = 0; V3 bs = {0, 0, 0};
+    for (int vi : cluster) {
+        const float nw = votes[vi].w;
+        bs[0] += nw * vbbox[vi][0]; bs[1] += nw * vbbox[vi][1]; bs[2] += nw * vbbox[vi][2];
+        maxWeight += nw;
+    }
+    m.weight = maxWeight;
+    bs[0] /= maxWeight; bs[1] /= maxWeight; bs[2] /= maxWeight;
+    m.bbox = bs;
+    maxima.push_back(m);
+}
+
+// Voting::findMaxima tail (voting.cpp:272, 298-323, 441-462): sort, normalise, MinThreshold, BestK, outputs of one object
+void finish_object(std::vector<Maximum>& maxima, int o, int C, int cap, float min_threshold, int best_k,
+                   int32_t* n_max_out, float* mpos, float* mw, int32_t* mcls, int32_t* minst, float* miw, float* mbs, int32_t* mnv, float* class_score) {
+        // sort (stable; std::sort in the reference leaves equal weights unordered), voting.cpp:272
+        std::stable_sort(maxima.begin(), maxima.end(), [](const Maximum& a, const Maximum& b) { return a.weight > b.weight; });
+        // normalizeWeights :441-462
+        float sum = 0, sum_inst = 0;
+        for (auto& m : maxima) { sum += m.weight; sum_inst += m.inst_weight; }
+        for (auto& m : maxima) { m.weight = sum != 0 ? m.weight / sum : 0; m.inst_weight = sum_inst != 0 ? m.inst_weight / sum_inst : 0; }
+        float thr = min_threshold;
+        if (thr < 0) { float mxw = maxima.size() > 0 ? maxima.front().weight : 0.0f; thr = -thr * mxw; }   // :304-309
+        std::vector<Maximum> filtered;
+        for (auto& m : maxima) if (m.weight >= thr) filtered.push_back(m);
+        maxima.swap(filtered);
+        if (best_k > 0 && static_cast<int>(maxima.size()) >= best_k) maxima.resize(best_k);          // :322-323
+        const int nm = std::min(static_cast<int>(maxima.size()), cap);
+        n_max_out[o] = nm;
+        for (int c = 0; c < C; ++c) class_score[static_cast<size_t>(o) * C + c] = 0.f;
+        for (size_t i = 0; i < maxima.size(); ++i) {
+            float& cs = class_score[static_cast<size_t>(o) * C + maxima[i].cls];
+            if (maxima[i].weight > cs) cs = maxima[i].weight;
+        }
+        for (int i = 0; i < cap; ++i) {
+            const size_t t = static_cast<size_t>(o) * cap + i;
+            const bool ok = i < nm;
+            mpos[t * 3] = ok ? maxima[i].pos[0] : 0.f; mpos[t * 3 + 1] = ok ? maxima[i].pos[1] : 0.f; mpos[t * 3 + 2] = ok ? maxima[i].pos[2] : 0.f;
+            mw[t] = ok ? maxima[i].weight : 0.f; mcls[t] = ok ? maxima[i].cls : -1; minst[t] = ok ? maxima[i].inst : -1;
+            miw[t] = ok ? maxima[i].inst_weight : 0.f; mnv[t] = ok ? maxima[i].n_votes : 0;
+            if (mbs) { mbs[t * 3] = ok ? maxima[i].bbox[0] : 0.f; mbs[t * 3 + 1] = ok ? maxima[i].bbox[1] : 0.f; mbs[t * 3 + 2] = ok ? maxima[i].bbox[2] : 0.f; }
+        }
+}
 }  // namespace
 
 /* ============================== exported C functions ======================================= */
@@ -1050,59 +1111,113 @@ int ismref_find_maxima(int n_obj, const uint32_t* so, const float* vpos, const f
                 std::vector<int> cluster;
                 float density = estimate_density(votes, pos.data(), h, P->kernel, true, &cluster, nb);
                 (void)density;
-                // Voting::findMaxima per-maximum block, voting.cpp:131-236
-                if (static_cast<int>(cluster.size()) < P->min_votes_threshold || cluster.empty()) continue;
-                std::map<unsigned, float> instance_weights;
-                for (int vi : cluster) {
-                    const float w = votes[vi].w; const unsigned id = static_cast<unsigned>(votes[vi].inst);
-                    auto it = instance_weights.find(id);
-                    if (it != instance_weights.end()) it->second += w; else instance_weights.insert({id, w});
-                }
-                unsigned max_id = 0; float best = 0; bool have = false;
-                for (auto& it : instance_weights) if (it.second > best) { best = it.second; max_id = it.first; have = true; }
-                Maximum m;
-                m.cls = c; m.inst = have ? static_cast<int>(max_id) : -1;
-                m.inst_weight = have ? instance_weights[max_id] : 0.f;
-                m.pos = pos; m.n_votes = static_cast<int>(cluster.size());
-                float maxWeight = 0; V3 bs = {0, 0, 0};
-                for (int vi : cluster) {
-                    const float nw = votes[vi].w;
-                    bs[0] += nw * vbbox[vi][0]; bs[1] += nw * vbbox[vi][1]; bs[2] += nw * vbbox[vi][2];
-                    maxWeight += nw;
-                }
-                m.weight = maxWeight;
-                bs[0] /= maxWeight; bs[1] /= maxWeight; bs[2] /= maxWeight;
-                m.bbox = bs;
-                maxima.push_back(m);
+                append_maximum(votes, vbbox, cluster, pos, c, P->min_votes_threshold, maxima);
             }
         }
-        // sort (stable; std::sort in the reference leaves equal weights unordered), voting.cpp:272
-        std::stable_sort(maxima.begin(), maxima.end(), [](const Maximum& a, const Maximum& b) { return a.weight > b.weight; });
-        // normalizeWeights :441-462
-        float sum = 0, sum_inst = 0;
-        for (auto& m : maxima) { sum += m.weight; sum_inst += m.inst_weight; }
-        for (auto& m : maxima) { m.weight = sum != 0 ? m.weight / sum : 0; m.inst_weight = sum_inst != 0 ? m.inst_weight / sum_inst : 0; }
-        float thr = P->min_threshold;
-        if (thr < 0) { float mxw = maxima.size() > 0 ? maxima.front().weight : 0.0f; thr = -thr * mxw; }   // :304-309
-        std::vector<Maximum> filtered;
-        for (auto& m : maxima) if (m.weight >= thr) filtered.push_back(m);
-        maxima.swap(filtered);
-        if (P->best_k > 0 && static_cast<int>(maxima.size()) >= P->best_k) maxima.resize(P->best_k);          // :322-323
-        const int nm = std::min(static_cast<int>(maxima.size()), cap);
-        n_max_out[o] = nm;
-        for (int c = 0; c < C; ++c) class_score[static_cast<size_t>(o) * C + c] = 0.f;
-        for (size_t i = 0; i < maxima.size(); ++i) {
-            float& cs = class_score[static_cast<size_t>(o) * C + maxima[i].cls];
-            if (maxima[i].weight > cs) cs = maxima[i].weight;
+        finish_object(maxima, o, C, cap, P->min_threshold, P->best_k, n_max_out, mpos, mw, mcls, minst, miw, mbs, mnv, class_score);
+    }
+    return 0;
+}
+
+/* Voting::findMaxima + VotingHough3D::iFindMaxima (ref: voting/voting_hough_3d.cpp:33-95) over pcl::recognition::HoughSpace3D
+ * (EXTERNAL, PCL 1.10 recognition/cg/hough_3d; restated from SURVEY Appendix A.7 -- parity unpinned):
+ *   bins: ceil((max - min) / bin) per axis, index = x + nx (y + ny z); accumulator in double
+ *   vote   : the bin of floor((p - min) / bin); a vote outside the space is dropped
+ *   voteInt: central bin c; per axis the central weight wc = 1 - |p - min - centre| / bin (centre = (2 c bin + bin) / 2, float)
+ *            and the neighbour on the vote's side with 1 - wc; the (up to) 8 bins get weight * product, bins with product 0 or
+ *            outside the space get nothing; every bin remembers its voters in vote order
+ *   findMaxima(-rel): threshold = rel * max(H) (rel > 1: max(H)); a bin >= threshold with no STRICTLY greater 26-neighbour is a
+ *            maximum; maxima in ascending bin index
+ * then per maximum: position = sum(pos * w) / sum(w) over its voters (float, vote order) and the Voting::findMaxima block.
+ * The reference makes the bins cubic with edge 2 * MaximaHandler::getSearchDistForClass(class) (= BinSize[0] for "Config"). */
+int ismref_hough3d_maxima(int n_obj, const uint32_t* so, const float* vpos, const float* vw, const int32_t* vcls,
+                          const int32_t* vinst, const float* vbs, const ismref_hough_params* P,
+                          int32_t* n_max_out, float* mpos, float* mw, int32_t* mcls, int32_t* minst, float* miw,
+                          float* mbs, int32_t* mnv, float* class_score) {
+    const int C = P->n_classes, cap = P->max_maxima;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int o = 0; o < n_obj; ++o) {
+        std::vector<Maximum> maxima;
+        for (int c = 0; c < C; ++c) {
+            std::vector<MSVote> votes;
+            std::vector<V3> vbbox;
+            for (uint32_t s = so[o]; s < so[o + 1]; ++s) {
+                if (vcls[s] != c) continue;
+                MSVote v; v.p[0] = vpos[s * 3]; v.p[1] = vpos[s * 3 + 1]; v.p[2] = vpos[s * 3 + 2];
+                v.w = vw[s]; v.inst = vinst[s]; v.slot = static_cast<int>(s);
+                votes.push_back(v);
+                vbbox.push_back(vbs ? V3{vbs[s * 3], vbs[s * 3 + 1], vbs[s * 3 + 2]} : V3{0, 0, 0});
+            }
+            if (votes.empty()) continue;            // class not present in m_votes
+            const double bin = static_cast<double>(P->class_bin ? P->class_bin[c] : P->bin_size);
+            long long cnt[3], total = 1;
+            for (int d = 0; d < 3; ++d) {
+                cnt[d] = static_cast<long long>(std::ceil((static_cast<double>(P->max_coord[d]) - static_cast<double>(P->min_coord[d])) / bin));
+                if (cnt[d] < 0) cnt[d] = 0;
+                total *= cnt[d];
+            }
+            if (total <= 0) continue;
+            // the space is sparse: (bin index -> value, voters); neighbours that were never voted for hold 0
+            std::map<long long, std::pair<double, std::vector<int>>> H;
+            for (size_t i = 0; i < votes.size(); ++i) {
+                long long cc[3]; double diff[3]; float wc[3]; bool in = true;
+                for (int d = 0; d < 3; ++d) {
+                    const double rel = static_cast<double>(votes[i].p[d]) - static_cast<double>(P->min_coord[d]);
+                    cc[d] = static_cast<long long>(std::floor(rel / bin));
+                    if (cc[d] >= cnt[d] || cc[d] < 0) { in = false; break; }
+                    const float centre = static_cast<float>((2.0 * static_cast<double>(cc[d]) * bin + bin) / 2.0);
+                    diff[d] = rel - static_cast<double>(centre);
+                    wc[d] = static_cast<float>(1.0 - std::fabs(diff[d]) / bin);
+                }
+                if (!in) continue;
+                if (!P->use_interpolation) {
+                    auto& e = H[cc[0] + cnt[0] * (cc[1] + cnt[1] * cc[2])];
+                    e.first += static_cast<double>(votes[i].w); e.second.push_back(static_cast<int>(i));
+                    continue;
+                }
+                for (int n = 0; n < 27; ++n) {
+                    const int nb[3] = {n % 3 - 1, (n / 3) % 3 - 1, n / 9 - 1};
+                    float iw = 1.0f; bool ok = true; long long idx = 0, stride = 1;
+                    for (int d = 0; d < 3 && ok; ++d) {
+                        const long long b = cc[d] + nb[d];
+                        if (b < 0 || b >= cnt[d]) { ok = false; break; }
+                        if (nb[d] == 0) iw *= wc[d];
+                        else if ((diff[d] < 0 ? -1 : 1) == nb[d]) iw *= 1.0f - wc[d];
+                        else ok = false;
+                        idx += b * stride; stride *= cnt[d];
+                    }
+                    if (!ok || !(iw > 0.0f)) continue;
+                    auto& e = H[idx];
+                    e.first += static_cast<double>(votes[i].w) * static_cast<double>(iw); e.second.push_back(static_cast<int>(i));
+                }
+            }
+            double hmax = std::numeric_limits<double>::min();
+            for (auto& kv : H) if (kv.second.first > hmax) hmax = kv.second.first;
+            const double rel = static_cast<double>(P->rel_threshold);
+            const double thr = rel <= 1.0 ? rel * hmax : hmax;
+            for (auto& kv : H) {                                   // std::map: ascending bin index
+                const double v = kv.second.first;
+                if (v < thr) continue;
+                const long long i0 = kv.first % cnt[0], i1 = (kv.first / cnt[0]) % cnt[1], i2 = kv.first / (cnt[0] * cnt[1]);
+                bool is_max = true;
+                for (int n = 0; n < 27 && is_max; ++n) {
+                    if (n == 13) continue;
+                    const long long b0 = i0 + n % 3 - 1, b1 = i1 + (n / 3) % 3 - 1, b2 = i2 + n / 9 - 1;
+                    if (b0 < 0 || b0 >= cnt[0] || b1 < 0 || b1 >= cnt[1] || b2 < 0 || b2 >= cnt[2]) continue;
+                    auto it = H.find(b0 + cnt[0] * (b1 + cnt[1] * b2));
+                    if (it != H.end() && it->second.first > v) is_max = false;
+                }
+                if (!is_max) continue;
+                // voting_hough_3d.cpp:70-93: weighted cluster centre of the bin's voters
+                float cx = 0, cy = 0, cz = 0, wsum = 0;
+                for (int vi : kv.second.second) {
+                    cx += votes[vi].p[0] * votes[vi].w; cy += votes[vi].p[1] * votes[vi].w; cz += votes[vi].p[2] * votes[vi].w;
+                    wsum += votes[vi].w;
+                }
+                append_maximum(votes, vbbox, kv.second.second, V3{cx / wsum, cy / wsum, cz / wsum}, c, P->min_votes_threshold, maxima);
+            }
         }
-        for (int i = 0; i < cap; ++i) {
-            const size_t t = static_cast<size_t>(o) * cap + i;
-            const bool ok = i < nm;
-            mpos[t * 3] = ok ? maxima[i].pos[0] : 0.f; mpos[t * 3 + 1] = ok ? maxima[i].pos[1] : 0.f; mpos[t * 3 + 2] = ok ? maxima[i].pos[2] : 0.f;
-            mw[t] = ok ? maxima[i].weight : 0.f; mcls[t] = ok ? maxima[i].cls : -1; minst[t] = ok ? maxima[i].inst : -1;
-            miw[t] = ok ? maxima[i].inst_weight : 0.f; mnv[t] = ok ? maxima[i].n_votes : 0;
-            if (mbs) { mbs[t * 3] = ok ? maxima[i].bbox[0] : 0.f; mbs[t * 3 + 1] = ok ? maxima[i].bbox[1] : 0.f; mbs[t * 3 + 2] = ok ? maxima[i].bbox[2] : 0.f; }
-        }
+        finish_object(maxima, o, C, cap, P->min_threshold, P->best_k, n_max_out, mpos, mw, mcls, minst, miw, mbs, mnv, class_score);
     }
     return 0;
 }
@@ -1195,6 +1310,130 @@ int ismref_class_sigmas(int metric, int dim, int n_feat, const float* feats, con
         variance /= num - 1;
         sigma_out[c] = variance;
     }
+    return 0;
+}
+
+
+/* Codebook::activate (codebook/codebook.cpp:64-368) with one codeword per training feature (clustering_none.cpp:25-35):
+ *   step 1  every feature (classes ascending, models in order, features in order) activates its k nearest codewords (exact,
+ *           ties -> lowest row; KNNRule trains with k = 1); every activation appends a vote = rotateInto(centre - keypoint, LRF)
+ *           to the codeword's distribution (codeword_distribution.cpp:37-71); class sigma^2 = sample variance of the distances
+ *           between the first >= sqrt(n_c) features (whole models) and the first >= sqrt(n_c) activated codewords (:94-193)
+ *   clean-up (KNN with K = 1 only, :201-224): keep distributions with exactly one vote
+ *   step 2  CodewordDistribution::computeWeights (codeword_distribution.cpp:169-243): per vote the MEDIAN over the activating
+ *           features j of exp(-|keyPos_j + rotateBack(vote_i, LRF_j) - modelCentre_i|^2 / 0.25)
+ *   steps 3-9 statistical class weights term1[c] * term2[word] * term3[c]; m_term3 is keyed by class only, so the value of the
+ *           LAST distribution (largest codeword id) holding class c is the one every word uses (:325-339) -- reproduced.
+ * Outputs: kept codewords in ascending id (word_src = its training feature), votes as CSR (vote_feature = activating feature). */
+int ismref_activate(int metric, int dim, int n, const float* feats, const float* lrf9, const float* kx, const float* ky, const float* kz,
+                    const uint32_t* feat_class, const uint32_t* feat_model, const float* feat_center,
+                    int k, int clean_up, int n_classes,
+                    int32_t* n_words_out, uint32_t* word_src, uint32_t* vote_off, uint32_t* vote_feature, float* vote_xyz,
+                    float* vote_weight, float* vote_class_weight, float* class_sigma) {
+    if (n <= 0 || k <= 0) return -1;
+    // exact kNN of every feature in the codebook of all features
+    std::vector<int32_t> act(static_cast<size_t>(n) * k, -1);
+    std::vector<float> actd(static_cast<size_t>(n) * k, 0.f);
+    ismref_knn(metric, n, dim, feats, n, feats, k, act.data(), actd.data());
+    // iteration order of the reference: classes ascending, models as they come, features as they come
+    std::vector<int> order;
+    for (int c = 0; c < n_classes; ++c) for (int i = 0; i < n; ++i) if (static_cast<int>(feat_class[i]) == c) order.push_back(i);
+    std::vector<std::vector<int>> dist(n);                    // per codeword: activating features in activation order
+    for (int c = 0; c < n_classes; ++c) {
+        class_sigma[c] = std::nanf("");
+        std::vector<int> ids;
+        for (int i = 0; i < n; ++i) if (static_cast<int>(feat_class[i]) == c) ids.push_back(i);
+        if (ids.empty()) continue;
+        const int max_elements = static_cast<int>(std::sqrt(static_cast<double>(ids.size())));
+        std::vector<int> allFeat, allWords;
+        size_t i = 0;
+        while (i < ids.size()) {
+            size_t j = i;
+            while (j < ids.size() && feat_model[ids[j]] == feat_model[ids[i]]) {
+                std::vector<int> activated;
+                for (int t = 0; t < k; ++t) { const int w = act[static_cast<size_t>(ids[j]) * k + t]; if (w >= 0) activated.push_back(w); }
+                for (int w : activated) dist[w].push_back(ids[j]);
+                if (static_cast<int>(allWords.size()) < max_elements) allWords.insert(allWords.end(), activated.begin(), activated.end());
+                ++j;
+            }
+            if (static_cast<int>(allFeat.size()) < max_elements) for (size_t t = i; t < j; ++t) allFeat.push_back(ids[t]);
+            i = j;
+        }
+        float sum = 0; std::vector<float> ds;
+        for (int fi : allFeat) for (int w : allWords) {
+            const float d = dist_any(metric, feats + static_cast<size_t>(fi) * dim, feats + static_cast<size_t>(w) * dim, dim);
+            sum += d; ds.push_back(d);
+        }
+        const int num = static_cast<int>(allFeat.size() * allWords.size());
+        const float mean = sum / num;
+        float variance = 0;
+        for (float d : ds) { const float diff = d - mean; variance += diff * diff; }
+        variance /= num - 1;
+        class_sigma[c] = variance;
+    }
+    // clean-up + CSR in ascending codeword id
+    std::vector<int> kept;
+    for (int w = 0; w < n; ++w) { if (dist[w].empty()) continue; if (clean_up && dist[w].size() != 1) continue; kept.push_back(w); }
+    *n_words_out = static_cast<int32_t>(kept.size());
+    vote_off[0] = 0;
+    std::vector<int> vote_word;
+    size_t nv = 0;
+    for (size_t e = 0; e < kept.size(); ++e) {
+        const int w = kept[e];
+        word_src[e] = static_cast<uint32_t>(w);
+        for (int fi : dist[w]) {
+            float v[3] = {feat_center[fi * 3] - kx[fi], feat_center[fi * 3 + 1] - ky[fi], feat_center[fi * 3 + 2] - kz[fi]};
+            quat_rotate(rot_quaternion(lrf9 + static_cast<size_t>(fi) * 9), v);          // rotateInto
+            vote_xyz[nv * 3] = v[0]; vote_xyz[nv * 3 + 1] = v[1]; vote_xyz[nv * 3 + 2] = v[2];
+            vote_feature[nv] = static_cast<uint32_t>(fi);
+            vote_word.push_back(static_cast<int>(e));
+            ++nv;
+        }
+        vote_off[e + 1] = static_cast<uint32_t>(nv);
+    }
+    // step 2: computeWeights
+    const float sigma = 0.5f;
+    for (size_t e = 0; e < kept.size(); ++e) {
+        const uint32_t v0 = vote_off[e], v1 = vote_off[e + 1];
+        for (uint32_t vi = v0; vi < v1; ++vi) {
+            std::vector<float> list;
+            const int fi_i = static_cast<int>(vote_feature[vi]);
+            for (uint32_t vj = v0; vj < v1; ++vj) {
+                const int fj = static_cast<int>(vote_feature[vj]);
+                float r[3] = {vote_xyz[vi * 3], vote_xyz[vi * 3 + 1], vote_xyz[vi * 3 + 2]};
+                quat_rotate_inv(rot_quaternion(lrf9 + static_cast<size_t>(fj) * 9), r);  // rotateBack
+                const float cx = kx[fj] + r[0], cy = ky[fj] + r[1], cz = kz[fj] + r[2];
+                const float dx = cx - feat_center[fi_i * 3], dy = cy - feat_center[fi_i * 3 + 1], dz = cz - feat_center[fi_i * 3 + 2];
+                const float d = std::sqrt(dx * dx + dy * dy + dz * dz);
+                list.push_back(static_cast<float>(std::exp(static_cast<double>((-1 * (d * d)) / (sigma * sigma)))));
+            }
+            std::sort(list.begin(), list.end());
+            vote_weight[vi] = list.size() % 2 == 0 ? (list[list.size() / 2 - 1] + list[list.size() / 2]) / 2 : list[list.size() / 2];
+        }
+    }
+    // steps 3-9
+    std::vector<std::map<int, int>> votesForClass(n_classes);    // class -> (word -> votes)
+    std::vector<int> numFeatures(n_classes, 0);
+    for (size_t e = 0; e < kept.size(); ++e)
+        for (uint32_t vi = vote_off[e]; vi < vote_off[e + 1]; ++vi) { const int c = static_cast<int>(feat_class[vote_feature[vi]]); votesForClass[c][static_cast<int>(e)]++; numFeatures[c]++; }
+    std::map<int, float> sum;
+    for (int c = 0; c < n_classes; ++c)
+        for (auto& kv : votesForClass[c]) {
+            if (sum.find(kv.first) == sum.end()) sum[kv.first] = kv.second / static_cast<float>(numFeatures[c]);
+            else sum[kv.first] += kv.second / static_cast<float>(numFeatures[c]);
+        }
+    std::vector<float> term1(n_classes, 0.f), term3(n_classes, 0.f);
+    for (int c = 0; c < n_classes; ++c) if (!votesForClass[c].empty()) term1[c] = 1.0f / static_cast<float>(votesForClass[c].size());
+    for (size_t e = 0; e < kept.size(); ++e) {                   // ascending codeword id: later words overwrite term3[c]
+        std::vector<int> classes;
+        for (uint32_t vi = vote_off[e]; vi < vote_off[e + 1]; ++vi) { const int c = static_cast<int>(feat_class[vote_feature[vi]]); if (std::find(classes.begin(), classes.end(), c) == classes.end()) classes.push_back(c); }
+        for (int c : classes) term3[c] = (votesForClass[c][static_cast<int>(e)] / static_cast<float>(numFeatures[c])) / sum[static_cast<int>(e)];
+    }
+    for (size_t e = 0; e < kept.size(); ++e) {
+        const float term2 = 1.0f / static_cast<float>(vote_off[e + 1] - vote_off[e]);
+        for (uint32_t vi = vote_off[e]; vi < vote_off[e + 1]; ++vi) { const int c = static_cast<int>(feat_class[vote_feature[vi]]); vote_class_weight[vi] = term1[c] * term2 * term3[c]; }
+    }
+    (void)order;
     return 0;
 }
 

@@ -101,6 +101,29 @@ int  ismref_find_maxima(int n_obj, const uint32_t* slot_offsets,
                         int32_t* max_class_out, int32_t* max_instance_out, float* max_instance_weight_out,
                         float* max_bbox_size_out, int32_t* max_n_votes_out, float* class_score_out);
 
+/* VotingHough3D (voting/voting_hough_3d.cpp:33-95) over pcl::recognition::HoughSpace3D; same outputs as
+ * ismref_find_maxima. Layout identical to ismhip_hough_params. */
+typedef struct ismref_hough_params {
+    int   n_classes;
+    float min_coord[3];
+    float max_coord[3];
+    float bin_size;
+    const float* class_bin;          /* [n_classes] or NULL */
+    int   use_interpolation;
+    float rel_threshold;
+    int   min_votes_threshold;
+    float min_threshold;
+    int   best_k;
+    int   max_maxima;
+} ismref_hough_params;
+int  ismref_hough3d_maxima(int n_obj, const uint32_t* slot_offsets,
+                           const float* vote_pos, const float* vote_weight, const int32_t* vote_class,
+                           const int32_t* vote_instance, const float* vote_bbox_size,
+                           const ismref_hough_params* params,
+                           int32_t* n_maxima_out, float* max_pos_out, float* max_weight_out,
+                           int32_t* max_class_out, int32_t* max_instance_out, float* max_instance_weight_out,
+                           float* max_bbox_size_out, int32_t* max_n_votes_out, float* class_score_out);
+
 /* mean-shift building blocks exposed for known-answer tests (voting_mean_shift.cpp:431-481, 331-376) */
 int  ismref_create_seeds(int n, const float* pos, const float* w, float bin_size, int cap,
                          float* seed_pos_out, float* seed_w_out);
@@ -116,6 +139,15 @@ int  ismref_voxel_grid(int n, const float* x, const float* y, const float* z, co
 int  ismref_class_sigmas(int metric, int dim, int n_feat, const float* feats, const uint32_t* feat_class,
                          const uint32_t* feat_model, const int32_t* activated_word, int n_words, const float* words,
                          int n_classes, float* sigma_out);
+
+/* Codebook::activate (codebook/codebook.cpp:64-368) for one codeword per training feature: exact kNN activation, class sigma^2,
+ * K = 1 clean-up, vote CSR, CodewordDistribution::computeWeights, statistical class weights (term1 * term2 * term3).
+ * Capacities: word_src[n], vote_off[n+1], vote_feature / vote_weight / vote_class_weight [n*k], vote_xyz[n*k*3]. */
+int  ismref_activate(int metric, int dim, int n, const float* feats, const float* lrf9, const float* kx, const float* ky, const float* kz,
+                     const uint32_t* feat_class, const uint32_t* feat_model, const float* feat_center,
+                     int k, int clean_up, int n_classes,
+                     int32_t* n_words_out, uint32_t* word_src, uint32_t* vote_off, uint32_t* vote_feature, float* vote_xyz,
+                     float* vote_weight, float* vote_class_weight, float* class_sigma);
 
 #ifdef __cplusplus
 }

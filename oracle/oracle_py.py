@@ -239,6 +239,32 @@ def find_maxima(slot_offsets, votes, n_classes, bandwidth, threshold=1e-3, max_i
     return out
 
 
+class HoughParams(C.Structure):
+    _fields_ = [("n_classes", C.c_int), ("min_coord", C.c_float * 3), ("max_coord", C.c_float * 3), ("bin_size", C.c_float),
+                ("class_bin", C.c_void_p), ("use_interpolation", C.c_int), ("rel_threshold", C.c_float),
+                ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int), ("max_maxima", C.c_int)]
+
+
+def hough3d_maxima(slot_offsets, votes, n_classes, bin_size, min_coord=(-5, -5, -5), max_coord=(5, 5, 5), use_interpolation=True,
+                   rel_threshold=0.8, min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16, class_bin=None):
+    so = _u(slot_offsets)
+    n_obj = len(so) - 1
+    cb = _f(class_bin)
+    P = HoughParams(n_classes, (C.c_float * 3)(*min_coord), (C.c_float * 3)(*max_coord), bin_size, cb.ctypes.data if cb is not None else None,
+                    1 if use_interpolation else 0, rel_threshold, min_votes_threshold, min_threshold, best_k, max_maxima)
+    out = dict(n=np.empty(n_obj, np.int32), pos=np.empty((n_obj, max_maxima, 3), np.float32),
+               weight=np.empty((n_obj, max_maxima), np.float32), cls=np.empty((n_obj, max_maxima), np.int32),
+               inst=np.empty((n_obj, max_maxima), np.int32), inst_weight=np.empty((n_obj, max_maxima), np.float32),
+               bbox_size=np.empty((n_obj, max_maxima, 3), np.float32), n_votes=np.empty((n_obj, max_maxima), np.int32),
+               class_score=np.empty((n_obj, n_classes), np.float32))
+    pos, w, cls, inst = _f(votes["pos"]), _f(votes["weight"]), _i(votes["cls"]), _i(votes["inst"])
+    bs = _f(votes.get("bbox_size"))
+    lib().ismref_hough3d_maxima(C.c_int(n_obj), _p(so), _p(pos), _p(w), _p(cls), _p(inst), _p(bs), C.byref(P), _p(out["n"]), _p(out["pos"]),
+                                _p(out["weight"]), _p(out["cls"]), _p(out["inst"]), _p(out["inst_weight"]), _p(out["bbox_size"]),
+                                _p(out["n_votes"]), _p(out["class_score"]))
+    return out
+
+
 def create_seeds(pos, w, bin_size):
     pos, w = _f(pos), _f(w)
     n = len(w)
@@ -262,3 +288,22 @@ def class_sigmas(metric, feats, feat_class, feat_model, activated_word, words, n
     lib().ismref_class_sigmas(C.c_int(metric), C.c_int(feats.shape[1]), C.c_int(feats.shape[0]), _p(feats), _p(_u(feat_class)),
                               _p(_u(feat_model)), _p(_i(activated_word)), C.c_int(words.shape[0]), _p(words), C.c_int(n_classes), _p(out))
     return out
+
+
+def activate(metric, feats, lrf, kp, feat_class, feat_model, feat_center, k=1, clean_up=True, n_classes=None):
+    """Codebook::activate for one codeword per training feature -> dict(word_src, vote_offsets, vote_feature, vote_xyz, vote_weight,
+    vote_class_weight, class_sigma)"""
+    feats, lrf, kp, feat_center = _f(feats), _f(lrf), _f(kp), _f(feat_center)
+    n, dim = feats.shape
+    fc, fm = _u(feat_class), _u(feat_model)
+    C_ = int(n_classes if n_classes is not None else fc.max() + 1)
+    kx, ky, kz = (np.ascontiguousarray(kp[:, i]) for i in range(3))
+    nw = C.c_int32(0)
+    word_src = np.empty(n, np.uint32); vo = np.empty(n + 1, np.uint32); vf = np.empty(n * k, np.uint32)
+    vxyz = np.empty((n * k, 3), np.float32); vw = np.empty(n * k, np.float32); vcw = np.empty(n * k, np.float32); sig = np.empty(C_, np.float32)
+    rc = lib().ismref_activate(C.c_int(metric), C.c_int(dim), C.c_int(n), _p(feats), _p(lrf), _p(kx), _p(ky), _p(kz), _p(fc), _p(fm), _p(feat_center),
+                               C.c_int(k), C.c_int(1 if clean_up else 0), C.c_int(C_), C.byref(nw), _p(word_src), _p(vo), _p(vf), _p(vxyz), _p(vw), _p(vcw), _p(sig))
+    assert rc == 0
+    m = nw.value; nv = int(vo[m])
+    return dict(word_src=word_src[:m].copy(), vote_offsets=vo[:m + 1].copy(), vote_feature=vf[:nv].copy(), vote_xyz=vxyz[:nv].copy(),
+                vote_weight=vw[:nv].copy(), vote_class_weight=vcw[:nv].copy(), class_sigma=sig)

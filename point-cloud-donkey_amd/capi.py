@@ -25,7 +25,7 @@ EXPORTS = [
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
     "ismhip_compact_features", "ismhip_voxel_keypoints",
     "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word",
-    "ismhip_knn", "ismhip_knn_ratio", "ismhip_knn_rule", "ismhip_cast_votes", "ismhip_find_maxima",
+    "ismhip_knn", "ismhip_knn_ratio", "ismhip_knn_rule", "ismhip_cast_votes", "ismhip_find_maxima", "ismhip_hough3d_maxima", "ismhip_train_activate",
 ]
 
 
@@ -34,6 +34,12 @@ class MaximaParams(C.Structure):
                 ("threshold", C.c_float), ("max_iter", C.c_int), ("kernel", C.c_int), ("suppression", C.c_int),
                 ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int),
                 ("max_maxima", C.c_int)]
+
+
+class HoughParams(C.Structure):
+    _fields_ = [("n_classes", C.c_int), ("min_coord", C.c_float * 3), ("max_coord", C.c_float * 3), ("bin_size", C.c_float),
+                ("class_bin_h", C.c_void_p), ("use_interpolation", C.c_int), ("rel_threshold", C.c_float),
+                ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int), ("max_maxima", C.c_int)]
 
 
 class IsmHipError(RuntimeError):
@@ -359,3 +365,48 @@ def find_maxima(ctx, slot_offsets, votes, n_classes, bandwidth, threshold=1e-3, 
                                        _p(out["weight"]), _p(out["cls"]), _p(out["inst"]), _p(out["inst_weight"]), _p(out["bbox_size"]),
                                        _p(out["n_votes"]), _p(out["class_score"])), "ismhip_find_maxima")
     return out
+
+
+def hough3d_maxima(ctx, slot_offsets, votes, n_classes, bin_size, min_coord=(-5, -5, -5), max_coord=(5, 5, 5), use_interpolation=True,
+                   rel_threshold=0.8, min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16, class_bin=None):
+    """VotingHough3D on the device: same outputs as find_maxima"""
+    torch = _torch()
+    so = _u32(slot_offsets)
+    n_obj = len(so) - 1
+    dev = votes["pos"].device
+    cb = None if class_bin is None else np.ascontiguousarray(np.asarray(class_bin, dtype=np.float32))
+    P = HoughParams(n_classes, (C.c_float * 3)(*min_coord), (C.c_float * 3)(*max_coord), bin_size, cb.ctypes.data if cb is not None else None,
+                    1 if use_interpolation else 0, rel_threshold, min_votes_threshold, min_threshold, best_k, max_maxima)
+    out = dict(
+        n=torch.empty((n_obj,), dtype=torch.int32, device=dev),
+        pos=torch.empty((n_obj, max_maxima, 3), dtype=torch.float32, device=dev),
+        weight=torch.empty((n_obj, max_maxima), dtype=torch.float32, device=dev),
+        cls=torch.empty((n_obj, max_maxima), dtype=torch.int32, device=dev),
+        inst=torch.empty((n_obj, max_maxima), dtype=torch.int32, device=dev),
+        inst_weight=torch.empty((n_obj, max_maxima), dtype=torch.float32, device=dev),
+        bbox_size=torch.empty((n_obj, max_maxima, 3), dtype=torch.float32, device=dev),
+        n_votes=torch.empty((n_obj, max_maxima), dtype=torch.int32, device=dev),
+        class_score=torch.empty((n_obj, n_classes), dtype=torch.float32, device=dev),
+    )
+    ctx.check(lib().ismhip_hough3d_maxima(ctx._h, C.c_int(n_obj), _p(so), _p(votes["pos"]), _p(votes["weight"]), _p(votes["cls"]),
+                                          _p(votes["inst"]), _p(votes.get("bbox_size")), C.byref(P), _p(out["n"]), _p(out["pos"]),
+                                          _p(out["weight"]), _p(out["cls"]), _p(out["inst"]), _p(out["inst_weight"]), _p(out["bbox_size"]),
+                                          _p(out["n_votes"]), _p(out["class_score"])), "ismhip_hough3d_maxima")
+    return out
+
+
+def train_activate(ctx, metric, desc, lrf, kx, ky, kz, feat_class, feat_model, feat_center, k=1, clean_up=True, n_classes=None):
+    """Codebook::activate on the device (features class-major) -> dict of host arrays (word_src, vote_offsets, vote_feature, vote_xyz, vote_weight, vote_class_weight, class_sigma)"""
+    n, dim = desc.shape
+    fc, fm = _u32(feat_class), _u32(feat_model)
+    ctr = np.ascontiguousarray(np.asarray(feat_center, dtype=np.float32))
+    C_ = int(n_classes if n_classes is not None else fc.max() + 1)
+    nw = C.c_int32(0)
+    word_src = np.empty(n, np.uint32); vo = np.empty(n + 1, np.uint32); vf = np.empty(n * k, np.uint32)
+    vxyz = np.empty((n * k, 3), np.float32); vw = np.empty(n * k, np.float32); vcw = np.empty(n * k, np.float32); sig = np.empty(C_, np.float32)
+    ctx.check(lib().ismhip_train_activate(ctx._h, C.c_int(metric), C.c_int(n), C.c_int(dim), _p(desc), _p(lrf), _p(kx), _p(ky), _p(kz), _p(fc), _p(fm),
+                                          _p(ctr), C.c_int(k), C.c_int(1 if clean_up else 0), C.c_int(C_), C.byref(nw), _p(word_src), _p(vo), _p(vf),
+                                          _p(vxyz), _p(vw), _p(vcw), _p(sig)), "ismhip_train_activate")
+    m = nw.value; nv = int(vo[m])
+    return dict(word_src=word_src[:m].copy(), vote_offsets=vo[:m + 1].copy(), vote_feature=vf[:nv].copy(), vote_xyz=vxyz[:nv].copy(),
+                vote_weight=vw[:nv].copy(), vote_class_weight=vcw[:nv].copy(), class_sigma=sig)

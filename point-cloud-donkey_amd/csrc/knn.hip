@@ -1052,38 +1052,7 @@ __device__ __forceinline__ float knn_abs_err(const VerifyParams& vp, float qn2) 
 }
 #define KNN_U 5.9604645e-08f
 
-// The FLANN functors evaluated by a whole wave, bit-identical to the scalar loops above. L2: the functor adds one 4-element
-// group sum ((d0^2 + d1^2) + d2^2) + d3^2 per step to the running result; the group sums are independent, so the lanes compute
-// them from coalesced 16-byte loads and only the chain of additions (dim/4 of them, from LDS) stays sequential. chi2: the
-// per-element terms are independent, the chain adds them one by one (a skipped term adds +0, which leaves the result unchanged).
-// Every lane returns the distance. sT: per-wave scratch of dim floats.
-__device__ __forceinline__ float wave_functor(int metric, const float* __restrict__ a, const float* __restrict__ b, int dim, int lane, float* sT) {
-    const int n4 = dim >> 2;
-    int n_terms;
-    if (metric == ISMHIP_METRIC_CHI2) {
-        for (int i = lane; i < dim; i += 64) {
-            const float x = a[i], y = b[i], sum = x + y, diff = x - y;
-            sT[i] = sum > 0 ? diff * diff / sum : 0.f;
-        }
-        n_terms = dim;
-    } else {
-        for (int g = lane; g < n4; g += 64) {
-            const f32x4 x = *(const f32x4*)(a + 4 * g), y = *(const f32x4*)(b + 4 * g);
-            const float d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2], d3 = x[3] - y[3];
-            sT[g] = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        }
-        for (int i = 4 * n4 + lane; i < dim; i += 64) { const float d0 = a[i] - b[i]; sT[n4 + (i - 4 * n4)] = d0 * d0; }
-        n_terms = n4 + (dim - 4 * n4);
-    }
-    float result = 0.f;                      // LDS traffic of one wave is ordered: the stores above are visible to the loads below
-    int i = 0;
-    for (; i + 3 < n_terms; i += 4) {
-        const f32x4 v = *(const f32x4*)(sT + i);
-        result += v[0]; result += v[1]; result += v[2]; result += v[3];
-    }
-    for (; i < n_terms; ++i) result += sT[i];
-    return result;
-}
+#include "functor.h"
 
 __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ words, int dim, int dim_pad, int n_words,
                                                     const float* __restrict__ q, int nq, int ldq, int metric,
@@ -1255,7 +1224,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
                 const int rr = __shfl(r, src, 64);
                 const float d = wave_functor(metric, qp, words + (size_t)rr * dim_pad, dim, lane, s_terms[threadIdx.x >> 6]);
                 unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)rr;
-                if (d != d) key = ~0ull - 1;                                        // NaN sorts last but stays a valid row
+                if (d != d) key = (0x7fc00000ull << 32) | (unsigned)rr;             // NaN sorts after every finite distance and keeps ITS row
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (j < k && key < best[j]) { const unsigned long long tmp = best[j]; best[j] = key; key = tmp; }
                 if (best[k - 1] != ~0ull) thr = fminf(thr, __uint_as_float((unsigned)(best[k - 1] >> 32)));
@@ -1457,10 +1426,10 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 }
 #endif
                 const size_t rlds = (size_t)RG_STAGES * RG_STAGE_HALVES * sizeof(u16) + 4 * RG_BM * sizeof(float) + 8 * 4 * 64 * sizeof(float);
-                static bool rattr_a[2] = {false, false};
-                bool& rattr = rattr_a[ring16 ? 1 : 0];
-                if (ctx->knn_dbg) rattr = false;
-                if (!rattr) { ISM_HIP(ctx, hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds)); rattr = true; }
+                if (ctx->knn_dbg || !ctx->attr_done.count(rk)) {          // per device, so remembered per ctx
+                    ISM_HIP(ctx, hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+                    ctx->attr_done.insert(rk);
+                }
                 const float* osc = (const float*)(qsc + 1);
                 float* cn_scaled = (float*)ism_scratch(ctx, SCR_QNORM2, (size_t)cb->n_words_pad * sizeof(float));
                 if (!cn_scaled) return ISMHIP_ERR_NOMEM;
@@ -1473,8 +1442,8 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 ISM_HIP(ctx, hipLaunchKernel(rk, grid, dim3(512), rargs, rlds, ctx->stream));
                 ISM_CHECK_LAUNCH(ctx, "k_knn_l2_ring");
             } else {
-            static bool attr[6] = {false, false, false, false, false, false};
-            if (!attr[ai]) { ISM_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr[ai] = true; }
+            (void)ai;
+            if (!ctx->attr_done.count(kern)) { ISM_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ctx->attr_done.insert(kern); }
             const float* word_norm = cb->word_norm; const float* osc = (const float*)(qsc + 1);
             int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
             const u16* qh_ = q_hi; const u16* ql_ = q_lo;

@@ -10,6 +10,7 @@
 // run on one lane exactly as the reference's loops do. Votes of a class are taken in slot order.
 // Not built (as in the oracle): RANSAC vote filter, global features, single-object max types, quaternion averaging.
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -373,6 +374,259 @@ __global__ __launch_bounds__(64) void k_finalize_maxima(MaxArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Discrete Hough space: VotingHough3D::iFindMaxima (voting/voting_hough_3d.cpp:33-95) over pcl::recognition::HoughSpace3D
+// (EXTERNAL, restated from SURVEY Appendix A.7 exactly as the oracle restates it).
+// One workgroup per (object, class) owns that class's whole accumulator, so the scatter is PRIVATE to the workgroup: the bins
+// the votes can reach (their bounding box in bin coordinates, +1 for the interpolation neighbours) are cut into tiles that fit
+// LDS, every tile is zeroed, filled with ds_add_u64 (2^-40 fixed point: the sum does not depend on the order of the votes,
+// where the reference's double accumulator does) and scanned for maxima in place. Nothing is shared between workgroups, so no
+// global atomics are needed; a vote set whose bounding box does not fit one tile simply takes more passes over the (few
+// hundred) votes, and one extra pass up front finds max(H) for the relative threshold.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define HG_FIX 1099511627776.0            /* 2^40 */
+struct HoughArgs {
+    const uint32_t* slot_off; const float* vpos; const float* vw; const int32_t* vcls; const int32_t* vinst; const float* vbs;
+    int n_classes; const float* class_bin; float bin; float minc[3], maxc[3]; int use_int; float rel; int min_votes, cap, tile_edge;
+    float* rec; int32_t* rec_count; int32_t* overflow;
+};
+struct HgBin { int c[3]; int dir[3]; float wc[3]; bool in; };
+__device__ __forceinline__ HgBin hg_bin(const HoughArgs& a, double bin, const int cnt[3], float px, float py, float pz) {
+    HgBin b; b.in = true;
+    const float p[3] = {px, py, pz};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double rel = (double)p[d] - (double)a.minc[d];
+        const double fl = floor(rel / bin);
+        if (!(fl >= 0.0 && fl < (double)cnt[d])) { b.in = false; b.c[d] = 0; b.dir[d] = 0; b.wc[d] = 0.f; continue; }
+        b.c[d] = (int)fl;
+        const float centre = (float)((2.0 * (double)b.c[d] * bin + bin) / 2.0);
+        const double diff = rel - (double)centre;
+        b.wc[d] = (float)(1.0 - fabs(diff) / bin);
+        b.dir[d] = diff < 0 ? -1 : 1;
+    }
+    return b;
+}
+
+__global__ __launch_bounds__(256) void k_hough3d(HoughArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int cap = a.cap;
+    float* vx = (float*)smem;               float* vy = vx + cap; float* vz = vy + cap; float* vw = vz + cap;
+    int* vinst = (int*)(vw + cap);          int* vslot = vinst + cap;
+    unsigned long long* hval = (unsigned long long*)(vslot + cap);      // instance tally (values)
+    int* hkey = (int*)(hval + cap);                                       // instance tally (keys)
+    unsigned char* member = (unsigned char*)(hkey + cap);
+    unsigned long long* tile = (unsigned long long*)(member + cap);     // tile_edge^3 bins
+    __shared__ int s_n, s_nmax, s_lo[3], s_hi[3], s_nm;
+    __shared__ int s_wcnt[4];
+    __shared__ float s_redf[4];
+    __shared__ int s_redi[4];
+    __shared__ int s_bi[4];
+    __shared__ unsigned long long s_bS[4], s_hmax;
+    __shared__ long long s_mbin[MX_MAXM_C];
+    const int o = blockIdx.x, c = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t s0 = a.slot_off[o], s1 = a.slot_off[o + 1];
+    const int C = a.n_classes;
+    float* rec = a.rec + ((size_t)o * C + c) * MX_MAXM_C * MX_REC;
+    if (tid == 0) { s_nmax = 0; s_n = 0; s_nm = 0; s_hmax = 0ull; a.rec_count[(size_t)o * C + c] = 0;
+                    for (int d = 0; d < 3; ++d) { s_lo[d] = 0x7fffffff; s_hi[d] = -1; } }
+    __syncthreads();
+    // ---- ordered compaction of the class's votes into LDS (as k_find_maxima)
+    for (uint32_t base = s0; base < s1; base += 256) {
+        const uint32_t s = base + tid;
+        const bool f = s < s1 && a.vcls[s] == c;
+        const unsigned long long mask = __ballot(f);
+        if (lane == 0) s_wcnt[wv] = __popcll(mask);
+        __syncthreads();
+        int off = s_n;
+        for (int k = 0; k < wv; ++k) off += s_wcnt[k];
+        if (f) {
+            const int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < cap) {
+                vx[pos] = a.vpos[(size_t)s * 3]; vy[pos] = a.vpos[(size_t)s * 3 + 1]; vz[pos] = a.vpos[(size_t)s * 3 + 2];
+                vw[pos] = a.vw[s]; vinst[pos] = a.vinst[s]; vslot[pos] = (int)s;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_n += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+    }
+    const int n = min(s_n, cap);
+    if (n == 0) return;                                       // class absent from m_votes (uniform across the block)
+    const double bin = (double)(a.class_bin ? a.class_bin[c] : a.bin);
+    int cnt[3];
+    for (int d = 0; d < 3; ++d) {
+        const double q = ceil(((double)a.maxc[d] - (double)a.minc[d]) / bin);
+        cnt[d] = q > 0.0 ? (q < 2.0e9 ? (int)q : 2000000000) : 0;
+    }
+    if (cnt[0] == 0 || cnt[1] == 0 || cnt[2] == 0) return;
+    // ---- bounding box of the reachable bins
+    for (int i = tid; i < n; i += 256) {
+        const HgBin b = hg_bin(a, bin, cnt, vx[i], vy[i], vz[i]);
+        if (!b.in) continue;
+        for (int d = 0; d < 3; ++d) { atomicMin(&s_lo[d], max(0, b.c[d] - 1)); atomicMax(&s_hi[d], min(cnt[d] - 1, b.c[d] + 1)); }
+    }
+    __syncthreads();
+    if (s_hi[0] < 0) return;                                  // every vote fell outside the space
+    const int E = a.tile_edge, EI = E - 2;                    // tile = interior EI^3 + a halo of one bin on every side
+    const int lo[3] = {s_lo[0], s_lo[1], s_lo[2]}, hi[3] = {s_hi[0], s_hi[1], s_hi[2]};
+    const int nt[3] = {(hi[0] - lo[0]) / EI + 1, (hi[1] - lo[1]) / EI + 1, (hi[2] - lo[2]) / EI + 1};
+    const int n_tiles = nt[0] * nt[1] * nt[2];
+    const int passes = a.rel > 0.f || true ? 2 : 1;          // pass 0: max(H); pass 1: maxima
+    unsigned long long thr_fix = 0ull;
+    for (int pass = 0; pass < passes; ++pass) {
+        for (int t = 0; t < n_tiles; ++t) {
+            // tile t covers interior bins [t0, t0 + EI) per axis, stored at local (b - t0 + 1)
+            const int t0[3] = {lo[0] + (t % nt[0]) * EI, lo[1] + ((t / nt[0]) % nt[1]) * EI, lo[2] + (t / (nt[0] * nt[1])) * EI};
+            for (int i = tid; i < E * E * E; i += 256) tile[i] = 0ull;
+            __syncthreads();
+            for (int i = tid; i < n; i += 256) {
+                const HgBin b = hg_bin(a, bin, cnt, vx[i], vy[i], vz[i]);
+                if (!b.in) continue;
+                const double w = (double)vw[i];
+                const int nn = a.use_int ? 8 : 1;
+                for (int q = 0; q < nn; ++q) {
+                    float iw = 1.0f; bool ok = true; int l[3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const int side = (q >> d) & 1;                 // 0: central bin, 1: the neighbour on the vote's side
+                        const int bb = b.c[d] + (side ? b.dir[d] : 0);
+                        if (bb < 0 || bb >= cnt[d]) ok = false;
+                        if (a.use_int) iw *= side ? 1.0f - b.wc[d] : b.wc[d];
+                        l[d] = bb - t0[d] + 1;
+                        if (l[d] < 0 || l[d] >= E) ok = false;
+                    }
+                    if (!ok || !(iw > 0.0f)) continue;
+                    const double contrib = a.use_int ? w * (double)iw : w;
+                    atomicAdd(&tile[(l[2] * E + l[1]) * E + l[0]], (unsigned long long)(contrib * HG_FIX + 0.5));
+                }
+            }
+            __syncthreads();
+            if (pass == 0) {
+                unsigned long long m = 0ull;
+                for (int i = tid; i < E * E * E; i += 256) m = tile[i] > m ? tile[i] : m;
+                m = wave_min_u64(~m); m = ~m;                             // wave max through the min helper
+                if (lane == 0) atomicMax(&s_hmax, m);
+            } else {
+                // interior bins >= threshold with no strictly greater 26-neighbour (halo bins are complete: every vote was scanned)
+                for (int i = tid; i < EI * EI * EI; i += 256) {
+                    const int lx = i % EI + 1, ly = (i / EI) % EI + 1, lz = i / (EI * EI) + 1;
+                    const int gx = t0[0] + lx - 1, gy = t0[1] + ly - 1, gz = t0[2] + lz - 1;
+                    if (gx > hi[0] || gy > hi[1] || gz > hi[2]) continue;
+                    const unsigned long long v = tile[(lz * E + ly) * E + lx];
+                    if (v < thr_fix || v == 0ull) continue;               // H = 0 bins have no voters: the reference drops them later (voting.cpp:131)
+                    bool is_max = true;
+                    for (int q = 0; q < 27 && is_max; ++q) {
+                        if (q == 13) continue;
+                        const int nx = lx + q % 3 - 1, ny = ly + (q / 3) % 3 - 1, nz = lz + q / 9 - 1;
+                        if (tile[(nz * E + ny) * E + nx] > v) is_max = false;
+                    }
+                    if (!is_max) continue;
+                    const int m = atomicAdd(&s_nm, 1);
+                    if (m < MX_MAXM_C) s_mbin[m] = (long long)gx + (long long)cnt[0] * ((long long)gy + (long long)cnt[1] * (long long)gz);
+                }
+            }
+            __syncthreads();
+        }
+        if (pass == 0) {
+            // findMaxima(-rel): threshold = rel * max(H), or max(H) itself when rel > 1; in fixed point, rounded down so that the
+            // bin holding the maximum always passes
+            const double hmax = (double)s_hmax / HG_FIX, rel = (double)a.rel;
+            const double thr = rel <= 1.0 ? rel * hmax : hmax;
+            thr_fix = (unsigned long long)(thr * HG_FIX);
+        }
+    }
+    int nm = s_nm;
+    if (nm > MX_MAXM_C) { if (tid == 0) atomicAdd(a.overflow, 1); nm = MX_MAXM_C; }
+    if (tid == 0)                                               // ascending bin index = the order findMaxima reports them in
+        for (int i = 1; i < nm; ++i) { const long long v = s_mbin[i]; int j = i - 1; while (j >= 0 && s_mbin[j] > v) { s_mbin[j + 1] = s_mbin[j]; --j; } s_mbin[j + 1] = v; }
+    __syncthreads();
+    // ---- per maximum: voters, weighted centre (voting_hough_3d.cpp:70-93) and the Voting::findMaxima block (voting.cpp:131-236)
+    for (int pi = 0; pi < nm; ++pi) {
+        const long long mb = s_mbin[pi];
+        const int mbx = (int)(mb % cnt[0]), mby = (int)((mb / cnt[0]) % cnt[1]), mbz = (int)(mb / ((long long)cnt[0] * cnt[1]));
+        int vcnt = 0; float sw = 0.f, px = 0.f, py = 0.f, pz = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        for (int i = tid; i < n; i += 256) {
+            const HgBin b = hg_bin(a, bin, cnt, vx[i], vy[i], vz[i]);
+            bool in = b.in;
+            const int mbc[3] = {mbx, mby, mbz};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (mbc[d] == b.c[d]) { if (a.use_int && !(b.wc[d] > 0.f)) in = false; }
+                else if (a.use_int && mbc[d] == b.c[d] + b.dir[d]) { if (!(1.0f - b.wc[d] > 0.f)) in = false; }
+                else in = false;
+            }
+            if (in && a.use_int) {                                        // the product of the three factors must itself be > 0
+                float iw = 1.0f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) iw *= mbc[d] == b.c[d] ? b.wc[d] : 1.0f - b.wc[d];
+                in = iw > 0.0f;
+            }
+            member[i] = in ? 1 : 0;
+            if (in) {
+                const float w = vw[i];
+                vcnt++; sw += w; px += vx[i] * w; py += vy[i] * w; pz += vz[i] * w;
+                if (a.vbs) { const size_t s = (size_t)vslot[i] * 3; b0 += w * a.vbs[s]; b1 += w * a.vbs[s + 1]; b2 += w * a.vbs[s + 2]; }
+            }
+        }
+        vcnt = block_sum_i(vcnt, s_redi);
+        if (vcnt < a.min_votes || vcnt == 0) continue;        // uniform across the block
+        sw = block_sum_f(sw, s_redf);
+        px = block_sum_f(px, s_redf); py = block_sum_f(py, s_redf); pz = block_sum_f(pz, s_redf);
+        b0 = block_sum_f(b0, s_redf); b1 = block_sum_f(b1, s_redf); b2 = block_sum_f(b2, s_redf);
+        __syncthreads();
+        // instance tally: as k_find_maxima (LDS hash, 2^-32 fixed point, ties -> smallest id, weights <= 0 never win)
+        const int HEMPTY = (int)0x80000000;
+        for (int i = tid; i < cap; i += 256) { hkey[i] = HEMPTY; hval[i] = 0ull; }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            if (!member[i]) continue;
+            const int id = vinst[i];
+            const float wv_ = vw[i];
+            const unsigned long long fx = wv_ > 0.f ? (unsigned long long)((double)wv_ * 4294967296.0) : 0ull;
+            unsigned slot = ((unsigned)id * 2654435761u) & (unsigned)(cap - 1);
+            for (int probe = 0; probe < cap; ++probe) {
+                const int old = atomicCAS(&hkey[slot], HEMPTY, id);
+                if (old == HEMPTY || old == id) { atomicAdd(&hval[slot], fx); break; }
+                slot = (slot + 1) & (unsigned)(cap - 1);
+            }
+        }
+        __syncthreads();
+        unsigned long long bS = 0ull; int bI = 0x7fffffff;
+        for (int i = tid; i < cap; i += 256) {
+            const int id = hkey[i];
+            if (id == HEMPTY) continue;
+            const unsigned long long S = hval[i];
+            if (S > bS || (S == bS && S > 0ull && (unsigned)id < (unsigned)bI)) { bS = S; bI = id; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long oS = __shfl_xor(bS, off, 64); const int oI = __shfl_xor(bI, off, 64);
+            if (oS > bS || (oS == bS && oS > 0ull && (unsigned)oI < (unsigned)bI)) { bS = oS; bI = oI; }
+        }
+        if (lane == 0) { s_bS[wv] = bS; s_bi[wv] = bI; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long fS = s_bS[0]; int bestI = s_bi[0];
+            for (int k = 1; k < 4; ++k)
+                if (s_bS[k] > fS || (s_bS[k] == fS && fS > 0ull && (unsigned)s_bi[k] < (unsigned)bestI)) { fS = s_bS[k]; bestI = s_bi[k]; }
+            const float bestS = (float)((double)fS * 2.3283064365386963e-10);
+            const int m = s_nmax;
+            if (m < MX_MAXM_C) {
+                float* r = rec + (size_t)m * MX_REC;
+                r[0] = px / sw; r[1] = py / sw; r[2] = pz / sw; r[3] = sw;
+                r[4] = __int_as_float(bestS > 0.f ? bestI : -1); r[5] = bestS > 0.f ? bestS : 0.f;
+                r[6] = b0 / sw; r[7] = b1 / sw; r[8] = b2 / sw; r[9] = __int_as_float(vcnt);
+                s_nmax = m + 1;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.rec_count[(size_t)o * C + c] = s_nmax;
+}
+
 }  // namespace
 
 uint32_t* ism_upload_offsets(ismhip_ctx* ctx, int slot, const uint32_t* off_h, int n);
@@ -413,10 +667,9 @@ extern "C" int ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* sl
     a.best_k = P->best_k; a.max_maxima = P->max_maxima; a.cap = cap;
     a.n_max = n_maxima_out; a.mpos = max_pos_out; a.mw = max_weight_out; a.mcls = max_class_out; a.minst = max_instance_out;
     a.miw = max_instance_weight_out; a.mbs = max_bbox_size_out; a.mnv = max_n_votes_out; a.class_score = class_score_out;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->attr_done.count((const void*)k_find_maxima)) {      // the attribute is per device: remembered per ctx, not per process
         ISM_HIP(ctx, hipFuncSetAttribute((const void*)k_find_maxima, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-        attr_set = true;
+        ctx->attr_done.insert((const void*)k_find_maxima);
     }
     const size_t n_oc = (size_t)n_obj * P->n_classes;
     a.rec = (float*)ism_scratch(ctx, SCR_MAX_REC, n_oc * MX_MAXM_C * MX_REC * sizeof(float) + n_oc * sizeof(int32_t));
@@ -425,6 +678,69 @@ extern "C" int ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* sl
     TimerScope ts(ctx, "maxima");
     hipLaunchKernelGGL(k_find_maxima, dim3(n_obj, P->n_classes), dim3(256), dyn, ctx->stream, a);
     ISM_CHECK_LAUNCH(ctx, "k_find_maxima");
+    hipLaunchKernelGGL(k_finalize_maxima, dim3(n_obj), dim3(64), 0, ctx->stream, a);
+    ISM_CHECK_LAUNCH(ctx, "k_finalize_maxima");
+    return ISMHIP_OK;
+}
+
+
+extern "C" int ismhip_hough3d_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* slot_offsets_h,
+                                     const float* vote_pos, const float* vote_weight, const int32_t* vote_class,
+                                     const int32_t* vote_instance, const float* vote_bbox_size,
+                                     const ismhip_hough_params* P,
+                                     int32_t* n_maxima_out, float* max_pos_out, float* max_weight_out,
+                                     int32_t* max_class_out, int32_t* max_instance_out, float* max_instance_weight_out,
+                                     float* max_bbox_size_out, int32_t* max_n_votes_out, float* class_score_out) {
+    if (!ctx || n_obj <= 0 || !slot_offsets_h || !vote_pos || !vote_weight || !vote_class || !vote_instance || !P ||
+        !n_maxima_out || !max_pos_out || !max_weight_out || !max_class_out || !max_instance_out || !max_instance_weight_out ||
+        !max_n_votes_out || !class_score_out || P->n_classes <= 0 || P->max_maxima <= 0 || !(P->bin_size > 0.f || P->class_bin_h))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "hough3d_maxima: bad argument");
+    if (P->n_classes > MX_MAXC) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "hough3d_maxima: more than 256 classes not built");
+    for (int d = 0; d < 3; ++d) if (!(P->max_coord[d] > P->min_coord[d])) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "hough3d_maxima: MaxCoord must exceed MinCoord");
+    if (P->class_bin_h) for (int c = 0; c < P->n_classes; ++c) if (!(P->class_bin_h[c] > 0.f)) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "hough3d_maxima: bin size");
+    uint32_t max_slots = 0;
+    for (int o = 0; o < n_obj; ++o) {
+        if (slot_offsets_h[o + 1] < slot_offsets_h[o]) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "hough3d_maxima: offsets not monotone");
+        max_slots = std::max(max_slots, slot_offsets_h[o + 1] - slot_offsets_h[o]);
+    }
+    int cap = 64; while ((uint32_t)cap < max_slots) cap <<= 1;
+    if (cap > 2048) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "hough3d_maxima: more than 2048 vote slots per object not built");
+    // LDS: 37 B per vote slot; the rest of ~150 KB holds the accumulator tile (edge 16 .. 24 bins including the halo)
+    const size_t vote_bytes = (size_t)cap * (4 * 4 + 2 * 4 + 8 + 4 + 1);
+    int edge = 24;
+    while (edge > 8 && ((vote_bytes + 15) / 16 * 16 + (size_t)edge * edge * edge * 8) > 150 * 1024) --edge;
+    const size_t dyn = (vote_bytes + 15) / 16 * 16 + (size_t)edge * edge * edge * 8 + 16;
+    uint32_t* so = ism_upload_offsets(ctx, SCR_SLOT_OFF, slot_offsets_h, n_obj + 1);
+    if (!so) return ISMHIP_ERR_HIP;
+    float* cbin = nullptr;
+    if (P->class_bin_h) {
+        cbin = (float*)ism_scratch(ctx, SCR_CLASS_BW, (size_t)P->n_classes * 4);
+        if (!cbin) return ISMHIP_ERR_NOMEM;
+        ISM_HIP(ctx, hipMemcpyAsync(cbin, P->class_bin_h, (size_t)P->n_classes * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const size_t n_oc = (size_t)n_obj * P->n_classes;
+    float* rec = (float*)ism_scratch(ctx, SCR_MAX_REC, n_oc * MX_MAXM_C * MX_REC * sizeof(float) + (n_oc + 1) * sizeof(int32_t));
+    if (!rec) return ISMHIP_ERR_NOMEM;
+    HoughArgs h;
+    h.slot_off = so; h.vpos = vote_pos; h.vw = vote_weight; h.vcls = vote_class; h.vinst = vote_instance; h.vbs = vote_bbox_size;
+    h.n_classes = P->n_classes; h.class_bin = cbin; h.bin = P->bin_size;
+    for (int d = 0; d < 3; ++d) { h.minc[d] = P->min_coord[d]; h.maxc[d] = P->max_coord[d]; }
+    h.use_int = P->use_interpolation ? 1 : 0; h.rel = P->rel_threshold; h.min_votes = P->min_votes_threshold; h.cap = cap; h.tile_edge = edge;
+    h.rec = rec; h.rec_count = (int32_t*)(rec + n_oc * MX_MAXM_C * MX_REC); h.overflow = h.rec_count + n_oc;
+    MaxArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_classes = P->n_classes; a.min_threshold = P->min_threshold; a.best_k = P->best_k; a.max_maxima = P->max_maxima;
+    a.n_max = n_maxima_out; a.mpos = max_pos_out; a.mw = max_weight_out; a.mcls = max_class_out; a.minst = max_instance_out;
+    a.miw = max_instance_weight_out; a.mbs = max_bbox_size_out; a.mnv = max_n_votes_out; a.class_score = class_score_out;
+    a.rec = h.rec; a.rec_count = h.rec_count;
+    if (!ctx->attr_done.count((const void*)k_hough3d)) {
+        ISM_HIP(ctx, hipFuncSetAttribute((const void*)k_hough3d, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        ctx->attr_done.insert((const void*)k_hough3d);
+    }
+    TimerScope ts(ctx, "hough3d");
+    ISM_HIP(ctx, hipMemsetAsync(h.overflow, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_hough3d, dim3(n_obj, P->n_classes), dim3(256), dyn, ctx->stream, h);
+    ISM_CHECK_LAUNCH(ctx, "k_hough3d");
     hipLaunchKernelGGL(k_finalize_maxima, dim3(n_obj), dim3(64), 0, ctx->stream, a);
     ISM_CHECK_LAUNCH(ctx, "k_finalize_maxima");
     return ISMHIP_OK;

@@ -356,6 +356,7 @@ void Codebook::upload(DeviceSession& s) const {
                                    d.vote_class_weight.empty() ? nullptr : d.vote_class_weight.data(), d.vote_class.data(), d.vote_instance.data(),
                                    d.vote_bbox_quat.empty() ? nullptr : d.vote_bbox_quat.data(), d.vote_bbox_size.empty() ? nullptr : d.vote_bbox_size.data(),
                                    (int)d.class_sigma.size(), d.class_sigma.data(), &m_dev), "ismhip_codebook_create");
+    if ((int)d.word_class.size() == d.numWords()) s.check(ismhip_codebook_set_word_class(s.ctx, m_dev, d.word_class.data()), "ismhip_codebook_set_word_class");
     m_dirty = false;
 }
 
@@ -403,88 +404,45 @@ void Codebook::activate(DeviceSession& s, const DeviceFeatures& f, const std::ve
     if (n == 0) throw RuntimeException("no training features");
     const ActivationStrategy* knn = m_activationStrategy.get();
     const bool is_knn = m_activationStrategy->getType() == "KNN";
-    const int k = is_knn ? knn->getK() : 1;                      // KNNRule trains with plain 1-NN
+    const int k = is_knn ? knn->getK() : 1;                      // KNNRule trains with plain 1-NN (activation_strategy_knn_rule.h:70-74)
     if (k > 4) throw RuntimeException("KNN activation with K > 4 is not built");
-    std::vector<float> words, lrf, kx, ky, kz;
-    s.d2h(words, f.desc, (size_t)n * D); s.d2h(lrf, f.lrf, (size_t)n * 9); s.d2h(kx, f.kx, n); s.d2h(ky, f.ky, n); s.d2h(kz, f.kz, n);
-    // step 1: every training feature activates its k nearest codewords (the codebook holds the feature itself)
-    CodebookData tmp; tmp.dim = D; tmp.words = words; tmp.vote_offsets.resize(n + 1);
-    std::iota(tmp.vote_offsets.begin(), tmp.vote_offsets.end(), 0u);
-    tmp.vote_xyz.assign((size_t)n * 3, 0.f); tmp.vote_class.assign(n, 0u); tmp.vote_instance.assign(n, 0u); tmp.class_sigma.assign(std::max(1, n_classes), 1.f);
-    ismhip_codebook* dev = nullptr;
-    s.check(ismhip_codebook_create(s.ctx, n, D, tmp.words.data(), nullptr, tmp.vote_offsets.data(), tmp.vote_xyz.data(), nullptr, nullptr, tmp.vote_class.data(),
-                                   tmp.vote_instance.data(), nullptr, nullptr, (int)tmp.class_sigma.size(), tmp.class_sigma.data(), &dev), "ismhip_codebook_create");
-    DevBuf didx, ddist;
-    didx.reserve((size_t)n * k * 4); ddist.reserve((size_t)n * k * 4);
-    knn->activateKNN(s, dev, f, metric, didx.as<int32_t>(), ddist.as<float>());
-    std::vector<int32_t> act;
-    s.d2h(act, didx, (size_t)n * k);
-    ismhip_codebook_destroy(s.ctx, dev);
-    // distributions: votes per codeword in activation order; vote = rotateInto(center - keyPos, LRF) (codeword_distribution.cpp:37-71)
-    std::vector<std::vector<uint32_t>> dist_feats(n);
-    for (uint32_t i = 0; i < n; ++i) for (int j = 0; j < k; ++j) { const int32_t w = act[(size_t)i * k + j]; if (w >= 0) dist_feats[w].push_back(i); }
-    // per-class sigma (codebook.cpp:94-193)
-    std::vector<float> sigma(n_classes, std::nanf(""));
-    for (int c = 0; c < n_classes; ++c) {
-        std::vector<uint32_t> ids;
-        for (uint32_t i = 0; i < n; ++i) if ((int)feat_class[i] == c) ids.push_back(i);
-        if (ids.empty()) continue;
-        const int max_elements = (int)std::sqrt((double)ids.size());
-        std::vector<uint32_t> allFeat; std::vector<int32_t> allWords;
-        size_t i = 0;
-        while (i < ids.size()) {
-            size_t j = i;
-            while (j < ids.size() && feat_model[ids[j]] == feat_model[ids[i]]) {
-                for (int t = 0; t < k; ++t) { const int32_t w = act[(size_t)ids[j] * k + t]; if ((int)allWords.size() < max_elements && w >= 0) allWords.push_back(w); }
-                ++j;
-            }
-            if ((int)allFeat.size() < max_elements) for (size_t t = i; t < j; ++t) allFeat.push_back(ids[t]);
-            i = j;
-        }
-        float sum = 0; std::vector<float> ds;
-        for (uint32_t fi : allFeat) for (int32_t w : allWords) { const float d = hostDistance(metric, &words[(size_t)fi * D], &words[(size_t)w * D], D); sum += d; ds.push_back(d); }
-        const int num = (int)ds.size();
-        const float mean = sum / num;
-        float variance = 0;
-        for (float d : ds) { const float diff = d - mean; variance += diff * diff; }
-        variance /= num - 1;
-        sigma[c] = variance;
-    }
-    // K = 1 clean-up: keep distributions with exactly one vote (codebook.cpp:201-224); otherwise every activated codeword stays
-    const bool clean_up = is_knn && k == 1;
-    CodebookData out; out.dim = D; out.class_sigma = sigma; out.vote_offsets.assign(1, 0u);
-    std::vector<uint32_t> kept;
-    for (uint32_t w = 0; w < n; ++w) {
-        if (dist_feats[w].empty()) continue;
-        if (clean_up && dist_feats[w].size() != 1) continue;
-        kept.push_back(w);
-    }
+    // the whole of Codebook::activate runs on the device (ismhip_train_activate): self-kNN, class sigma^2, K = 1 clean-up,
+    // vote CSR, computeWeights and the statistical class weights. Features must be class-major, as train() collects them.
+    std::vector<float> words, centers((size_t)n * 3);
+    s.d2h(words, f.desc, (size_t)n * D);
+    for (uint32_t i = 0; i < n; ++i) for (int d = 0; d < 3; ++d) centers[(size_t)i * 3 + d] = feat_center[i][d];
+    const bool clean_up = is_knn && k == 1;                     // codebook.cpp:201-224
+    int32_t n_words = 0;
+    std::vector<uint32_t> word_src(n), vote_off((size_t)n + 1), vote_feature((size_t)n * k);
+    std::vector<float> vote_xyz((size_t)n * k * 3), vote_weight((size_t)n * k), vote_cw((size_t)n * k), sigma((size_t)std::max(1, n_classes));
+    s.check(ismhip_train_activate(s.ctx, metric, (int)n, D, f.desc.as<float>(), f.lrf.as<float>(), f.kx.as<float>(), f.ky.as<float>(), f.kz.as<float>(),
+                                  feat_class.data(), feat_model.data(), centers.data(), k, clean_up ? 1 : 0, std::max(1, n_classes), &n_words, word_src.data(),
+                                  vote_off.data(), vote_feature.data(), vote_xyz.data(), vote_weight.data(), vote_cw.data(), sigma.data()), "ismhip_train_activate");
+    std::vector<uint32_t> kept(word_src.begin(), word_src.begin() + n_words);
+    std::vector<uint32_t> sel(kept.size());
+    std::iota(sel.begin(), sel.end(), 0u);
     if (m_use_random_codebook && m_random_codebook_factor < 1.0f) {   // codebook.cpp:821-829, seeded instead of std::random_device
         std::mt19937 rng(0x5EED);
         std::uniform_int_distribution<uint32_t> distr(0, (uint32_t)kept.size());
         std::vector<uint32_t> sub;
-        for (uint32_t w : kept) if (!(distr(rng) > m_random_codebook_factor * kept.size())) sub.push_back(w);
-        kept.swap(sub);
+        for (uint32_t e : sel) if (!(distr(rng) > m_random_codebook_factor * kept.size())) sub.push_back(e);
+        sel.swap(sub);
     }
-    std::vector<int> words_per_class(n_classes, 0);
-    for (uint32_t w : kept) { std::vector<char> seen(n_classes, 0); for (uint32_t fi : dist_feats[w]) if (!seen[feat_class[fi]]) { seen[feat_class[fi]] = 1; words_per_class[feat_class[fi]]++; } }
-    for (uint32_t w : kept) {
+    CodebookData out; out.dim = D; out.class_sigma = sigma; out.vote_offsets.assign(1, 0u);
+    for (uint32_t e : sel) {
+        const uint32_t w = kept[e];
         out.words.insert(out.words.end(), words.begin() + (size_t)w * D, words.begin() + (size_t)(w + 1) * D);
         out.word_weight.push_back(1.0f);
-        for (uint32_t fi : dist_feats[w]) {
-            const float* L = &lrf[(size_t)fi * 9];
-            const float v[3] = {feat_center[fi][0] - kx[fi], feat_center[fi][1] - ky[fi], feat_center[fi][2] - kz[fi]};
-            // rotateInto: rows of the frame are the axes (utils.cpp:154-165)
-            out.vote_xyz.push_back(L[0] * v[0] + L[1] * v[1] + L[2] * v[2]);
-            out.vote_xyz.push_back(L[3] * v[0] + L[4] * v[1] + L[5] * v[2]);
-            out.vote_xyz.push_back(L[6] * v[0] + L[7] * v[1] + L[8] * v[2]);
+        out.word_class.push_back(feat_class[w]);                 // Codeword::getClassId: class of the feature the word was made from
+        for (uint32_t v = vote_off[e]; v < vote_off[e + 1]; ++v) {
+            const uint32_t fi = vote_feature[v];
+            out.vote_xyz.push_back(vote_xyz[(size_t)v * 3]); out.vote_xyz.push_back(vote_xyz[(size_t)v * 3 + 1]); out.vote_xyz.push_back(vote_xyz[(size_t)v * 3 + 2]);
             out.vote_class.push_back(feat_class[fi]); out.vote_instance.push_back(feat_instance[fi]);
-            out.vote_weight.push_back(1.0f);                                                     // computeWeights: exact centre -> exp(0)
-            out.vote_class_weight.push_back(1.0f / (float)std::max(1, words_per_class[feat_class[fi]]));   // term1 * term2 * term3 for single-vote words
+            out.vote_weight.push_back(vote_weight[v]); out.vote_class_weight.push_back(vote_cw[v]);
         }
         out.vote_offsets.push_back((uint32_t)out.vote_class.size());
     }
-    LOG_INFO("Size of distribution at the end of training: " << kept.size());
+    LOG_INFO("Size of distribution at the end of training: " << sel.size());
     setData(out);
 }
 
@@ -570,6 +528,7 @@ std::vector<std::vector<VotingMaximum>> Voting::findMaxima(DeviceSession& s) {
     return out;
 }
 
+struct Voting::MaximaBuffers { DevBuf n_max, pos, w, cls, inst, iw, bs, nv, score; int M = 32; void reserve(int n_obj, int C); };
 VotingMeanShift::VotingMeanShift() {              // voting_mean_shift.cpp:20-27
     addParameter(m_bandwidth, "Bandwidth", 0.2f);
     addParameter(m_threshold, "Threshold", 1e-3f);
@@ -585,15 +544,21 @@ void VotingMeanShift::iFindMaxima(DeviceSession& s, std::vector<std::vector<Voti
     P.kernel = m_kernel == "Uniform" ? ISMHIP_KERNEL_UNIFORM : ISMHIP_KERNEL_GAUSSIAN;
     P.suppression = m_maxima_suppression_type == "Average" ? ISMHIP_SUPPRESS_AVERAGE : (m_maxima_suppression_type == "Suppress" ? ISMHIP_SUPPRESS_SUPPRESS : ISMHIP_SUPPRESS_NONE);
     P.min_votes_threshold = m_minVotesThreshold; P.min_threshold = m_minThreshold; P.best_k = m_bestK; P.max_maxima = M;
-    DevBuf n_max, pos, w, cls, inst, iw, bs, nv, score;
-    const size_t t = (size_t)s.n_obj * M;
-    n_max.reserve(s.n_obj * 4); pos.reserve(t * 12); w.reserve(t * 4); cls.reserve(t * 4); inst.reserve(t * 4); iw.reserve(t * 4); bs.reserve(t * 12);
-    nv.reserve(t * 4); score.reserve((size_t)s.n_obj * C * 4);
+    MaximaBuffers B; B.M = M; B.reserve(s.n_obj, C);
     s.check(ismhip_find_maxima(s.ctx, s.n_obj, s.slot_off.data(), s.v_pos.as<float>(), s.v_w.as<float>(), s.v_cls.as<int32_t>(), s.v_inst.as<int32_t>(),
-                               s.v_bs.as<float>(), &P, n_max.as<int32_t>(), pos.as<float>(), w.as<float>(), cls.as<int32_t>(), inst.as<int32_t>(),
-                               iw.as<float>(), bs.as<float>(), nv.as<int32_t>(), score.as<float>()), "ismhip_find_maxima");
+                               s.v_bs.as<float>(), &P, B.n_max.as<int32_t>(), B.pos.as<float>(), B.w.as<float>(), B.cls.as<int32_t>(), B.inst.as<int32_t>(),
+                               B.iw.as<float>(), B.bs.as<float>(), B.nv.as<int32_t>(), B.score.as<float>()), "ismhip_find_maxima");
+    collectMaxima(s, B, out);
+}
+void Voting::MaximaBuffers::reserve(int n_obj, int C) {
+    const size_t t = (size_t)n_obj * M;
+    n_max.reserve((size_t)n_obj * 4); pos.reserve(t * 12); w.reserve(t * 4); cls.reserve(t * 4); inst.reserve(t * 4); iw.reserve(t * 4); bs.reserve(t * 12);
+    nv.reserve(t * 4); score.reserve((size_t)n_obj * C * 4);
+}
+void Voting::collectMaxima(DeviceSession& s, MaximaBuffers& b, std::vector<std::vector<VotingMaximum>>& out) {
+    const int M = b.M; const size_t t = (size_t)s.n_obj * M;
     std::vector<int32_t> hn, hcls, hinst, hnv; std::vector<float> hpos, hw, hiw, hbs;
-    s.d2h(hn, n_max, s.n_obj); s.d2h(hpos, pos, t * 3); s.d2h(hw, w, t); s.d2h(hcls, cls, t); s.d2h(hinst, inst, t); s.d2h(hiw, iw, t); s.d2h(hbs, bs, t * 3); s.d2h(hnv, nv, t);
+    s.d2h(hn, b.n_max, s.n_obj); s.d2h(hpos, b.pos, t * 3); s.d2h(hw, b.w, t); s.d2h(hcls, b.cls, t); s.d2h(hinst, b.inst, t); s.d2h(hiw, b.iw, t); s.d2h(hbs, b.bs, t * 3); s.d2h(hnv, b.nv, t);
     for (int o = 0; o < s.n_obj; ++o)
         for (int m = 0; m < hn[o]; ++m) {
             const size_t i = (size_t)o * M + m;
@@ -603,6 +568,30 @@ void VotingMeanShift::iFindMaxima(DeviceSession& s, std::vector<std::vector<Voti
             vm.boundingBox.position = vm.position; vm.boundingBox.size = {hbs[i * 3], hbs[i * 3 + 1], hbs[i * 3 + 2]};
             out[o].push_back(vm);
         }
+}
+
+VotingHough3D::VotingHough3D() {                  // voting_hough_3d.cpp:15-26
+    addParameter(m_useInterpolation, "UseInterpolation", true);
+    addParameter(m_minCoord, "MinCoord", Vec3d{{-5, -5, -5}});
+    addParameter(m_maxCoord, "MaxCoord", Vec3d{{5, 5, 5}});
+    addParameter(m_binSize, "BinSize", Vec3d{{0.2, 0.2, 0.2}});
+    addParameter(m_relThreshold, "RelThreshold", 0.8f);
+}
+void VotingHough3D::iFindMaxima(DeviceSession& s, std::vector<std::vector<VotingMaximum>>& out) {
+    if (m_single_object_mode) LOG_WARN("SingleObjectMode is not supported with Hough3D - switch to MeanShift to use it!");   // :42-43
+    const int C = std::max(1, s.n_classes);
+    ismhip_hough_params P;
+    P.n_classes = C;
+    for (int d = 0; d < 3; ++d) { P.min_coord[d] = (float)m_minCoord[d]; P.max_coord[d] = (float)m_maxCoord[d]; }
+    // :45-47: MaximaHandler::setRadius(BinSize[0] / 2); the bins become cubes of edge 2 * getSearchDistForClass (= BinSize[0] with "Config")
+    P.bin_size = 2.0f * (float)(m_binSize[0] / 2); P.class_bin_h = nullptr;
+    P.use_interpolation = m_useInterpolation ? 1 : 0; P.rel_threshold = m_relThreshold;
+    P.min_votes_threshold = m_minVotesThreshold; P.min_threshold = m_minThreshold; P.best_k = m_bestK;
+    MaximaBuffers B; P.max_maxima = B.M; B.reserve(s.n_obj, C);
+    s.check(ismhip_hough3d_maxima(s.ctx, s.n_obj, s.slot_off.data(), s.v_pos.as<float>(), s.v_w.as<float>(), s.v_cls.as<int32_t>(), s.v_inst.as<int32_t>(),
+                                  s.v_bs.as<float>(), &P, B.n_max.as<int32_t>(), B.pos.as<float>(), B.w.as<float>(), B.cls.as<int32_t>(), B.inst.as<int32_t>(),
+                                  B.iw.as<float>(), B.bs.as<float>(), B.nv.as<int32_t>(), B.score.as<float>()), "ismhip_hough3d_maxima");
+    collectMaxima(s, B, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -625,7 +614,8 @@ template <> ActivationStrategy* Factory<ActivationStrategy>::createByType(const 
 }
 template <> Voting* Factory<Voting>::createByType(const std::string& type) {
     if (type == VotingMeanShift::getTypeStatic()) return new VotingMeanShift();
-    throw RuntimeException("voting type \"" + type + "\" is not built (built: MeanShift)");
+    if (type == VotingHough3D::getTypeStatic()) return new VotingHough3D();
+    throw RuntimeException("voting type \"" + type + "\" is not built (built: MeanShift, Hough3D)");
 }
 template <> Codebook* Factory<Codebook>::createByType(const std::string&) { return new Codebook(); }
 

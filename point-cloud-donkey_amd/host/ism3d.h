@@ -105,6 +105,12 @@ template <> struct JSONParameterTraits<std::string> {
     static std::string get(const Json& v) { return v.str; }
     static Json put(const std::string& v) { return Json::of(v); }
 };
+typedef std::array<double, 3> Vec3d;      // Eigen::Vector3d parameters: a JSON array of three numbers (json_parameter_traits.h:107-128)
+template <> struct JSONParameterTraits<Vec3d> {
+    static bool ok(const Json& v) { return v.type == Json::Array && v.arr.size() == 3 && v.arr[0].type == Json::Number && v.arr[1].type == Json::Number && v.arr[2].type == Json::Number; }
+    static Vec3d get(const Json& v) { return Vec3d{{v.arr[0].num, v.arr[1].num, v.arr[2].num}}; }
+    static Json put(const Vec3d& v) { Json j = Json::array(); for (double x : v) j.arr.push_back(Json::of(x)); return j; }
+};
 template <typename T>
 struct JSONParameter : JSONParameterBase {
     T& ref; T def;
@@ -249,6 +255,7 @@ struct CodebookData {          // host copy of what Codebook::iSaveData persists
     std::vector<uint32_t> vote_offsets{0};
     std::vector<float> vote_xyz, vote_weight, vote_class_weight, vote_bbox_quat, vote_bbox_size;
     std::vector<uint32_t> vote_class, vote_instance;
+    std::vector<uint32_t> word_class;      // Codeword::getClassId per word (empty: class of the word's first vote)
     std::vector<float> class_sigma;
     int numWords() const { return dim ? (int)(words.size() / dim) : 0; }
 };
@@ -299,9 +306,22 @@ public:
 protected:
     friend class Codebook;
     virtual void iFindMaxima(DeviceSession& s, std::vector<std::vector<VotingMaximum>>& out) = 0;
+    // device outputs of ismhip_find_maxima / ismhip_hough3d_maxima -> VotingMaximum lists
+    struct MaximaBuffers;                                        // defined in ism3d.cpp (device buffers)
+    static void collectMaxima(DeviceSession& s, MaximaBuffers& b, std::vector<std::vector<VotingMaximum>>& out);
     float m_minThreshold; int m_minVotesThreshold; int m_bestK; bool m_averageRotation;
     std::string m_radiusType; float m_radiusFactor; std::string m_max_filter_type, m_max_type_param;
     bool m_single_object_mode; bool m_use_global_features; bool m_vote_filtering_with_ransac;
+};
+class VotingHough3D : public Voting {             // voting/voting_hough_3d.{h,cpp}
+public:
+    VotingHough3D();
+    static std::string getTypeStatic() { return "Hough3D"; }
+    std::string getType() const override { return getTypeStatic(); }
+protected:
+    void iFindMaxima(DeviceSession& s, std::vector<std::vector<VotingMaximum>>& out) override;
+private:
+    bool m_useInterpolation; Vec3d m_minCoord, m_maxCoord, m_binSize; float m_relThreshold;
 };
 class VotingMeanShift : public Voting {
 public:

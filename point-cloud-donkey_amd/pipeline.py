@@ -21,6 +21,7 @@ class IsmConfig:
     radius: float = 0.4              # Features.Radius
     lrf_radius: float = 0.3          # Features.ReferenceFrameRadius
     distance: str = "Euclidean"      # DistanceType: "Euclidean" (FLANN L2, squared) | "ChiSquared"
+    activation: str = "KNN"          # ActivationStrategy.Type: "KNN" | "KNNRule"
     k: int = 1                       # ActivationStrategy.K
     use_distance_ratio: bool = False
     distance_ratio_threshold: float = 0.95
@@ -37,6 +38,12 @@ class IsmConfig:
     min_threshold: float = 0.0
     best_k: int = -1
     max_maxima: int = 16
+    voting: str = "MeanShift"        # Voting.Type: "MeanShift" | "Hough3D"
+    hough_min_coord: tuple = (-5.0, -5.0, -5.0)   # Voting(Hough3D).MinCoord / MaxCoord / BinSize[0] / UseInterpolation / RelThreshold
+    hough_max_coord: tuple = (5.0, 5.0, 5.0)
+    hough_bin_size: float = 0.2
+    hough_use_interpolation: bool = True
+    hough_rel_threshold: float = 0.8
     n_classes: int = 10
     use_random_codebook: bool = False
     random_codebook_size: int = 0    # fixed-size seeded subset (reference: UseRandomCodebook/RandomCodebookFactor, codebook.cpp:821-829)
@@ -183,32 +190,29 @@ class Recognizer:
         desc = torch.cat(descs); lrf = torch.cat(lrfs); kp = torch.cat(kps); center = torch.cat(centers)
         cls = np.concatenate(cls); inst = np.concatenate(inst); model = np.concatenate(model)
         n = desc.shape[0]
-        # one codeword per training feature (clustering_none.cpp), dataset rows in feature order
+        # Codebook::activate on the device (ismhip_train_activate): one codeword per training feature (clustering_none.cpp), exact
+        # kNN activation, class sigma^2, K = 1 clean-up, vote CSR, computeWeights and the statistical class weights
+        assert (np.diff(cls.astype(np.int64)) >= 0).all(), "training objects must be ordered class-major"
+        knn_rule = getattr(c, "activation", "KNN") == "KNNRule"
+        k_act = 1 if knn_rule else c.k                       # KNNRule trains with plain 1-NN and keeps multi-vote codewords
+        act = capi.train_activate(ctx, c.metric, desc, lrf, kp[:, 0].contiguous(), kp[:, 1].contiguous(), kp[:, 2].contiguous(), cls, model,
+                                  center.cpu().numpy(), k=k_act, clean_up=(not knn_rule and c.k == 1), n_classes=c.n_classes)
         words_h = desc.cpu().numpy()
-        ones = np.arange(n + 1, dtype=np.uint32)
-        cb0 = capi.Codebook(ctx, words_h, ones, np.zeros((n, 3), np.float32), cls, inst, c.n_classes, np.ones(c.n_classes, np.float32))
-        act, _ = capi.knn(ctx, cb0, c.metric, desc, 1)                    # Codebook::activate, activateKNN per training feature
-        act = act[:, 0].cpu().numpy()
-        cb0.close()
-        # vote = rotateInto(center - keyPos, LRF): rows of the frame are the axes (utils.cpp:154-165)
-        votes = torch.einsum("nij,nj->ni", lrf.view(-1, 3, 3), center - kp).cpu().numpy()
-        sigma = class_sigmas_numpy(c.metric, words_h, cls, model, act, c.n_classes)
-        # k = 1 clean-up: keep distributions with exactly one vote (codebook.cpp:201-224)
-        n_votes = np.bincount(act, minlength=n)
-        keep_words = np.nonzero(n_votes == 1)[0]
-        owner = np.full(n, -1, np.int64)
-        owner[act] = np.arange(n)                     # the single feature that activated each kept word
-        src = owner[keep_words]
+        keep_words, vote_off, src = act["word_src"].astype(np.int64), act["vote_offsets"], act["vote_feature"].astype(np.int64)
+        vote_xyz, vote_w, vote_cw = act["vote_xyz"], act["vote_weight"], act["vote_class_weight"]
         if c.use_random_codebook and 0 < c.random_codebook_size < len(keep_words):
+            # fixed-size seeded subset of the codewords (reference: UseRandomCodebook at load time, codebook.cpp:821-829)
             rng = np.random.default_rng(c.random_codebook_seed)
             sel = np.sort(rng.choice(len(keep_words), c.random_codebook_size, replace=False))
-            keep_words, src = keep_words[sel], src[sel]
+            cnt = np.diff(vote_off.astype(np.int64))
+            vsel = np.concatenate([np.arange(vote_off[e], vote_off[e + 1]) for e in sel]) if len(sel) else np.zeros(0, np.int64)
+            keep_words = keep_words[sel]; vote_off = np.concatenate([[0], np.cumsum(cnt[sel])]).astype(np.uint32)
+            src, vote_xyz, vote_w, vote_cw = src[vsel], vote_xyz[vsel], vote_w[vsel], vote_cw[vsel]
         m = len(keep_words)
-        per_class = np.bincount(cls[src], minlength=c.n_classes).astype(np.float32)
-        self.cb_host = dict(words=words_h[keep_words], vote_offsets=np.arange(m + 1, dtype=np.uint32), vote_xyz=votes[src],
-                            vote_class=cls[src], vote_instance=inst[src], class_sigma=sigma,
-                            vote_class_weight=(1.0 / np.maximum(per_class, 1))[cls[src]].astype(np.float32),
-                            vote_weight=np.ones(m, np.float32), word_weight=np.ones(m, np.float32))
+        self.cb_host = dict(words=words_h[keep_words], vote_offsets=vote_off.astype(np.uint32), vote_xyz=vote_xyz,
+                            vote_class=cls[src], vote_instance=inst[src], class_sigma=act["class_sigma"],
+                            vote_class_weight=vote_cw.astype(np.float32), vote_weight=vote_w.astype(np.float32), word_weight=np.ones(m, np.float32),
+                            word_class=cls[keep_words])
         self.load_codebook(self.cb_host)
         return self.cb_host
 
@@ -220,21 +224,29 @@ class Recognizer:
                                       self.cfg.n_classes, cb["class_sigma"], word_weight=cb.get("word_weight"),
                                       vote_weight=cb.get("vote_weight"), vote_class_weight=cb.get("vote_class_weight"),
                                       vote_bbox_quat=cb.get("vote_bbox_quat"), vote_bbox_size=cb.get("vote_bbox_size"))
+        if cb.get("word_class") is not None:
+            self.codebook.set_word_class(cb["word_class"])       # Codeword::getClassId = class of the feature the word was made from
 
     # -- ImplicitShapeModel::detect() over a batch --------------------------------------------------------------
     def detect(self, b: DeviceBatch, keep_intermediates=False):
         c, ctx, cb = self.cfg, self.ctx, self.codebook
         f = self.compute_features(b)
-        if c.use_distance_ratio and c.k == 1:
+        if getattr(c, "activation", "KNN") == "KNNRule":
+            idx, dist = capi.knn_rule(ctx, cb, c.metric, f["desc"], c.distance_ratio_threshold)
+        elif c.use_distance_ratio and c.k == 1:
             idx, dist = capi.knn_ratio(ctx, cb, c.metric, f["desc"], c.distance_ratio_threshold)
         else:
             idx, dist = capi.knn(ctx, cb, c.metric, f["desc"], c.k)
         votes = capi.cast_votes(ctx, cb, c.weight_flags, f["lrf"], f["kx"], f["ky"], f["kz"], idx, dist)
         slot_off = f["off"].astype(np.uint64) * (c.k * cb.max_votes)
-        mx = capi.find_maxima(ctx, slot_off.astype(np.uint32), votes, c.n_classes, c.bandwidth, c.threshold, c.max_iter,
-                              capi.KERNEL_GAUSSIAN if c.kernel == "Gaussian" else capi.KERNEL_UNIFORM,
-                              {"Average": capi.SUPPRESS_AVERAGE, "Suppress": capi.SUPPRESS_SUPPRESS}.get(c.maxima_suppression, capi.SUPPRESS_NONE),
-                              c.min_votes_threshold, c.min_threshold, c.best_k, c.max_maxima)
+        if c.voting == "Hough3D":
+            mx = capi.hough3d_maxima(ctx, slot_off.astype(np.uint32), votes, c.n_classes, c.hough_bin_size, c.hough_min_coord, c.hough_max_coord,
+                                     c.hough_use_interpolation, c.hough_rel_threshold, c.min_votes_threshold, c.min_threshold, c.best_k, c.max_maxima)
+        else:
+            mx = capi.find_maxima(ctx, slot_off.astype(np.uint32), votes, c.n_classes, c.bandwidth, c.threshold, c.max_iter,
+                                  capi.KERNEL_GAUSSIAN if c.kernel == "Gaussian" else capi.KERNEL_UNIFORM,
+                                  {"Average": capi.SUPPRESS_AVERAGE, "Suppress": capi.SUPPRESS_SUPPRESS}.get(c.maxima_suppression, capi.SUPPRESS_NONE),
+                                  c.min_votes_threshold, c.min_threshold, c.best_k, c.max_maxima)
         if keep_intermediates:
             mx.update(features=f, idx=idx, dist=dist, votes=votes, slot_off=slot_off.astype(np.uint32))
         else:

@@ -400,11 +400,28 @@ def maxima_thresholds():
                 instances=[7, 1, 5], instance_weights=[3.0 / 5.0, 2.0 / 5.0, 1.0 / 5.0], n_votes=[4, 3, 2], tol=1e-6)
 
 
+def hough3d_three_bins():
+    """KAT 15: VotingHough3D over HoughSpace3D, space [-5,5]^3, bin 0.2 (50^3 bins, bin c centred at
+    -5 + (c + 0.5) 0.2). Vote A (w 1) sits on the centre of bin (25,25,25); vote B (w 2) a quarter bin off the centre of bin
+    (30,25,25) in +x and +y: trilinear split 0.75*0.75*2 = 1.125 central, 0.375 to (31,25,25) and (30,26,25), 0.125 to (31,26,25);
+    vote C (w 1) on the centre of bin (25,30,25). RelThreshold 0.8 -> threshold 0.9: the three central bins are the maxima
+    (ascending bin index: A, B, C), each with ITS vote's full weight -> normalised 0.25, 0.5, 0.25, sorted B, A, C."""
+    ctr = lambda c: -5.0 + (c + 0.5) * 0.2
+    A = [ctr(25), ctr(25), ctr(25)]; B = [ctr(30) + 0.05, ctr(25) + 0.05, ctr(25)]; Cc = [ctr(25), ctr(30), ctr(25)]
+    return dict(pos=[A, B, Cc], w=[1.0, 2.0, 1.0], cls=[0, 0, 0], inst=[4, 5, 6], bin=0.2, min_coord=[-5, -5, -5], max_coord=[5, 5, 5],
+                rel_threshold=0.8, n_classes=2, expected_n=3, expected_pos=[B, A, Cc], expected_weight=[0.5, 0.25, 0.25], expected_inst=[5, 4, 6],
+                expected_n_votes=[1, 1, 1],
+                # with RelThreshold 0.3 (threshold 0.3375) B's x and y neighbours (0.375) pass the threshold but have a strictly greater
+                # neighbour (B's central bin), so the maxima stay the same three; without interpolation likewise
+                tol=2e-6)
+
+
 def main():
     kat = dict(shot_sector_centres=shot_sector_centres(), lrf_paraboloid=lrf_paraboloid(), rgb2lab=rgb2lab_cases(),
                fpfh_two_points=fpfh_two_points(), distances=distances(), rotations=rotations(), seeds_order=seeds_order(),
                voxel_grid=voxel_grid(), knn_ties=knn_ties(), shot_off_centre=shot_off_centre(), cshot_colour_pairs=cshot_colour_pairs(),
-               cast_votes_vector=cast_votes_vector(), knn_rule_table=knn_rule_table(), maxima_thresholds=maxima_thresholds())
+               cast_votes_vector=cast_votes_vector(), knn_rule_table=knn_rule_table(), maxima_thresholds=maxima_thresholds(),
+               hough3d_three_bins=hough3d_three_bins())
     with open(OUT, "w") as f:
         json.dump(kat, f, indent=1)
     print("wrote", OUT)

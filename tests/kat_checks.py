@@ -90,3 +90,19 @@ def maxima_thresholds(find_maxima):
         score = np.zeros(k["n_classes"], np.float32)
         score[k["classes"][:n]] = k["weights"][:n]
         np.testing.assert_allclose(np.asarray(out["class_score"])[0], score, atol=k["tol"])
+
+
+def hough3d_three_bins(hough):
+    """hough(slot_offsets, votes dict, **kw) -> dict as oracle_py.hough3d_maxima"""
+    k = KAT["hough3d_three_bins"]
+    v = dict(pos=np.asarray(k["pos"], np.float32), weight=np.asarray(k["w"], np.float32), cls=np.asarray(k["cls"], np.int32),
+             inst=np.asarray(k["inst"], np.int32))
+    for rel, interp in ((k["rel_threshold"], True), (0.3, True), (0.4, False)):      # no interpolation: H = 1, 2, 1 -> threshold 0.8
+        out = hough([0, 3], v, n_classes=k["n_classes"], bin_size=k["bin"], min_coord=k["min_coord"], max_coord=k["max_coord"],
+                    rel_threshold=rel, use_interpolation=interp, max_maxima=8)
+        n = int(np.asarray(out["n"])[0])
+        assert n == k["expected_n"], (rel, interp, n)
+        np.testing.assert_allclose(np.asarray(out["pos"])[0, :n], np.asarray(k["expected_pos"], np.float32), atol=k["tol"])
+        np.testing.assert_allclose(np.asarray(out["weight"])[0, :n], k["expected_weight"], atol=k["tol"])
+        assert np.asarray(out["inst"])[0, :n].tolist() == k["expected_inst"] and np.asarray(out["n_votes"])[0, :n].tolist() == k["expected_n_votes"]
+        np.testing.assert_allclose(np.asarray(out["class_score"])[0], [0.5, 0.0], atol=k["tol"])

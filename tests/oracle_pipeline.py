@@ -25,8 +25,12 @@ def detect(ora, cfg, cb, nb, n_classes):
     votes = ora.cast_votes(cb, cfg.weight_flags, lrf[ok], kx[ok], ky[ok], kz[ok], idx, dist)
     maxv = int(np.max(np.diff(np.asarray(cb["vote_offsets"], np.int64))))
     slot_off = (off.astype(np.int64) * idx.shape[1] * maxv).astype(np.uint32)
-    mx = ora.find_maxima(slot_off, votes, n_classes, cfg.bandwidth, cfg.threshold, cfg.max_iter, 0 if cfg.kernel == "Gaussian" else 1,
-                         {"Average": 0, "Suppress": 1}.get(cfg.maxima_suppression, 2), cfg.min_votes_threshold, cfg.min_threshold, cfg.best_k,
-                         cfg.max_maxima)
+    if getattr(cfg, "voting", "MeanShift") == "Hough3D":
+        mx = ora.hough3d_maxima(slot_off, votes, n_classes, cfg.hough_bin_size, cfg.hough_min_coord, cfg.hough_max_coord, cfg.hough_use_interpolation,
+                                cfg.hough_rel_threshold, cfg.min_votes_threshold, cfg.min_threshold, cfg.best_k, cfg.max_maxima)
+    else:
+        mx = ora.find_maxima(slot_off, votes, n_classes, cfg.bandwidth, cfg.threshold, cfg.max_iter, 0 if cfg.kernel == "Gaussian" else 1,
+                             {"Average": 0, "Suppress": 1}.get(cfg.maxima_suppression, 2), cfg.min_votes_threshold, cfg.min_threshold, cfg.best_k,
+                             cfg.max_maxima)
     mx.update(desc=q, lrf=lrf[ok], off=off, idx=idx, dist=dist, votes=votes, keep=ok)
     return mx

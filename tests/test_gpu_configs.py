@@ -88,6 +88,18 @@ def test_cfg4_dual_fpfh_shot(pkg, gpu, ora):
     assert (fused_gpu.argmax(1) == nb["labels"]).all()
 
 
+def test_cfg1_with_hough3d_voting(pkg, gpu, ora):
+    """the ModelNet-like value set with Voting.Type Hough3D (BinSize 0.4, RelThreshold 0.5): the discrete accumulator end to end"""
+    cfg = pkg.pipeline.IsmConfig(feature="SHOT", n_classes=4, voting="Hough3D", hough_bin_size=0.4, hough_rel_threshold=0.5,
+                                 hough_min_coord=(-3.0, -3.0, -3.0), hough_max_coord=(3.0, 3.0, 3.0))
+    syn = pkg.synthetic
+    train = syn.Dataset(4, 8, split=0, n_points=8192, n_keypoints=512)
+    test = syn.Dataset(4, 4, split=1, n_points=8192, n_keypoints=512)
+    got, want, nb = _run(pkg, gpu, ora, cfg, train, test, 8, 4)
+    assert (got["cls"][:, 0].cpu().numpy() == nb["labels"]).all()
+    np.testing.assert_allclose(got["pos"].cpu().numpy(), want["pos"], atol=1e-4)
+
+
 def test_knn_rule_matches_oracle(pkg, gpu, ora):
     import torch
     ctx, dev = gpu

@@ -710,6 +710,40 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
     assert flagged[0] < nq // 20, flagged                                                   # the proof carries the bulk, the scan the rest
 
 
+# ------------------------------------------------------------------------------------------------ training on the device
+@pytest.mark.parametrize("metric,k,clean_up", [(0, 1, True), (1, 1, True), (0, 2, False), (0, 3, False), (1, 2, False), (0, 1, False)])
+def test_train_activate_matches_oracle(pkg, gpu, ora, metric, k, clean_up):
+    """Codebook::activate on the device (ismhip_train_activate) against ismref_activate: kept words, vote CSR, vote geometry,
+    computeWeights medians, statistical class weights (with the reference's class-keyed term3) and class sigma^2."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(40 + 10 * metric + k)
+    n, D = 1500, 48
+    proto = rng.random((60, D)).astype(np.float32)
+    feats = (proto[rng.integers(0, 60, n)] + 0.05 * rng.random((n, D))).astype(np.float32)      # clustered: shared nearest neighbours
+    feats[1000:1030] = feats[5:35]                                # exact duplicates: with k = 1 both copies activate the LOWER row
+    cls = np.sort(rng.integers(0, 4, n)).astype(np.uint32)
+    model = np.zeros(n, np.uint32)
+    for c in range(4):                                            # a few models per class, contiguous
+        ids = np.nonzero(cls == c)[0]
+        model[ids] = c * 10 + (np.arange(len(ids)) * 3 // max(1, len(ids)))
+    A = rng.normal(size=(n, 3, 3)); Q, _ = np.linalg.qr(A); Q[np.linalg.det(Q) < 0, 2] *= -1
+    lrf = Q.reshape(n, 9).astype(np.float32); kp = rng.normal(size=(n, 3)).astype(np.float32)
+    centre = rng.normal(size=(40, 3)).astype(np.float32)[model]
+    got = pkg.capi.train_activate(ctx, metric, T(feats, dev), T(lrf, dev), T(kp[:, 0], dev), T(kp[:, 1], dev), T(kp[:, 2], dev), cls, model, centre,
+                                  k=k, clean_up=clean_up, n_classes=4)
+    want = ora.activate(metric, feats, lrf, kp, cls, model, centre, k=k, clean_up=clean_up, n_classes=4)
+    for key in ("word_src", "vote_offsets", "vote_feature"):
+        assert np.array_equal(got[key], want[key]), key
+    np.testing.assert_allclose(got["vote_xyz"], want["vote_xyz"], atol=2e-6)
+    np.testing.assert_allclose(got["vote_weight"], want["vote_weight"], atol=2e-6)
+    np.testing.assert_allclose(got["vote_class_weight"], want["vote_class_weight"], rtol=1e-6, atol=1e-12)
+    assert np.array_equal(got["class_sigma"], want["class_sigma"])            # same functor order, same sequential float sums
+    if not clean_up:
+        assert np.diff(want["vote_offsets"].astype(np.int64)).max() >= (3 if k > 1 else 2)   # multi-vote distributions were exercised
+    else:
+        assert len(want["word_src"]) < n - 30                                  # the duplicated rows were cleaned away
+
+
 # ------------------------------------------------------------------------------------------------ round-2 known-answer vectors
 # the same closed-form vectors the oracle is held to (tests/kat_checks.py), here through the C ABI on the GPU
 def test_kat_shot_off_centre_interpolation(pkg, gpu):
@@ -766,6 +800,61 @@ def test_kat_maxima_thresholds_and_bestk(pkg, gpu):
         out = pkg.capi.find_maxima(ctx, off, {k: T(a, dev) for k, a in v.items()}, **kw)
         return {k: a.cpu().numpy() for k, a in out.items()}
     kat_checks.maxima_thresholds(f)
+
+
+def test_kat_hough3d_three_bins(pkg, gpu):
+    ctx, dev = gpu
+
+    def f(off, v, **kw):
+        out = pkg.capi.hough3d_maxima(ctx, off, {k: T(a, dev) for k, a in v.items()}, **kw)
+        return {k: a.cpu().numpy() for k, a in out.items()}
+    kat_checks.hough3d_three_bins(f)
+
+
+@pytest.mark.parametrize("interp,bin_size,rel", [(True, 0.4, 0.6), (False, 0.4, 0.6), (True, 0.1, 0.3), (True, 0.25, 0.9)])
+def test_hough3d_matches_oracle(pkg, gpu, ora, interp, bin_size, rel):
+    """VotingHough3D on the device against the oracle on ragged vote sets (empty object, slots without a vote, clutter, votes
+    outside the space). bin 0.1 spreads a class over ~60 bins per axis: the accumulator takes several LDS tiles."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(int(1000 * bin_size) + int(interp))
+    off, v = _vote_scene(rng, 10, 4)
+    v["pos"][::53] += 20.0                                        # outside [-5, 5]^3: dropped by the accumulator
+    tv = {k2: T(a, dev) for k2, a in v.items()}
+    kw = dict(n_classes=4, bin_size=bin_size, use_interpolation=interp, rel_threshold=rel, max_maxima=24, min_votes_threshold=2)
+    got = pkg.capi.hough3d_maxima(ctx, off, tv, **kw)
+    want = ora.hough3d_maxima(off, v, **kw)
+    assert np.array_equal(got["n"].cpu().numpy(), want["n"])
+    assert np.array_equal(got["cls"].cpu().numpy(), want["cls"])
+    assert np.array_equal(got["inst"].cpu().numpy(), want["inst"])
+    assert np.array_equal(got["n_votes"].cpu().numpy(), want["n_votes"])
+    np.testing.assert_allclose(got["weight"].cpu().numpy(), want["weight"], atol=TOL)
+    np.testing.assert_allclose(got["inst_weight"].cpu().numpy(), want["inst_weight"], atol=TOL)
+    np.testing.assert_allclose(got["pos"].cpu().numpy(), want["pos"], atol=1e-4)
+    np.testing.assert_allclose(got["bbox_size"].cpu().numpy(), want["bbox_size"], atol=1e-3)
+    np.testing.assert_allclose(got["class_score"].cpu().numpy(), want["class_score"], atol=TOL)
+    assert want["n"][1] == 0 and want["n"].max() >= 2
+
+
+def test_all_gather_records_over_rccl_world1(pkg, gpu):
+    """the path's one collective through the nccl (= RCCL) backend on this box's GPU: world size 1, device tensors"""
+    import torch
+    import torch.distributed as dist
+    ctx, dev = gpu
+    sh = pkg.shard
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1, device_id=dev)
+    try:
+        g = torch.Generator().manual_seed(5)
+        scores = torch.rand((9, 4), generator=g).to(dev)
+        scores[3] = 0
+        rec = sh.pack_records(torch.arange(9, device=dev), scores, 12)
+        out = sh.all_gather_records(rec, 1)
+        assert out.is_cuda and out.shape == (12, 6) and dist.get_backend() == "nccl"
+        oi, best, sc = sh.unpack_records(out)
+        exp = scores.argmax(1); exp[3] = -1
+        assert oi.tolist() == list(range(9)) and best.tolist() == exp.tolist() and torch.equal(sc, scores)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_errors_are_loud(pkg, gpu):

@@ -106,3 +106,40 @@ def test_all_gather_records_gloo_world2(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_strong_scaling_plan_covers_the_split_once():
+    b = _bench()
+    for n, batch in ((908, 512), (2468, 512), (7, 512), (908, 100)):
+        for world in (1, 2, 4, 8):
+            seen, pads = [], set()
+            for r in range(world):
+                lo, hi, pad, bounds = b.plan_shard(n, r, world, batch)
+                assert bounds[0] == lo and bounds[-1] == hi and all(0 <= y - x <= batch for x, y in zip(bounds, bounds[1:]))
+                assert hi - lo <= pad
+                seen += list(range(lo, hi)); pads.add(pad)
+            assert seen == list(range(n)) and len(pads) == 1          # every object exactly once, equal-sized all-gather records
+    assert b.plan_shard(908, 0, 1, 512)[3] == [0, 454, 908] and b.plan_shard(908, 7, 8, 512)[:2] == (798, 908)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` without a launcher starts the N ranks itself -- or fails loudly when the box has fewer GPUs (here: none)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("2+ GPUs present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and "GPU(s) visible" in r.stderr
+    # launched with a WORLD_SIZE that contradicts --gpus: refused before anything touches a GPU
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29544")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

@@ -52,7 +52,7 @@ def test_shipped_configs_load(cfgfile):
 
 def test_config_errors_match_reference_behaviour():
     for edits, needle in [({"Children/Features/Type": "PFH"}, "outside the MI355X hot path"),
-                          ({"Children/Voting/Type": "Hough3D"}, "not built"),
+                          ({"Children/Voting/Type": "Hough4D"}, "not built"),
                           ({"Children/Codebook/Children/ActivationStrategy/Type": "INN"}, "not built"),
                           ({"Children/Clustering/Type": "KMeans"}, "out of scope"),
                           ({"Parameters/DistanceType": "Manhattan"}, "invalid distance type"),
@@ -149,6 +149,39 @@ def test_host_train_write_read_detect_matches_python_harness(pkg, gpu, tmp_path)
     assert np.array_equal(got["cls"][:, :k], want["cls"][:, :k].cpu().numpy())
     np.testing.assert_allclose(got["weight"][:, :k], want["weight"][:, :k].cpu().numpy(), atol=1e-4)
     np.testing.assert_allclose(got["pos"][:, :k], want["pos"][:, :k].cpu().numpy(), atol=2e-3)
+    assert (got["cls"][:, 0] == nb["labels"]).all()
+
+
+@pytest.mark.gpu
+def test_host_hough3d_voting_matches_python_harness(pkg, gpu):
+    """Factory<Voting> accepts "Hough3D" (voting_factory.h:20-29): the C++ host with the reference's parameter names against
+    the Python harness on the same data"""
+    ctx, dev = gpu
+    train, test = _dataset(pkg, 3, 9, 6)
+    order = sorted(range(9), key=lambda i: (train.label(i), i))
+    m = hb.Model()
+    m.config_from_json(_cfg(**{"Children/Voting/Type": "Hough3D",
+                               "Children/Voting/Parameters": {"UseInterpolation": True, "MinCoord": [-3, -3, -3], "MaxCoord": [3, 3, 3],
+                                                              "BinSize": [0.4, 0.4, 0.4], "RelThreshold": 0.5, "MinThreshold": 0.0,
+                                                              "MinVotesThreshold": 1, "BestK": -1}}))
+    out = json.loads(m.config_to_json())
+    assert out["Children"]["Voting"]["Type"] == "Hough3D" and out["Children"]["Voting"]["Parameters"]["BinSize"] == [0.4, 0.4, 0.4]
+    for i in order:
+        o = train.get(i)
+        m.add_training(o["xyz"], o["normals"], o["label"], i)
+    m.train()
+    cfg = pkg.pipeline.IsmConfig(n_classes=3, voting="Hough3D", hough_bin_size=0.4, hough_rel_threshold=0.5,
+                                 hough_min_coord=(-3.0, -3.0, -3.0), hough_max_coord=(3.0, 3.0, 3.0))
+    rec = pkg.pipeline.Recognizer(ctx, cfg)
+    rec.train([pkg.pipeline.DeviceBatch(train.batch(order), dev)], instance_ids=order)
+    nb = test.batch(range(6))
+    got = m.detect_batch(nb["pt_off"], nb["xyz"], nb["normals"], max_maxima=8)
+    want = rec.detect(pkg.pipeline.DeviceBatch(nb, dev))
+    assert np.array_equal(got["n"], np.minimum(want["n"].cpu().numpy(), 8))
+    k = 3
+    assert np.array_equal(got["cls"][:, :k], want["cls"][:, :k].cpu().numpy())
+    np.testing.assert_allclose(got["weight"][:, :k], want["weight"][:, :k].cpu().numpy(), atol=1e-4)
+    np.testing.assert_allclose(got["pos"][:, :k], want["pos"][:, :k].cpu().numpy(), atol=1e-3)
     assert (got["cls"][:, 0] == nb["labels"]).all()
 
 

@@ -258,16 +258,44 @@ def test_cast_votes_gate_and_geometry(ora):
     assert abs(m["weight"][0] - (1 / np.sqrt(2 * np.pi * 1.0)) * np.exp(-0.25 / 2.0)) < 1e-6
 
 
-def test_class_sigmas_match_harness(ora, pkg):
+def test_activate_matches_class_sigmas_and_single_vote_weights(ora):
+    """ismref_activate against the older sigma helper, and the closed forms of the K = 1 case (codebook.cpp:201-368): every kept
+    word has one vote, vote weight exp(0) = 1 (the vote reproduces the model centre), class weight 1 / words of the class."""
     rng = np.random.default_rng(8)
-    feats = rng.random((600, 16)).astype(np.float32)
+    n = 600
+    feats = rng.random((n, 16)).astype(np.float32)
     cls = np.repeat(np.arange(3), 200).astype(np.uint32)
-    model = (np.arange(600) // 50).astype(np.uint32)
-    act = np.arange(600, dtype=np.int32)
+    model = (np.arange(n) // 50).astype(np.uint32)
+    A = rng.normal(size=(n, 3, 3)); Q, _ = np.linalg.qr(A); Q[np.linalg.det(Q) < 0, 2] *= -1
+    lrf = Q.reshape(n, 9).astype(np.float32); kp = rng.normal(size=(n, 3)).astype(np.float32)
+    centre = np.repeat(rng.normal(size=(12, 3)), 50, axis=0).astype(np.float32)
     for metric in (0, 1):
-        a = ora.class_sigmas(metric, feats, cls, model, act, feats, 3)
-        b = pkg.pipeline.class_sigmas_numpy(metric, feats, cls, model, act, 3)
-        np.testing.assert_allclose(a, b, rtol=2e-4)
+        act, _ = ora.knn(metric, feats, feats, 1)
+        r = ora.activate(metric, feats, lrf, kp, cls, model, centre, k=1, clean_up=True, n_classes=3)
+        np.testing.assert_array_equal(r["class_sigma"], ora.class_sigmas(metric, feats, cls, model, act[:, 0], feats, 3))
+        assert (np.diff(r["vote_offsets"].astype(np.int64)) == 1).all()
+        np.testing.assert_allclose(r["vote_weight"], 1.0, atol=1e-6)
+        per_class = np.bincount(cls[r["vote_feature"]], minlength=3)
+        np.testing.assert_allclose(r["vote_class_weight"], 1.0 / per_class[cls[r["vote_feature"]]], rtol=1e-6)
+        # vote = rows-of-the-frame rotation of (centre - keypoint)
+        v = np.einsum("nij,nj->ni", lrf.reshape(-1, 3, 3)[r["vote_feature"]], (centre - kp)[r["vote_feature"]])
+        np.testing.assert_allclose(r["vote_xyz"], v, atol=2e-6)
+    # K = 2, no clean-up: every feature votes twice; term3 is taken from the LAST word holding the class
+    r = ora.activate(0, feats, lrf, kp, cls, model, centre, k=2, clean_up=False, n_classes=3)
+    assert r["vote_offsets"][-1] == 2 * n and ((r["vote_weight"] >= 0) & (r["vote_weight"] <= 1)).all()
+    e_of_vote = np.repeat(np.arange(len(r["word_src"])), np.diff(r["vote_offsets"].astype(np.int64)))
+    vc = cls[r["vote_feature"]]
+    nF = np.bincount(vc, minlength=3).astype(np.float32)
+    for c in range(3):
+        e_last = e_of_vote[vc == c].max()
+        in_e = e_of_vote == e_last
+        s_e = sum(np.float32((vc[in_e] == cc).sum()) / nF[cc] for cc in sorted(set(vc[in_e])))
+        t3 = (np.float32((vc[in_e] == c).sum()) / nF[c]) / np.float32(s_e)
+        t1 = 1.0 / len(set(e_of_vote[vc == c]))
+        sel = np.nonzero(vc == c)[0][:5]
+        for v_ in sel:
+            m = (e_of_vote == e_of_vote[v_]).sum()
+            np.testing.assert_allclose(r["vote_class_weight"][v_], t1 * (1.0 / m) * t3, rtol=1e-5)
 
 
 # ---- round-2 vectors (kat_checks.py runs the same checks on the HIP path in test_gpu_parity.py) ---------------------------
@@ -303,3 +331,22 @@ def test_knn_rule_truth_table(ora):
 
 def test_maxima_thresholds_and_bestk_vector(ora):
     kat_checks.maxima_thresholds(ora.find_maxima)
+
+
+def test_hough3d_three_bins_vector(ora):
+    kat_checks.hough3d_three_bins(ora.hough3d_maxima)
+
+
+def test_hough3d_properties(ora):
+    rng = np.random.default_rng(9)
+    # two tight blobs of one class far apart -> two maxima near the blob means; a vote outside the space is ignored
+    a = np.array([0.31, -1.07, 0.52]) + 0.02 * rng.normal(size=(40, 3)); b = np.array([-2.2, 1.4, 0.9]) + 0.02 * rng.normal(size=(25, 3))
+    pos = np.concatenate([a, b, [[7.0, 0, 0]]]).astype(np.float32)
+    v = dict(pos=pos, weight=np.ones(len(pos), np.float32), cls=np.ones(len(pos), np.int32), inst=(np.arange(len(pos)) % 3).astype(np.int32))
+    out = ora.hough3d_maxima([0, len(pos)], v, 3, 0.4, rel_threshold=0.3, max_maxima=8)
+    assert out["n"][0] == 2 and (out["cls"][0, :2] == 1).all()
+    np.testing.assert_allclose(out["pos"][0, 0], a.mean(0), atol=0.05)
+    np.testing.assert_allclose(out["pos"][0, 1], b.mean(0), atol=0.05)
+    assert out["weight"][0, 0] > out["weight"][0, 1] and abs(out["weight"][0, :2].sum() - 1) < 1e-6
+    e = ora.hough3d_maxima([0, 0, len(pos)], dict(v, cls=np.full(len(pos), -1, np.int32)), 3, 0.4, max_maxima=4)
+    assert e["n"].tolist() == [0, 0]
