@@ -60,6 +60,61 @@ int ism3d_codebook_get(void* m, float* words, float* vote_xyz, uint32_t* vote_cl
     if (class_sigma) std::memcpy(class_sigma, d.class_sigma.data(), d.class_sigma.size() * 4);
     return (int)d.vote_class.size();
 }
+// installs a codebook from flat arrays (persistence tests without a GPU); optional arrays may be NULL
+int ism3d_codebook_set(void* m, int n_words, int dim, const float* words, const int32_t* word_id, const uint32_t* word_class, const float* word_weight,
+                       const float* word_keypoint, const uint32_t* vote_off, const float* vote_xyz, const float* vote_weight, const float* vote_class_weight,
+                       const uint32_t* vote_class, const uint32_t* vote_instance, const float* vote_bbox_quat, const float* vote_bbox_size,
+                       int n_classes, const float* class_sigma) {
+    GUARD(
+        CodebookData d; d.dim = dim;
+        const size_t nv = vote_off[n_words];
+        d.words.assign(words, words + (size_t)n_words * dim);
+        if (word_id) d.word_id.assign(word_id, word_id + n_words);
+        if (word_class) d.word_class.assign(word_class, word_class + n_words);
+        if (word_weight) d.word_weight.assign(word_weight, word_weight + n_words);
+        if (word_keypoint) d.word_keypoint.assign(word_keypoint, word_keypoint + (size_t)n_words * 3);
+        d.vote_offsets.assign(vote_off, vote_off + n_words + 1);
+        d.vote_xyz.assign(vote_xyz, vote_xyz + nv * 3);
+        if (vote_weight) d.vote_weight.assign(vote_weight, vote_weight + nv);
+        if (vote_class_weight) d.vote_class_weight.assign(vote_class_weight, vote_class_weight + nv);
+        d.vote_class.assign(vote_class, vote_class + nv); d.vote_instance.assign(vote_instance, vote_instance + nv);
+        if (vote_bbox_quat) d.vote_bbox_quat.assign(vote_bbox_quat, vote_bbox_quat + nv * 4);
+        if (vote_bbox_size) d.vote_bbox_size.assign(vote_bbox_size, vote_bbox_size + nv * 3);
+        d.class_sigma.assign(class_sigma, class_sigma + n_classes);
+        const std::string why = d.validate();
+        if (!why.empty()) { g_err = why; return -2; }
+        ((ImplicitShapeModel*)m)->setCodebookData(d, n_classes);
+        return 0;)
+}
+// every persisted table of the codebook; arrays may be NULL. Returns the number of votes; *n_words_out / *dim_out the shape.
+int ism3d_codebook_get_all(void* m, int* n_words_out, int* dim_out, int* n_classes_out, float* words, int32_t* word_id, uint32_t* word_class, float* word_weight,
+                           float* word_keypoint, uint32_t* vote_off, float* vote_xyz, float* vote_weight, float* vote_class_weight, uint32_t* vote_class,
+                           uint32_t* vote_instance, float* vote_bbox_quat, float* vote_bbox_size, float* class_sigma) {
+    const CodebookData& d = ((ImplicitShapeModel*)m)->getCodebook()->data();
+    const int nw = d.numWords();
+    if (n_words_out) *n_words_out = nw;
+    if (dim_out) *dim_out = d.dim;
+    if (n_classes_out) *n_classes_out = (int)d.class_sigma.size();
+    auto cp = [](auto* dst, const auto& v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+    cp(words, d.words); cp(word_id, d.word_id); cp(word_class, d.word_class); cp(word_weight, d.word_weight); cp(word_keypoint, d.word_keypoint);
+    cp(vote_off, d.vote_offsets); cp(vote_xyz, d.vote_xyz); cp(vote_weight, d.vote_weight); cp(vote_class_weight, d.vote_class_weight);
+    cp(vote_class, d.vote_class); cp(vote_instance, d.vote_instance); cp(vote_bbox_quat, d.vote_bbox_quat); cp(vote_bbox_size, d.vote_bbox_size);
+    cp(class_sigma, d.class_sigma);
+    return (int)d.vote_class.size();
+}
+// label maps and the per-class size hints (Voting::forwardBoxesAndRadii) that travel with the model
+int ism3d_set_labels(void* m, int n_classes, const char* const* class_labels, int n_inst, const char* const* inst_labels, const unsigned* inst_to_class) {
+    GUARD(((ImplicitShapeModel*)m)->setLabels(std::vector<std::string>(class_labels, class_labels + n_classes), std::vector<std::string>(inst_labels, inst_labels + n_inst),
+                                             std::vector<unsigned>(inst_to_class, inst_to_class + n_inst)); return 0;)
+}
+int ism3d_get_label(void* m, int which, unsigned id, char* out, int cap) {
+    GUARD(std::string s = ((ImplicitShapeModel*)m)->getLabel(which, id); if ((int)s.size() + 1 > cap) return -2; std::memcpy(out, s.c_str(), s.size() + 1); return (int)s.size();)
+}
+int ism3d_dimensions(void* m, unsigned class_id, float* out4) {     // object radius, median box edge, and their variances; -2 when absent
+    GUARD(return ((ImplicitShapeModel*)m)->getDimensions(class_id, out4) ? 0 : -2;)
+}
+int ism3d_set_dimensions(void* m, unsigned class_id, const float* in4) { GUARD(((ImplicitShapeModel*)m)->setDimensions(class_id, in4); return 0;) }
+
 // detectBatch over concatenated SoA arrays; outputs per object up to max_maxima records sorted by weight
 int ism3d_detect_batch(void* m, int n_obj, const uint32_t* pt_off, const float* x, const float* y, const float* z, const float* nx, const float* ny,
                        const float* nz, const uint32_t* rgba, int max_maxima, int32_t* n_out, float* pos_out, float* weight_out, int32_t* cls_out,

@@ -381,6 +381,25 @@ int ActivationStrategyKnnRule::activateKNN(DeviceSession& s, const ismhip_codebo
 }
 
 // FLANN functors on the host, used by the training statistics only (utils/distance.cpp:33-52)
+// Utils::getRotQuaternion + matrix2Quat (utils.cpp:136-151, 342-380): rows of the matrix are the frame axes; out = (w, x, y, z)
+static void hostRotQuaternion(const float* l, float* out) {
+    const float m[3][3] = {{l[0], l[1], l[2]}, {l[3], l[4], l[5]}, {l[6], l[7], l[8]}};
+    float q[4] = {0.f, 0.f, 0.f, 1.f};
+    const float trace = m[0][0] + m[1][1] + m[2][2];
+    float root;
+    if (trace > 0.0f) {
+        root = sqrtf(trace + 1.0f); q[3] = 0.5f * root; root = 0.5f / root;
+        q[0] = (m[2][1] - m[1][2]) * root; q[1] = (m[0][2] - m[2][0]) * root; q[2] = (m[1][0] - m[0][1]) * root;
+    } else {
+        int i = 0;
+        if (m[1][1] > m[0][0]) i = 1;
+        if (m[2][2] > m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        root = sqrtf((float)((double)(m[i][i] - m[j][j] - m[k][k]) + 1.0)); q[i] = 0.5f * root; root = 0.5f / root;
+        q[3] = (m[k][j] - m[j][k]) * root; q[j] = (m[j][i] + m[i][j]) * root; q[k] = (m[k][i] + m[i][k]) * root;
+    }
+    out[0] = q[3]; out[1] = q[0]; out[2] = q[1]; out[3] = q[2];
+}
 static float hostDistance(int metric, const float* a, const float* b, int n) {
     float result = 0.f;
     if (metric == ISMHIP_METRIC_CHI2) {
@@ -397,7 +416,8 @@ static float hostDistance(int metric, const float* a, const float* b, int n) {
 }
 
 void Codebook::activate(DeviceSession& s, const DeviceFeatures& f, const std::vector<unsigned>& feat_class, const std::vector<unsigned>& feat_instance,
-                        const std::vector<unsigned>& feat_model, const std::vector<std::array<float, 3>>& feat_center, int metric, int n_classes) {
+                        const std::vector<unsigned>& feat_model, const std::vector<std::array<float, 3>>& feat_center,
+                        const std::vector<std::array<float, 3>>& feat_bbox_size, int metric, int n_classes) {
     // codebook.cpp:64-368 for Clustering "None" (one codeword per training feature, clustering_none.cpp:25-35) and KNN activation.
     const uint32_t n = f.n;
     const int D = f.dim;
@@ -408,8 +428,8 @@ void Codebook::activate(DeviceSession& s, const DeviceFeatures& f, const std::ve
     if (k > 4) throw RuntimeException("KNN activation with K > 4 is not built");
     // the whole of Codebook::activate runs on the device (ismhip_train_activate): self-kNN, class sigma^2, K = 1 clean-up,
     // vote CSR, computeWeights and the statistical class weights. Features must be class-major, as train() collects them.
-    std::vector<float> words, centers((size_t)n * 3);
-    s.d2h(words, f.desc, (size_t)n * D);
+    std::vector<float> words, centers((size_t)n * 3), lrf, kx, ky, kz;
+    s.d2h(words, f.desc, (size_t)n * D); s.d2h(lrf, f.lrf, (size_t)n * 9); s.d2h(kx, f.kx, n); s.d2h(ky, f.ky, n); s.d2h(kz, f.kz, n);
     for (uint32_t i = 0; i < n; ++i) for (int d = 0; d < 3; ++d) centers[(size_t)i * 3 + d] = feat_center[i][d];
     const bool clean_up = is_knn && k == 1;                     // codebook.cpp:201-224
     int32_t n_words = 0;
@@ -434,11 +454,17 @@ void Codebook::activate(DeviceSession& s, const DeviceFeatures& f, const std::ve
         out.words.insert(out.words.end(), words.begin() + (size_t)w * D, words.begin() + (size_t)(w + 1) * D);
         out.word_weight.push_back(1.0f);
         out.word_class.push_back(feat_class[w]);                 // Codeword::getClassId: class of the feature the word was made from
+        out.word_id.push_back((int32_t)w); out.word_num_features.push_back(1);          // clustering_none.cpp:25-35: one feature per codeword
+        out.word_keypoint.push_back(kx[w]); out.word_keypoint.push_back(ky[w]); out.word_keypoint.push_back(kz[w]);
         for (uint32_t v = vote_off[e]; v < vote_off[e + 1]; ++v) {
             const uint32_t fi = vote_feature[v];
             out.vote_xyz.push_back(vote_xyz[(size_t)v * 3]); out.vote_xyz.push_back(vote_xyz[(size_t)v * 3 + 1]); out.vote_xyz.push_back(vote_xyz[(size_t)v * 3 + 2]);
             out.vote_class.push_back(feat_class[fi]); out.vote_instance.push_back(feat_instance[fi]);
             out.vote_weight.push_back(vote_weight[v]); out.vote_class_weight.push_back(vote_cw[v]);
+            // addCodeword (codeword_distribution.cpp:63-70): the box in the keypoint's frame, rotQuat = box.rotQuat * conj(q(LRF)); AABB boxes carry (1,0,0,0)
+            float q[4]; hostRotQuaternion(&lrf[(size_t)fi * 9], q);
+            out.vote_bbox_quat.push_back(q[0]); out.vote_bbox_quat.push_back(-q[1]); out.vote_bbox_quat.push_back(-q[2]); out.vote_bbox_quat.push_back(-q[3]);
+            for (int d = 0; d < 3; ++d) out.vote_bbox_size.push_back(feat_bbox_size[fi][d]);
         }
         out.vote_offsets.push_back((uint32_t)out.vote_class.size());
     }
@@ -472,30 +498,183 @@ void Codebook::castVotes(DeviceSession& s, const DeviceFeatures& f, int metric, 
     s.n_classes = (int)m_data.class_sigma.size();
 }
 
-static void writeVec(std::ostream& os, const void* p, size_t bytes) { uint64_t n = bytes; os.write((const char*)&n, 8); os.write((const char*)p, bytes); }
-template <typename T> static void writeVec(std::ostream& os, const std::vector<T>& v) { writeVec(os, v.data(), v.size() * sizeof(T)); }
-template <typename T> static bool readVec(std::istream& is, std::vector<T>& v) {
-    uint64_t n = 0; is.read((char*)&n, 8);
-    if (!is || n % sizeof(T)) return false;
-    v.resize(n / sizeof(T));
-    is.read((char*)v.data(), n);
-    return (bool)is;
+std::string CodebookData::validate() const {
+    const size_t nw = (size_t)numWords(), nv = vote_offsets.empty() ? 0 : vote_offsets.back();
+    if (dim <= 0 || words.size() % (size_t)dim) return "descriptor length does not divide the word array";
+    if (vote_offsets.size() != nw + 1 || vote_offsets[0] != 0) return "vote offsets do not match the number of codewords";
+    for (size_t i = 0; i < nw; ++i) if (vote_offsets[i + 1] < vote_offsets[i]) return "vote offsets not monotone";
+    if (vote_xyz.size() != nv * 3 || vote_class.size() != nv || vote_instance.size() != nv) return "vote arrays do not match the vote offsets";
+    if (!vote_weight.empty() && vote_weight.size() != nv) return "vote weights do not match the vote offsets";
+    if (!vote_class_weight.empty() && vote_class_weight.size() != nv) return "class weights do not match the vote offsets";
+    if (!vote_bbox_quat.empty() && vote_bbox_quat.size() != nv * 4) return "bounding-box quaternions do not match the vote offsets";
+    if (!vote_bbox_size.empty() && vote_bbox_size.size() != nv * 3) return "bounding-box sizes do not match the vote offsets";
+    if (!word_weight.empty() && word_weight.size() != nw) return "word weights do not match the number of codewords";
+    if (!word_class.empty() && word_class.size() != nw) return "word classes do not match the number of codewords";
+    if (class_sigma.empty()) return "no class sigmas";
+    for (uint32_t c : vote_class) if (c >= class_sigma.size()) return "vote class id beyond the class sigmas";
+    return "";
 }
-void Codebook::save(std::ostream& os) const {
+
+// Codebook::iSaveData (codebook.cpp:739-761) -> CodewordDistribution::iSaveData (codeword_distribution.cpp:349-391) ->
+// Codeword::iSaveData (codeword.cpp:71-83), field by field
+void Codebook::save(BoostBinaryOArchive& oa) const {
     const CodebookData& d = m_data;
-    int32_t dim = d.dim; os.write((const char*)&dim, 4);
-    writeVec(os, d.words); writeVec(os, d.word_weight); writeVec(os, d.vote_offsets); writeVec(os, d.vote_xyz); writeVec(os, d.vote_weight);
-    writeVec(os, d.vote_class_weight); writeVec(os, d.vote_class); writeVec(os, d.vote_instance); writeVec(os, d.vote_bbox_quat);
-    writeVec(os, d.vote_bbox_size); writeVec(os, d.class_sigma);
+    const int nw = d.numWords();
+    oa << nw;                                                                     // distribution_size
+    for (int w = 0; w < nw; ++w) {
+        // Codeword: m_id, m_numFeatures, m_weight, m_data, m_class_id, keypoint xyz
+        oa << (d.word_id.empty() ? w : (int)d.word_id[w]) << (d.word_num_features.empty() ? 1 : (int)d.word_num_features[w])
+           << (d.word_weight.empty() ? 1.0f : d.word_weight[w]);
+        oa << std::vector<float>(d.words.begin() + (size_t)w * d.dim, d.words.begin() + (size_t)(w + 1) * d.dim);
+        const uint32_t v0 = d.vote_offsets[w], v1 = d.vote_offsets[w + 1];
+        oa << (int)(d.word_class.empty() ? (v1 > v0 ? d.vote_class[v0] : 0u) : d.word_class[w]);
+        for (int k = 0; k < 3; ++k) oa << (d.word_keypoint.empty() ? 0.0f : d.word_keypoint[(size_t)w * 3 + k]);
+        // distribution: votes, m_weights, m_class_ids, m_instance_ids, m_classWeights (std::map: ascending class), bounding boxes
+        oa << (int)(v1 - v0);
+        for (uint32_t v = v0; v < v1; ++v) oa << d.vote_xyz[(size_t)v * 3] << d.vote_xyz[(size_t)v * 3 + 1] << d.vote_xyz[(size_t)v * 3 + 2];
+        oa << (d.vote_weight.empty() ? std::vector<float>(v1 - v0, 1.0f) : std::vector<float>(d.vote_weight.begin() + v0, d.vote_weight.begin() + v1));
+        oa << std::vector<unsigned>(d.vote_class.begin() + v0, d.vote_class.begin() + v1);
+        oa << std::vector<unsigned>(d.vote_instance.begin() + v0, d.vote_instance.begin() + v1);
+        std::map<unsigned, float> cw;
+        for (uint32_t v = v0; v < v1; ++v) cw[d.vote_class[v]] = d.vote_class_weight.empty() ? 1.0f : d.vote_class_weight[v];
+        oa << (int)cw.size();
+        for (auto& kv : cw) oa << (int)kv.first << kv.second;
+        oa << (int)(v1 - v0);
+        for (uint32_t v = v0; v < v1; ++v) {
+            for (int k = 0; k < 4; ++k) oa << (d.vote_bbox_quat.empty() ? (k == 0 ? 1.0f : 0.0f) : d.vote_bbox_quat[(size_t)v * 4 + k]);
+            for (int k = 0; k < 3; ++k) oa << (d.vote_bbox_size.empty() ? 0.0f : d.vote_bbox_size[(size_t)v * 3 + k]);
+        }
+    }
+    // m_classSigmas (std::map<unsigned, float>): only classes that were trained have an entry
+    int n_sig = 0;
+    for (float sg : d.class_sigma) if (sg == sg) ++n_sig;      // NaN marks a class id that was never trained: no map entry
+    oa << n_sig;
+    for (size_t c = 0; c < d.class_sigma.size(); ++c) if (d.class_sigma[c] == d.class_sigma[c]) oa << (int)c << d.class_sigma[c];
+    // m_activationStrategy->saveData: nothing (json_object.cpp:256-259)
 }
-bool Codebook::load(std::istream& is) {
-    CodebookData d; int32_t dim = 0; is.read((char*)&dim, 4); d.dim = dim;
-    bool ok = readVec(is, d.words) && readVec(is, d.word_weight) && readVec(is, d.vote_offsets) && readVec(is, d.vote_xyz) && readVec(is, d.vote_weight) &&
-              readVec(is, d.vote_class_weight) && readVec(is, d.vote_class) && readVec(is, d.vote_instance) && readVec(is, d.vote_bbox_quat) &&
-              readVec(is, d.vote_bbox_size) && readVec(is, d.class_sigma);
-    if (!ok) return false;
+
+bool Codebook::load(BoostBinaryIArchive& ia) {
+    CodebookData d;
+    int nw = 0; ia >> nw;
+    if (!ia.ok() || nw < 0 || !ia.plausible((uint64_t)nw, 60)) return false;
+    LOG_INFO("Loading codebook with size: " << nw);
+    std::mt19937 rng(0x5EED);                                  // UseRandomCodebook (codebook.cpp:821-829), seeded instead of std::random_device
+    std::uniform_int_distribution<int> pick(0, nw);
+    std::map<unsigned, float> sig_map;
+    for (int w = 0; w < nw && ia.ok(); ++w) {
+        int id = 0, nf = 0, cls = 0; float weight = 0.f, kp[3] = {0, 0, 0};
+        std::vector<float> data, weights; std::vector<unsigned> class_ids, instance_ids;
+        ia >> id >> nf >> weight >> data >> cls >> kp[0] >> kp[1] >> kp[2];
+        int votes = 0; ia >> votes;
+        if (!ia.ok() || votes < 0 || !ia.plausible((uint64_t)votes, 12)) return false;
+        std::vector<float> vxyz((size_t)votes * 3);
+        for (float& x : vxyz) ia >> x;
+        ia >> weights >> class_ids >> instance_ids;
+        int ncw = 0; ia >> ncw;
+        if (!ia.ok() || ncw < 0 || !ia.plausible((uint64_t)ncw, 8)) return false;
+        std::map<unsigned, float> cw;
+        for (int i = 0; i < ncw; ++i) { int c = 0; float x = 0.f; ia >> c >> x; cw[(unsigned)c] = x; }
+        int nbb = 0; ia >> nbb;
+        if (!ia.ok() || nbb < 0 || !ia.plausible((uint64_t)nbb, 28)) return false;
+        std::vector<float> bq((size_t)nbb * 4), bs((size_t)nbb * 3);
+        for (int i = 0; i < nbb; ++i) { for (int k = 0; k < 4; ++k) ia >> bq[(size_t)i * 4 + k]; for (int k = 0; k < 3; ++k) ia >> bs[(size_t)i * 3 + k]; }
+        if (!ia.ok()) return false;
+        if ((int)weights.size() != votes || (int)class_ids.size() != votes || (int)instance_ids.size() != votes || nbb != votes) { ia.fail("codeword distribution arrays of unequal length"); return false; }
+        if (d.dim == 0) d.dim = (int)data.size();
+        if ((int)data.size() != d.dim || d.dim == 0) { ia.fail("codewords of different descriptor length"); return false; }
+        if (m_use_random_codebook && pick(rng) > m_random_codebook_factor * nw) continue;      // skip features while loading (:821-829)
+        d.words.insert(d.words.end(), data.begin(), data.end());
+        d.word_id.push_back(id); d.word_num_features.push_back(nf); d.word_weight.push_back(weight); d.word_class.push_back((uint32_t)cls);
+        d.word_keypoint.insert(d.word_keypoint.end(), kp, kp + 3);
+        d.vote_xyz.insert(d.vote_xyz.end(), vxyz.begin(), vxyz.end());
+        d.vote_weight.insert(d.vote_weight.end(), weights.begin(), weights.end());
+        d.vote_class.insert(d.vote_class.end(), class_ids.begin(), class_ids.end());
+        d.vote_instance.insert(d.vote_instance.end(), instance_ids.begin(), instance_ids.end());
+        for (unsigned c : class_ids) { auto it = cw.find(c); d.vote_class_weight.push_back(it == cw.end() ? 1.0f : it->second); }   // castVotes: 1 + warning when missing (:97-104)
+        d.vote_bbox_quat.insert(d.vote_bbox_quat.end(), bq.begin(), bq.end()); d.vote_bbox_size.insert(d.vote_bbox_size.end(), bs.begin(), bs.end());
+        d.vote_offsets.push_back((uint32_t)d.vote_class.size());
+    }
+    int n_sig = 0; ia >> n_sig;
+    if (!ia.ok() || n_sig < 0 || !ia.plausible((uint64_t)n_sig, 8)) return false;
+    unsigned max_class = 0;
+    for (int i = 0; i < n_sig; ++i) { int c = 0; float sg = 0.f; ia >> c >> sg; if (c < 0 || c > (1 << 20)) { ia.fail("class id out of range"); return false; } sig_map[(unsigned)c] = sg; max_class = std::max(max_class, (unsigned)c); }
+    for (unsigned c : d.vote_class) max_class = std::max(max_class, c);
+    if (max_class > (1u << 20)) { ia.fail("class id out of range"); return false; }
+    d.class_sigma.assign((size_t)max_class + 1, 1.0f);          // castVotes uses sigma 1 (+ warning) for a class without an entry (:108-117)
+    for (auto& kv : sig_map) d.class_sigma[kv.first] = kv.second;
+    if (!ia.ok()) return false;
+    const std::string why = d.validate();
+    if (!why.empty()) { ia.fail("inconsistent codebook: " + why); return false; }
+    if (m_use_random_codebook) LOG_INFO("Reduced codebook size: " << d.numWords());
     setData(d);
     return true;
+}
+
+// Voting::forwardBoxesAndRadii (voting.cpp:496-551)
+void Voting::forwardBoxesAndRadii(const std::map<unsigned, std::vector<std::array<float, 3>>>& box_sizes, const std::map<unsigned, std::vector<float>>& object_radii) {
+    m_dimensions_map.clear(); m_variance_map.clear();
+    for (auto& it : box_sizes) {
+        const unsigned classId = it.first;
+        float median_box_dim = 0, median_box_dim_squared = 0;
+        for (auto& size : it.second) {
+            const float mx = std::max(size[0], std::max(size[1], size[2])), mn = std::min(size[0], std::min(size[1], size[2]));
+            float med = size[0];                               // "find the other value" (:512-520)
+            for (int i = 1; i < 3; ++i) if (med == mx || med == mn) med = size[i];
+            median_box_dim += med; median_box_dim_squared += med * med;
+        }
+        float class_radii = 0, class_radii_squared = 0;
+        auto rit = object_radii.find(classId);
+        if (rit != object_radii.end()) for (float r : rit->second) { class_radii += r; class_radii_squared += r * r; }
+        const float n = (float)it.second.size();
+        median_box_dim /= n; median_box_dim_squared /= n; class_radii /= n; class_radii_squared /= n;
+        m_dimensions_map[classId] = {class_radii, median_box_dim};
+        m_variance_map[classId] = {class_radii_squared - class_radii * class_radii, median_box_dim_squared - median_box_dim * median_box_dim};
+    }
+}
+// MaximaHandler::getSearchDistForClass (maxima_handler.cpp:509-521)
+std::vector<float> Voting::searchDistPerClass(float radius, int n_classes) const {
+    if (m_radiusType == "Config" || m_radiusType == "Fixed") return {};
+    const bool first = m_radiusType == "FirstDim" || m_radiusType == "ObjectRadius", second = m_radiusType == "SecondDim" || m_radiusType == "BoundingBoxMedian";
+    if (!first && !second) { LOG_ERROR("Invalid radius type: " << m_radiusType << "! Using config value instead."); return {}; }
+    std::vector<float> out((size_t)n_classes, radius);
+    for (int c = 0; c < n_classes; ++c) {
+        auto it = m_dimensions_map.find((unsigned)c);
+        if (it == m_dimensions_map.end()) continue;            // a class that was never trained casts no votes either
+        out[c] = (first ? it->second.first : it->second.second) * m_radiusFactor;
+    }
+    return out;
+}
+void Voting::save(BoostBinaryOArchive& oa) const {
+    oa << (unsigned)m_dimensions_map.size();
+    for (auto& it : m_dimensions_map) oa << it.first << it.second.first << it.second.second;
+    oa << (unsigned)m_variance_map.size();
+    for (auto& it : m_variance_map) oa << it.first << it.second.first << it.second.second;
+    oa << 0u;                                                  // global features: none (out of scope)
+}
+bool Voting::load(BoostBinaryIArchive& ia) {
+    m_dimensions_map.clear(); m_variance_map.clear();
+    unsigned n = 0; ia >> n;
+    if (!ia.plausible(n, 12)) return false;
+    for (unsigned i = 0; i < n; ++i) { unsigned c = 0; float a = 0, b = 0; ia >> c >> a >> b; m_dimensions_map[c] = {a, b}; }
+    ia >> n;
+    if (!ia.plausible(n, 12)) return false;
+    for (unsigned i = 0; i < n; ++i) { unsigned c = 0; float a = 0, b = 0; ia >> c >> a >> b; m_variance_map[c] = {a, b}; }
+    // global features must be deserialised completely even when unused (voting.cpp:652-705); they are read and dropped
+    unsigned n_glob = 0; ia >> n_glob;
+    if (!ia.plausible(n_glob, 8)) return false;
+    for (unsigned i = 0; i < n_glob && ia.ok(); ++i) {
+        unsigned classId = 0, clouds = 0; ia >> classId >> clouds;
+        if (!ia.plausible(clouds, 4)) return false;
+        for (unsigned j = 0; j < clouds && ia.ok(); ++j) {
+            unsigned feats = 0; ia >> feats;
+            if (!ia.plausible(feats, 52)) return false;
+            for (unsigned k = 0; k < feats && ia.ok(); ++k) {
+                float rf; for (int r = 0; r < 9; ++r) ia >> rf;
+                std::vector<float> desc; float radius; unsigned inst; ia >> desc >> radius >> inst;
+            }
+        }
+    }
+    return ia.ok();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -518,7 +697,6 @@ void Voting::clear() {}
 std::vector<std::vector<VotingMaximum>> Voting::findMaxima(DeviceSession& s) {
     if (m_use_global_features) throw RuntimeException("UseGlobalFeatures is out of scope of the MI355X path (SURVEY §2 row 10)");
     if (m_vote_filtering_with_ransac) throw RuntimeException("RansacVoteFiltering is not built on the MI355X path");
-    if (m_radiusType != "Config" && m_radiusType != "Fixed") throw RuntimeException("BinOrBandwidthType \"" + m_radiusType + "\" is not built (only \"Config\")");
     if (m_max_filter_type != "None") throw RuntimeException("MaxFilterType \"" + m_max_filter_type + "\" is not built (only \"None\")");
     if (m_single_object_mode && m_max_type_param != "None" && m_max_type_param != "Default")
         throw RuntimeException("SingleObjectMaxType \"" + m_max_type_param + "\" is not built (only \"None\"/\"Default\")");
@@ -540,7 +718,8 @@ void VotingMeanShift::iFindMaxima(DeviceSession& s, std::vector<std::vector<Voti
     const int C = std::max(1, s.n_classes);
     const int M = 32;
     ismhip_maxima_params P;
-    P.n_classes = C; P.class_bandwidth_h = nullptr; P.bandwidth = m_bandwidth; P.threshold = m_threshold; P.max_iter = m_maxIter;
+    const std::vector<float> class_bw = searchDistPerClass(m_bandwidth, C);      // voting_mean_shift.cpp:46-49
+    P.n_classes = C; P.class_bandwidth_h = class_bw.empty() ? nullptr : class_bw.data(); P.bandwidth = m_bandwidth; P.threshold = m_threshold; P.max_iter = m_maxIter;
     P.kernel = m_kernel == "Uniform" ? ISMHIP_KERNEL_UNIFORM : ISMHIP_KERNEL_GAUSSIAN;
     P.suppression = m_maxima_suppression_type == "Average" ? ISMHIP_SUPPRESS_AVERAGE : (m_maxima_suppression_type == "Suppress" ? ISMHIP_SUPPRESS_SUPPRESS : ISMHIP_SUPPRESS_NONE);
     P.min_votes_threshold = m_minVotesThreshold; P.min_threshold = m_minThreshold; P.best_k = m_bestK; P.max_maxima = M;
@@ -584,7 +763,10 @@ void VotingHough3D::iFindMaxima(DeviceSession& s, std::vector<std::vector<Voting
     P.n_classes = C;
     for (int d = 0; d < 3; ++d) { P.min_coord[d] = (float)m_minCoord[d]; P.max_coord[d] = (float)m_maxCoord[d]; }
     // :45-47: MaximaHandler::setRadius(BinSize[0] / 2); the bins become cubes of edge 2 * getSearchDistForClass (= BinSize[0] with "Config")
-    P.bin_size = 2.0f * (float)(m_binSize[0] / 2); P.class_bin_h = nullptr;
+    P.bin_size = 2.0f * (float)(m_binSize[0] / 2);
+    std::vector<float> class_bin = searchDistPerClass((float)(m_binSize[0] / 2), C);
+    for (float& b : class_bin) b *= 2.0f;
+    P.class_bin_h = class_bin.empty() ? nullptr : class_bin.data();
     P.use_interpolation = m_useInterpolation ? 1 : 0; P.rel_threshold = m_relThreshold;
     P.min_votes_threshold = m_minVotesThreshold; P.min_threshold = m_minThreshold; P.best_k = m_bestK;
     MaximaBuffers B; P.max_maxima = B.M; B.reserve(s.n_obj, C);
@@ -681,33 +863,48 @@ bool ImplicitShapeModel::iChildConfigsFromJson(const Json& c) {   // :1085-1142
     return m_codebook && m_keypoints_detector && m_feature_descriptor && m_voting;
 }
 
-void ImplicitShapeModel::iSaveData(std::ostream& os) const {      // :1144-1179 (own container, not Boost's archive: DESIGN.md §7)
-    const char magic[8] = {'I', 'S', 'M', 'D', 'A', 'M', 'D', '1'};
-    os.write(magic, 8);
-    int32_t nc = m_n_classes; os.write((const char*)&nc, 4);
-    m_codebook->save(os);
-    auto writeMap = [&](const std::map<unsigned, std::string>& m) {
-        uint32_t n = (uint32_t)m.size(); os.write((const char*)&n, 4);
-        for (auto& kv : m) { uint32_t k = kv.first, l = (uint32_t)kv.second.size(); os.write((const char*)&k, 4); os.write((const char*)&l, 4); os.write(kv.second.data(), l); }
-    };
-    writeMap(m_class_labels); writeMap(m_instance_labels);
-    uint32_t n = (uint32_t)m_instance_to_class_map.size(); os.write((const char*)&n, 4);
-    for (auto& kv : m_instance_to_class_map) { uint32_t a = kv.first, b = kv.second; os.write((const char*)&a, 4); os.write((const char*)&b, 4); }
+void ImplicitShapeModel::iSaveData(std::ostream& os) const {      // :1144-1179, as a Boost binary archive (boost_archive.h)
+    BoostBinaryOArchive oa(os);
+    oa << (unsigned)m_instance_to_class_map.size();
+    for (auto& kv : m_instance_to_class_map) oa << kv.first << kv.second;
+    m_codebook->save(oa);
+    // keypoints, features, global features, clustering: JSONObject::iSaveData writes nothing (json_object.cpp:256-259)
+    m_voting->save(oa);
+    // feature ranking: nothing
+    oa << (unsigned)m_class_labels.size();
+    for (auto& kv : m_class_labels) oa << kv.second;
+    oa << (unsigned)m_instance_labels.size();
+    for (auto& kv : m_instance_labels) oa << kv.second;
 }
 bool ImplicitShapeModel::iLoadData(std::istream& is) {            // :1181-1237
-    char magic[8]; is.read(magic, 8);
-    if (!is || std::memcmp(magic, "ISMDAMD1", 8) != 0) { LOG_ERROR("not an ISMD-AMD1 data file (Boost binary archives of the reference are not readable yet)"); return false; }
-    int32_t nc = 0; is.read((char*)&nc, 4); m_n_classes = nc;
-    if (!m_codebook->load(is)) return false;
-    auto readMap = [&](std::map<unsigned, std::string>& m) {
-        uint32_t n = 0; is.read((char*)&n, 4);
-        for (uint32_t i = 0; i < n && is; ++i) { uint32_t k = 0, l = 0; is.read((char*)&k, 4); is.read((char*)&l, 4); std::string s(l, ' '); is.read(&s[0], l); m[k] = s; }
-    };
-    readMap(m_class_labels); readMap(m_instance_labels);
-    uint32_t n = 0; is.read((char*)&n, 4);
-    for (uint32_t i = 0; i < n && is; ++i) { uint32_t a = 0, b = 0; is.read((char*)&a, 4); is.read((char*)&b, 4); m_instance_to_class_map[a] = b; }
-    return (bool)is;
+    BoostBinaryIArchive ia(is);
+    if (!ia.ok()) { LOG_ERROR("could not read the data file: " << ia.error()); return false; }
+    unsigned size = 0; ia >> size;
+    if (!ia.plausible(size, 8)) { LOG_ERROR("could not read the data file: " << ia.error()); return false; }
+    m_instance_to_class_map.clear();
+    for (unsigned i = 0; i < size; ++i) { unsigned a = 0, b = 0; ia >> a >> b; m_instance_to_class_map.insert({a, b}); }
+    if (!m_codebook->load(ia) || !m_voting->load(ia)) { LOG_ERROR("could not load child objects: " << ia.error()); return false; }
+    m_n_classes = (int)m_codebook->data().class_sigma.size();
+    ia >> size;
+    if (!ia.plausible(size, 8)) { LOG_ERROR("could not read the data file: " << ia.error()); return false; }
+    m_class_labels.clear();
+    for (unsigned i = 0; i < size; ++i) { std::string l; ia >> l; m_class_labels.insert({i, l}); }
+    ia >> size;
+    if (!ia.plausible(size, 8)) { LOG_ERROR("could not read the data file: " << ia.error()); return false; }
+    m_instance_labels.clear();
+    for (unsigned i = 0; i < size; ++i) { std::string l; ia >> l; m_instance_labels.insert({i, l}); }
+    if (!ia.ok()) { LOG_ERROR("could not read the data file: " << ia.error()); return false; }
+    return true;
 }
+
+bool ImplicitShapeModel::getDimensions(unsigned class_id, float* out4) const {
+    auto it = m_voting->getDimensionsMap().find(class_id);
+    auto iv = m_voting->getVarianceMap().find(class_id);
+    if (it == m_voting->getDimensionsMap().end() || iv == m_voting->getVarianceMap().end()) return false;
+    out4[0] = it->second.first; out4[1] = it->second.second; out4[2] = iv->second.first; out4[3] = iv->second.second;
+    return true;
+}
+void ImplicitShapeModel::setDimensions(unsigned class_id, const float* in4) { m_voting->setDimensions(class_id, in4[0], in4[1], in4[2], in4[3]); }
 
 DeviceSession& ImplicitShapeModel::session() {
     if (!m_session) m_session.reset(new DeviceSession(m_device));
@@ -817,7 +1014,8 @@ void ImplicitShapeModel::train() {                // :252-500
     // features in chunks of objects, gathered on the host as one DeviceFeatures for activation
     auto all = std::make_shared<DeviceFeatures>();
     std::vector<float> hdesc, hlrf, hkx, hky, hkz;
-    std::vector<unsigned> fclass, finst, fmodel; std::vector<std::array<float, 3>> fcenter;
+    std::vector<unsigned> fclass, finst, fmodel; std::vector<std::array<float, 3>> fcenter, fbox;
+    std::map<unsigned, std::vector<std::array<float, 3>>> box_sizes; std::map<unsigned, std::vector<float>> object_radii;
     const size_t chunk = 32;
     const int D = m_feature_descriptor->getDescriptorLength();
     for (size_t b = 0; b < clouds.size(); b += chunk) {
@@ -836,16 +1034,29 @@ void ImplicitShapeModel::train() {                // :252-500
                 mn[0] = std::min(mn[0], c.x[i]); mx[0] = std::max(mx[0], c.x[i]); mn[1] = std::min(mn[1], c.y[i]); mx[1] = std::max(mx[1], c.y[i]);
                 mn[2] = std::min(mn[2], c.z[i]); mx[2] = std::max(mx[2], c.z[i]);
             }
-            const std::array<float, 3> center = {(mn[0] + mx[0]) * 0.5f, (mn[1] + mx[1]) * 0.5f, (mn[2] + mx[2]) * 0.5f};
+            // Utils::computeAABB (utils.cpp:222-233): size = max - min, position = min + size / 2
+            const std::array<float, 3> bsize = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+            const std::array<float, 3> center = {mn[0] + bsize[0] / 2, mn[1] + bsize[1] / 2, mn[2] + bsize[2] / 2};
+            // Utils::computeCloudRadius (utils.cpp:302-321): largest distance to the centroid (pcl::compute3DCentroid into a Vector4f)
+            float cs[3] = {0, 0, 0};
+            for (size_t i = 0; i < c.size(); ++i) { cs[0] += c.x[i]; cs[1] += c.y[i]; cs[2] += c.z[i]; }
+            for (int d = 0; d < 3; ++d) cs[d] /= (float)c.size();
+            float radius = 0.f;
+            for (size_t i = 0; i < c.size(); ++i) {
+                const float dx = c.x[i] - cs[0], dy = c.y[i] - cs[1], dz = c.z[i] - cs[2];
+                radius = std::max(radius, std::sqrt(dx * dx + dy * dy + dz * dz));
+            }
+            box_sizes[obj_class[b + o]].push_back(bsize); object_radii[obj_class[b + o]].push_back(radius);
             const uint32_t cnt = f->off[o + 1] - f->off[o];
             fclass.insert(fclass.end(), cnt, obj_class[b + o]); finst.insert(finst.end(), cnt, obj_inst[b + o]);
-            fmodel.insert(fmodel.end(), cnt, (unsigned)(b + o)); fcenter.insert(fcenter.end(), cnt, center);
+            fmodel.insert(fmodel.end(), cnt, (unsigned)(b + o)); fcenter.insert(fcenter.end(), cnt, center); fbox.insert(fbox.end(), cnt, bsize);
         }
     }
     all->dim = D; all->n = (uint32_t)fclass.size();
     DeviceSession::h2d(all->desc, hdesc); DeviceSession::h2d(all->lrf, hlrf); DeviceSession::h2d(all->kx, hkx); DeviceSession::h2d(all->ky, hky); DeviceSession::h2d(all->kz, hkz);
     LOG_INFO("activating codewords with " << all->n << " training features");
-    m_codebook->activate(s, *all, fclass, finst, fmodel, fcenter, met, m_n_classes);
+    m_voting->forwardBoxesAndRadii(box_sizes, object_radii);     // :433: bandwidth hints per class, persisted with the model
+    m_codebook->activate(s, *all, fclass, finst, fmodel, fcenter, fbox, met, m_n_classes);
     LOG_INFO("training done");
 }
 

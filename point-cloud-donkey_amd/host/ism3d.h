@@ -23,6 +23,7 @@
 
 #include "../../include/ismhip.h"
 #include "json.h"
+#include "boost_archive.h"
 
 namespace ism3d {
 
@@ -256,8 +257,13 @@ struct CodebookData {          // host copy of what Codebook::iSaveData persists
     std::vector<float> vote_xyz, vote_weight, vote_class_weight, vote_bbox_quat, vote_bbox_size;
     std::vector<uint32_t> vote_class, vote_instance;
     std::vector<uint32_t> word_class;      // Codeword::getClassId per word (empty: class of the word's first vote)
+    std::vector<int32_t> word_id;          // Codeword::getId per word, ascending (empty: the row index)
+    std::vector<int32_t> word_num_features;// Codeword::getNumFeatures (empty: 1)
+    std::vector<float> word_keypoint;      // [n_words*3] Codeword::getKeypoint (empty: 0)
     std::vector<float> class_sigma;
     int numWords() const { return dim ? (int)(words.size() / dim) : 0; }
+    // consistency of the arrays with each other (a data file is untrusted input); empty string = fine
+    std::string validate() const;
 };
 
 class Voting;
@@ -268,7 +274,8 @@ public:
     std::string getType() const override { return "Codebook"; }
     // training: Codebook::activate (codebook.cpp:64-368) for Clustering "None": one codeword per feature
     void activate(DeviceSession& s, const DeviceFeatures& f, const std::vector<unsigned>& feat_class, const std::vector<unsigned>& feat_instance,
-                  const std::vector<unsigned>& feat_model, const std::vector<std::array<float, 3>>& feat_center, int metric, int n_classes);
+                  const std::vector<unsigned>& feat_model, const std::vector<std::array<float, 3>>& feat_center,
+                  const std::vector<std::array<float, 3>>& feat_bbox_size, int metric, int n_classes);
     // detection: Codebook::castVotes (codebook.cpp:403-555): activate every feature, emit the votes into the voting space
     void castVotes(DeviceSession& s, const DeviceFeatures& f, int metric, Voting& voting) const;
     bool isEmpty() const { return m_data.numWords() == 0; }
@@ -277,8 +284,8 @@ public:
     const CodebookData& data() const { return m_data; }
     void setData(const CodebookData& d) { m_data = d; m_dirty = true; }
     const ActivationStrategy* getActivationStrategy() const { return m_activationStrategy.get(); }
-    void save(std::ostream& os) const;
-    bool load(std::istream& is);
+    void save(BoostBinaryOArchive& oa) const;     // Codebook::iSaveData (codebook.cpp:739-761)
+    bool load(BoostBinaryIArchive& ia);           // Codebook::iLoadData (codebook.cpp:763-950)
 protected:
     Json iChildConfigsToJson() const override;
     bool iChildConfigsFromJson(const Json&) override;
@@ -303,7 +310,17 @@ public:
     std::vector<std::vector<VotingMaximum>> findMaxima(DeviceSession& s);
     void clear();
     bool isSingleObjectMode() const { return m_single_object_mode; }
+    // Voting::forwardBoxesAndRadii (voting.cpp:496-551): per class (mean object radius, mean median box edge) and their variances
+    void forwardBoxesAndRadii(const std::map<unsigned, std::vector<std::array<float, 3>>>& box_sizes, const std::map<unsigned, std::vector<float>>& object_radii);
+    const std::map<unsigned, std::pair<float, float>>& getDimensionsMap() const { return m_dimensions_map; }
+    const std::map<unsigned, std::pair<float, float>>& getVarianceMap() const { return m_variance_map; }
+    void setDimensions(unsigned class_id, float radius, float box, float radius_var, float box_var) { m_dimensions_map[class_id] = {radius, box}; m_variance_map[class_id] = {radius_var, box_var}; }
+    void save(BoostBinaryOArchive& oa) const;     // Voting::iSaveData (voting.cpp:559-614)
+    bool load(BoostBinaryIArchive& ia);           // Voting::iLoadData (voting.cpp:616-734)
 protected:
+    // MaximaHandler::getSearchDistForClass (maxima_handler.cpp:509-521) for every class; empty = the configured radius for all
+    std::vector<float> searchDistPerClass(float radius, int n_classes) const;
+    std::map<unsigned, std::pair<float, float>> m_dimensions_map, m_variance_map;
     friend class Codebook;
     virtual void iFindMaxima(DeviceSession& s, std::vector<std::vector<VotingMaximum>>& out) = 0;
     // device outputs of ismhip_find_maxima / ismhip_hough3d_maxima -> VotingMaximum lists
@@ -378,6 +395,16 @@ public:
     bool isInstancePrimaryLabel() { return m_instance_labels_primary; }
     const std::map<std::string, double>& getProcessingTimes() const { return m_processing_times; }
     int numClasses() const { return m_n_classes; }
+    // test / tooling access to what travels in the data file
+    void setCodebookData(const CodebookData& d, int n_classes) { m_codebook->setData(d); m_n_classes = n_classes; }
+    void setLabels(const std::vector<std::string>& cls, const std::vector<std::string>& inst, const std::vector<unsigned>& inst_to_class) {
+        m_class_labels.clear(); m_instance_labels.clear(); m_instance_to_class_map.clear();
+        for (size_t i = 0; i < cls.size(); ++i) m_class_labels[(unsigned)i] = cls[i];
+        for (size_t i = 0; i < inst.size(); ++i) { m_instance_labels[(unsigned)i] = inst[i]; m_instance_to_class_map[(unsigned)i] = inst_to_class[i]; }
+    }
+    std::string getLabel(int which, unsigned id) const { const auto& m = which == 0 ? m_class_labels : m_instance_labels; auto it = m.find(id); return it == m.end() ? std::string() : it->second; }
+    bool getDimensions(unsigned class_id, float* out4) const;
+    void setDimensions(unsigned class_id, const float* in4);
     void setDevice(int device) { m_device = device; }
 
     static std::shared_ptr<PointCloud> loadPointCloud(const std::string& file);

@@ -78,6 +78,50 @@ class Model:
         nv = self.L.ism3d_codebook_get(self.h, _p(words), _p(vx), _p(vc), _p(sg))
         return words, vx[:nv], vc[:nv], sg
 
+    def set_codebook(self, cb, n_classes):
+        """cb: dict with words [n,dim], vote_offsets, vote_xyz, vote_class, vote_instance, class_sigma and optional word_id, word_class,
+        word_weight, word_keypoint, vote_weight, vote_class_weight, vote_bbox_quat, vote_bbox_size"""
+        u = lambda k: None if cb.get(k) is None else np.ascontiguousarray(cb[k], np.uint32)
+        f = lambda k: None if cb.get(k) is None else _f(cb[k])
+        words = _f(cb["words"])
+        wid = None if cb.get("word_id") is None else np.ascontiguousarray(cb["word_id"], np.int32)
+        self._ck(self.L.ism3d_codebook_set(self.h, words.shape[0], words.shape[1], _p(words), _p(wid), _p(u("word_class")), _p(f("word_weight")),
+                                           _p(f("word_keypoint")), _p(u("vote_offsets")), _p(f("vote_xyz")), _p(f("vote_weight")), _p(f("vote_class_weight")),
+                                           _p(u("vote_class")), _p(u("vote_instance")), _p(f("vote_bbox_quat")), _p(f("vote_bbox_size")), n_classes,
+                                           _p(f("class_sigma"))), "setCodebookData")
+
+    def codebook_all(self):
+        nw, dim, nc = C.c_int(), C.c_int(), C.c_int()
+        nv = self.L.ism3d_codebook_get_all(self.h, C.byref(nw), C.byref(dim), C.byref(nc), *([None] * 14))
+        n, d, c = nw.value, dim.value, nc.value
+        out = dict(words=np.zeros((n, d), np.float32), word_id=np.zeros(n, np.int32), word_class=np.zeros(n, np.uint32), word_weight=np.zeros(n, np.float32),
+                   word_keypoint=np.zeros((n, 3), np.float32), vote_offsets=np.zeros(n + 1, np.uint32), vote_xyz=np.zeros((nv, 3), np.float32),
+                   vote_weight=np.zeros(nv, np.float32), vote_class_weight=np.zeros(nv, np.float32), vote_class=np.zeros(nv, np.uint32),
+                   vote_instance=np.zeros(nv, np.uint32), vote_bbox_quat=np.zeros((nv, 4), np.float32), vote_bbox_size=np.zeros((nv, 3), np.float32),
+                   class_sigma=np.zeros(c, np.float32))
+        keys = ["words", "word_id", "word_class", "word_weight", "word_keypoint", "vote_offsets", "vote_xyz", "vote_weight", "vote_class_weight", "vote_class",
+                "vote_instance", "vote_bbox_quat", "vote_bbox_size", "class_sigma"]
+        self.L.ism3d_codebook_get_all(self.h, None, None, None, *[_p(out[k]) for k in keys])
+        return out
+
+    def set_labels(self, class_labels, instance_labels, instance_to_class):
+        ca = (C.c_char_p * len(class_labels))(*[s.encode() for s in class_labels])
+        ia = (C.c_char_p * len(instance_labels))(*[s.encode() for s in instance_labels])
+        m = np.ascontiguousarray(instance_to_class, np.uint32)
+        self._ck(self.L.ism3d_set_labels(self.h, len(class_labels), ca, len(instance_labels), ia, _p(m)), "setLabels")
+
+    def label(self, which, idx):
+        buf = C.create_string_buffer(4096)
+        n = self.L.ism3d_get_label(self.h, which, idx, buf, len(buf))
+        return buf.value.decode() if n >= 0 else None
+
+    def dimensions(self, class_id):
+        out = np.zeros(4, np.float32)
+        return out if self.L.ism3d_dimensions(self.h, class_id, _p(out)) == 0 else None
+
+    def set_dimensions(self, class_id, radius, box, radius_var=0.0, box_var=0.0):
+        self._ck(self.L.ism3d_set_dimensions(self.h, class_id, _p(np.asarray([radius, box, radius_var, box_var], np.float32))), "setDimensions")
+
     def detect_batch(self, pt_off, xyz, normals, max_maxima=8, rgba=None):
         po = np.ascontiguousarray(pt_off, np.uint32)
         n_obj = len(po) - 1

@@ -103,6 +103,165 @@ def test_pcd_reader_three_encodings_agree(tmp_path):
         hb.load_cloud(pc)
 
 
+# ---- .ismd: the byte stream of boost::archive::binary_oarchive in the reference's field order (FORMAT UNPINNED:
+#      no file written by the real reference exists here). The independent reader / writer below follows the cited save functions
+#      with struct.pack, not the host library's code.
+import struct
+
+
+class _BoostWriter:
+    def __init__(self, version=17):
+        self.b = bytearray()
+        self.b += struct.pack("<Q", 22) + b"serialization::archive" + struct.pack("<H", version) + bytes([4, 8, 4, 8]) + struct.pack("<i", 1)
+
+    def i(self, v): self.b += struct.pack("<i", v)
+    def u(self, v): self.b += struct.pack("<I", v)
+    def f(self, v): self.b += struct.pack("<f", v)
+    def s(self, t): self.b += struct.pack("<Q", len(t)) + t.encode()
+    def vf(self, a): a = np.asarray(a, np.float32); self.b += struct.pack("<Q", len(a)) + a.tobytes()
+    def vu(self, a): a = np.asarray(a, np.uint32); self.b += struct.pack("<Q", len(a)) + a.tobytes()
+
+
+class _BoostReader:
+    def __init__(self, data):
+        self.d, self.o = data, 0
+        assert self.q() == 22 and self.raw(22) == b"serialization::archive"
+        self.version = struct.unpack_from("<H", self.raw(2))[0]
+        assert self.raw(4) == bytes([4, 8, 4, 8]) and self.i() == 1
+
+    def raw(self, n): r = self.d[self.o:self.o + n]; self.o += n; assert len(r) == n; return bytes(r)
+    def q(self): return struct.unpack("<Q", self.raw(8))[0]
+    def i(self): return struct.unpack("<i", self.raw(4))[0]
+    def u(self): return struct.unpack("<I", self.raw(4))[0]
+    def f(self): return struct.unpack("<f", self.raw(4))[0]
+    def s(self): return self.raw(self.q()).decode()
+    def vf(self): return np.frombuffer(self.raw(4 * self.q()), np.float32)
+    def vu(self): return np.frombuffer(self.raw(4 * self.q()), np.uint32)
+
+
+def _toy_codebook(rng, n_words=7, dim=5, n_classes=3):
+    cnt = rng.integers(1, 4, n_words)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+    nv = int(off[-1])
+    vote_class = np.concatenate([np.sort(rng.integers(0, n_classes, c)) for c in cnt]).astype(np.uint32)
+    cw = np.zeros(nv, np.float32)
+    for w in range(n_words):                                     # one class weight per (word, class), as CodewordDistribution stores them
+        for c in set(vote_class[off[w]:off[w + 1]]):
+            cw[off[w]:off[w + 1]][vote_class[off[w]:off[w + 1]] == c] = rng.random()
+    q = rng.normal(size=(nv, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return dict(words=rng.random((n_words, dim)).astype(np.float32), word_id=(np.arange(n_words) * 3 + 11).astype(np.int32),
+                word_class=rng.integers(0, n_classes, n_words).astype(np.uint32), word_weight=rng.random(n_words).astype(np.float32),
+                word_keypoint=rng.normal(size=(n_words, 3)).astype(np.float32), vote_offsets=off, vote_xyz=rng.normal(size=(nv, 3)).astype(np.float32),
+                vote_weight=rng.random(nv).astype(np.float32), vote_class_weight=cw, vote_class=vote_class,
+                vote_instance=rng.integers(0, 9, nv).astype(np.uint32), vote_bbox_quat=q.astype(np.float32),
+                vote_bbox_size=rng.random((nv, 3)).astype(np.float32), class_sigma=rng.random(n_classes).astype(np.float32))
+
+
+def test_ismd_is_a_boost_binary_archive_in_the_reference_field_order(tmp_path):
+    rng = np.random.default_rng(3)
+    cb = _toy_codebook(rng)
+    m = hb.Model()
+    m.config_from_json(_cfg())
+    m.set_codebook(cb, 3)
+    m.set_labels(["chair", "table", "lamp"], ["chair_a", "chair_b", "table_a", "lamp_a"], [0, 0, 1, 2])
+    m.set_dimensions(0, 0.9, 0.5, 0.01, 0.02); m.set_dimensions(2, 1.1, 0.7, 0.03, 0.04)
+    path = str(tmp_path / "toy.ism")
+    m.write(path)
+    data = open(str(tmp_path / "toy.ismd"), "rb").read()
+    # header: 8-byte length + signature, 2-byte library version, the four type sizes, the endianness probe (40 bytes)
+    assert data[:40] == struct.pack("<Q", 22) + b"serialization::archive" + struct.pack("<H", 17) + bytes([4, 8, 4, 8]) + struct.pack("<i", 1)
+    r = _BoostReader(data)
+    # ImplicitShapeModel::iSaveData (implicit_shape_model.cpp:1144-1179)
+    assert [(r.u(), r.u()) for _ in range(r.u())] == [(0, 0), (1, 0), (2, 1), (3, 2)]
+    # Codebook::iSaveData (codebook.cpp:739-761)
+    assert r.i() == 7
+    for w in range(7):
+        v0, v1 = int(cb["vote_offsets"][w]), int(cb["vote_offsets"][w + 1])
+        assert (r.i(), r.i()) == (int(cb["word_id"][w]), 1) and r.f() == cb["word_weight"][w]                   # Codeword (codeword.cpp:71-83)
+        assert np.array_equal(r.vf(), cb["words"][w]) and r.i() == int(cb["word_class"][w])
+        assert [r.f(), r.f(), r.f()] == cb["word_keypoint"][w].tolist()
+        assert r.i() == v1 - v0                                                                                   # CodewordDistribution (:349-391)
+        assert np.array_equal(np.asarray([r.f() for _ in range(3 * (v1 - v0))], np.float32), cb["vote_xyz"][v0:v1].reshape(-1))
+        assert np.array_equal(r.vf(), cb["vote_weight"][v0:v1]) and np.array_equal(r.vu(), cb["vote_class"][v0:v1]) and np.array_equal(r.vu(), cb["vote_instance"][v0:v1])
+        classes = sorted(set(cb["vote_class"][v0:v1].tolist()))
+        assert r.i() == len(classes)
+        for c in classes:
+            assert r.i() == c and r.f() == cb["vote_class_weight"][v0:v1][cb["vote_class"][v0:v1] == c][0]
+        assert r.i() == v1 - v0
+        for v in range(v0, v1):
+            assert [r.f() for _ in range(4)] == cb["vote_bbox_quat"][v].tolist() and [r.f() for _ in range(3)] == cb["vote_bbox_size"][v].tolist()
+    assert r.i() == 3 and [(r.i(), r.f()) for _ in range(3)] == [(c, float(cb["class_sigma"][c])) for c in range(3)]
+    # Voting::iSaveData (voting.cpp:559-614): dimension map, variance map, no global features
+    assert r.u() == 2 and (r.u(), r.f(), r.f()) == (0, np.float32(0.9), np.float32(0.5)) and (r.u(), r.f(), r.f()) == (2, np.float32(1.1), np.float32(0.7))
+    assert r.u() == 2 and (r.u(), r.f(), r.f()) == (0, np.float32(0.01), np.float32(0.02)) and (r.u(), r.f(), r.f()) == (2, np.float32(0.03), np.float32(0.04))
+    assert r.u() == 0
+    assert r.u() == 3 and [r.s() for _ in range(3)] == ["chair", "table", "lamp"]
+    assert r.u() == 4 and [r.s() for _ in range(4)] == ["chair_a", "chair_b", "table_a", "lamp_a"]
+    assert r.o == len(data)
+    # write -> read round trip through the host library
+    m2 = hb.Model()
+    m2.read(path)
+    got = m2.codebook_all()
+    for k, v in cb.items():
+        assert np.array_equal(got[k].reshape(-1), np.asarray(v).reshape(-1)), k
+    assert m2.label(0, 1) == "table" and m2.label(1, 3) == "lamp_a" and np.allclose(m2.dimensions(2), [1.1, 0.7, 0.03, 0.04]) and m2.dimensions(1) is None
+
+
+def test_ismd_written_the_reference_way_is_read(tmp_path):
+    """A data file assembled with struct.pack as the reference's save functions would write it: arbitrary ascending codeword ids,
+    a class without a sigma entry, stored global features (which must be consumed and dropped), Boost library version 18."""
+    rng = np.random.default_rng(4)
+    cb = _toy_codebook(rng, n_words=5, dim=4, n_classes=3)
+    w = _BoostWriter(version=18)
+    w.u(2); w.u(0); w.u(0); w.u(1); w.u(2)                                  # instance -> class
+    w.i(5)
+    for k in range(5):
+        v0, v1 = int(cb["vote_offsets"][k]), int(cb["vote_offsets"][k + 1])
+        w.i(int(cb["word_id"][k])); w.i(1); w.f(cb["word_weight"][k]); w.vf(cb["words"][k]); w.i(int(cb["word_class"][k]))
+        for x in cb["word_keypoint"][k]: w.f(x)
+        w.i(v1 - v0)
+        for x in cb["vote_xyz"][v0:v1].reshape(-1): w.f(x)
+        w.vf(cb["vote_weight"][v0:v1]); w.vu(cb["vote_class"][v0:v1]); w.vu(cb["vote_instance"][v0:v1])
+        classes = sorted(set(cb["vote_class"][v0:v1].tolist()))
+        w.i(len(classes))
+        for c in classes:
+            w.i(c); w.f(cb["vote_class_weight"][v0:v1][cb["vote_class"][v0:v1] == c][0])
+        w.i(v1 - v0)
+        for v in range(v0, v1):
+            for x in cb["vote_bbox_quat"][v]: w.f(x)
+            for x in cb["vote_bbox_size"][v]: w.f(x)
+    w.i(2); w.i(0); w.f(cb["class_sigma"][0]); w.i(2); w.f(cb["class_sigma"][2])   # class 1 has no sigma entry
+    w.u(1); w.u(0); w.f(0.8); w.f(0.4); w.u(1); w.u(0); w.f(0.1); w.f(0.2)
+    w.u(1); w.u(0); w.u(1); w.u(2)                                            # global features: class 0, one cloud, two features
+    for _ in range(2):
+        for x in range(9): w.f(float(x))
+        w.vf(rng.random(6)); w.f(0.3); w.u(1)
+    w.u(2); w.s("mug"); w.s("bowl"); w.u(2); w.s("mug_1"); w.s("bowl_1")
+    open(str(tmp_path / "ref.ismd"), "wb").write(bytes(w.b))
+    j = {"ObjectConfig": json.loads(_cfg()), "ObjectData": "ref.ismd"}
+    open(str(tmp_path / "ref.ism"), "w").write(json.dumps(j))
+    m = hb.Model()
+    m.read(str(tmp_path / "ref.ism"))
+    got = m.codebook_all()
+    for k in ("words", "word_id", "word_class", "vote_offsets", "vote_xyz", "vote_weight", "vote_class_weight", "vote_class", "vote_instance", "vote_bbox_quat"):
+        assert np.array_equal(got[k].reshape(-1), np.asarray(cb[k]).reshape(-1)), k
+    assert got["class_sigma"][0] == cb["class_sigma"][0] and got["class_sigma"][1] == 1.0 and got["class_sigma"][2] == cb["class_sigma"][2]
+    assert m.label(0, 1) == "bowl" and np.allclose(m.dimensions(0), [0.8, 0.4, 0.1, 0.2])
+    # damaged files are errors, not crashes: cut anywhere, absurd lengths, wrong signature
+    good = bytes(w.b)
+    for cut in (10, 39, 41, 60, 200, len(good) - 3):
+        open(str(tmp_path / "ref.ismd"), "wb").write(good[:cut])
+        with pytest.raises(hb.HostError):
+            hb.Model().read(str(tmp_path / "ref.ism"))
+    bad = bytearray(good); bad[60:68] = struct.pack("<Q", 1 << 60)             # first vector length
+    open(str(tmp_path / "ref.ismd"), "wb").write(bytes(bad))
+    with pytest.raises(hb.HostError):
+        hb.Model().read(str(tmp_path / "ref.ism"))
+    open(str(tmp_path / "ref.ismd"), "wb").write(b"ISMDAMD1" + good[8:])
+    with pytest.raises(hb.HostError):
+        hb.Model().read(str(tmp_path / "ref.ism"))
+
+
 def _dataset(pkg, n_classes, n_train, n_test):
     syn = pkg.synthetic
     train = syn.Dataset(n_classes, n_train, split=0, n_points=4096, leaf=0.2)
