@@ -1,0 +1,83 @@
+"""Condenses the rocprofv3 outputs of tools/collect_profiles.sh.
+  on the GPU box : python tools/make_profiles.py --condense gpurun_out     (per-kernel, per-dispatch averages -> gpurun_out/pmc_condensed.csv,
+                                                                            bench line of the stats pass -> gpurun_out/prof_bench_line.json)
+  locally        : python tools/make_profiles.py round2                    (copies the summaries into profiles/round2_*)"""
+import collections, csv, glob, json, os, shutil, sys
+
+SHORT = [("k_knn_l2_ring16", "k_knn_l2_ring16"), ("k_knn_l2_mfma16", "k_knn_l2_mfma16"), ("k_shot<false", "k_shot<false>"), ("k_shot<true", "k_shot<true>"),
+         ("k_lrf_cov", "k_lrf_cov"), ("k_lrf_sign", "k_lrf_sign"), ("k_lrf_tie", "k_lrf_tie"), ("k_lrf_eig", "k_lrf_eig"), ("k_knn_rerank", "k_knn_rerank"),
+         ("k_knn_fallback_merge", "k_knn_fallback_merge"), ("k_knn_fallback", "k_knn_fallback"), ("k_find_maxima", "k_find_maxima"), ("k_scatter", "k_scatter"),
+         ("k_count", "k_count"), ("k_to_f16_tiled", "k_to_f16_tiled"), ("k_cast_votes", "k_cast_votes"), ("k_knn_merge_splits", "k_knn_merge_splits")]
+
+
+def short(name):
+    for pat, s in SHORT:
+        if pat in name:
+            return s
+    return None
+
+
+def condense(root):
+    rows = []
+    for p in ("pmc_fetch_final", "pmc_write_final", "pmc_sq_finalA", "pmc_sq_finalB"):
+        acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set); meta = {}
+        for f in glob.glob(os.path.join(root, p, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                if not k:
+                    continue
+                if k == "k_knn_l2_ring16" and "<2," not in r["Kernel_Name"]:
+                    continue                                   # stage 1 of the search (T = 2) is the bench kernel; the training launch uses it too
+                k = (k, int(r.get("Grid_Size", 0) or 0))      # launches of different size (training, stage 2, the two bench chunks) stay apart
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
+                meta[k] = (r.get("Grid_Size", ""), r.get("Workgroup_Size", ""), r.get("LDS_Block_Size", ""), r.get("VGPR_Count", ""))
+        biggest = {}
+        for (name, grid) in acc:
+            biggest[name] = max(biggest.get(name, 0), grid)
+        for k, c in acc.items():
+            if k[1] != biggest[k[0]]:
+                continue                                       # keep the bench-sized launches of every kernel
+            for n, v in sorted(c.items()):
+                rows.append(dict(pass_=p, kernel=k[0], dispatches=len(cnt[k]), grid_threads=meta[k][0], workgroup=meta[k][1], lds_bytes=meta[k][2], vgprs=meta[k][3],
+                                 counter=n, value_per_dispatch=v / len(cnt[k])))
+    with open(os.path.join(root, "pmc_condensed.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()) if rows else ["pass_"])
+        w.writeheader(); w.writerows(rows)
+    log = os.path.join(root, "prof_final.log")
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith('{"metric"')]
+        if lines:
+            open(os.path.join(root, "prof_bench_line.json"), "w").write(lines[-1])
+    print("condensed", len(rows), "rows")
+
+
+def publish(tag, root="gpurun_out", dst="profiles"):
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(root, "prof_final", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+    for src, name in (("pmc_condensed.csv", f"{tag}_pmc_bench_counters.csv"), ("prof_bench_line.json", f"{tag}_bench_line.json")):
+        if os.path.exists(os.path.join(root, src)):
+            shutil.copy(os.path.join(root, src), os.path.join(dst, name))
+    # beyond-L2 traffic per launch of the two roofline kernels: FETCH_SIZE (KiB, counts 64 B per 128-B request on gfx950 -> doubled,
+    # MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KiB)
+    rows = list(csv.DictReader(open(os.path.join(root, "pmc_condensed.csv"))))
+    line = json.load(open(os.path.join(root, "prof_bench_line.json")))
+    out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --cpu-objects 0 --no-e2e --steps 2 --warmup 1",
+           "note": "FETCH_SIZE/WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request and is doubled (MI355X_MICROARCH.md, HBM); "
+                   "Infinity-Cache hits are included, so this is traffic beyond the XCD L2s, not DRAM alone",
+           "objects": line["config"]["objects_per_step_all_gpus"], "batch": 512}
+    for k in ("k_shot<false>", "k_knn_l2_ring16", "k_lrf_cov", "k_lrf_sign"):
+        f = [float(r["value_per_dispatch"]) for r in rows if r["kernel"] == k and r["counter"] == "FETCH_SIZE"]
+        w = [float(r["value_per_dispatch"]) for r in rows if r["kernel"] == k and r["counter"] == "WRITE_SIZE"]
+        if f and w:
+            out[k] = {"fetch_kib_raw": f[0], "write_kib": w[0], "bytes_per_launch": (2 * f[0] + w[0]) * 1024}
+    json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    print("published", tag, {k: v for k, v in out.items() if isinstance(v, dict)})
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--condense":
+        condense(sys.argv[2])
+    else:
+        publish(sys.argv[1])
