@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ISMHIP_ABI_VERSION 1
+#define ISMHIP_ABI_VERSION 2
 
 #define ISMHIP_OK               0
 #define ISMHIP_ERR_INVALID     -1   /* bad argument (null pointer, negative size, unsupported value) */
@@ -52,6 +52,10 @@ extern "C" {
 #define ISMHIP_SUPPRESS_AVERAGE  0
 #define ISMHIP_SUPPRESS_SUPPRESS 1
 #define ISMHIP_SUPPRESS_NONE     2
+/* inter-class maxima filter: voting/maxima_handler.cpp:272-296 ("Simple" = greedy non-maximum suppression over ALL classes inside
+ * the search radius, suppressNeighborMaxima2 :227-268; "Merge" is not built) */
+#define ISMHIP_MAXFILTER_NONE   0
+#define ISMHIP_MAXFILTER_SIMPLE 1
 
 #define ISMHIP_SHOT_DIM   352
 #define ISMHIP_CSHOT_DIM 1344
@@ -143,6 +147,10 @@ int  ismhip_compact_features(ismhip_ctx* ctx, int n_obj, const uint32_t* kp_offs
                              float* kpx_out, float* kpy_out, float* kpz_out,
                              uint32_t* src_index_out, uint32_t* keep_offsets_h_out);
 
+/* ---- partial descriptors: Codebook::castVotes with UsePartialShot (codebook/codebook.cpp:416-475, mask :952-1036) keeps the
+ *      histograms of some of the 32 SHOT signatures: dst[n_rows * n_cols] = src[:, cols_h] (cols_h host, ascending). */
+int  ismhip_gather_columns(ismhip_ctx* ctx, int n_rows, int dim_in, const float* src, int n_cols, const int32_t* cols_h, float* dst);
+
 /* ---- codebook: FlannHelper dataset (utils/flann_helper.cpp:21-70) + CodewordDistribution vote
  *      tables (codebook/codeword_distribution.cpp:73-144) + classSigmas (codebook.cpp:107,159-193).
  *      Rows of words_h are in getCodewords() order (ascending codeword id, codebook.cpp:856-859).
@@ -211,6 +219,8 @@ typedef struct ismhip_maxima_params {
     float min_threshold;            /* Voting.MinThreshold (negative = relative to best) */
     int   best_k;                   /* Voting.BestK (<=0: all) */
     int   max_maxima;               /* capacity of the output per object */
+    int   max_filter;               /* Voting.MaxFilterType: ISMHIP_MAXFILTER_NONE | _SIMPLE (MaximaHandler::filterMaxima, maxima_handler.cpp:272-296);
+                                       not applied in single-object mode: pass NONE there (voting.cpp:262-268) */
 } ismhip_maxima_params;
 
 /* slot_offsets_h[n_obj+1]: vote-slot range of each object. Outputs per object o, maximum m (sorted by
@@ -259,6 +269,7 @@ typedef struct ismhip_hough_params {
     float min_threshold;            /* Voting.MinThreshold (negative = relative to best) */
     int   best_k;                   /* Voting.BestK (<=0: all) */
     int   max_maxima;               /* capacity of the output per object */
+    int   max_filter;               /* as ismhip_maxima_params.max_filter; the radius is bin_size / 2 (voting_hough_3d.cpp:45) */
 } ismhip_hough_params;
 int  ismhip_hough3d_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* slot_offsets_h,
                            const float* vote_pos, const float* vote_weight, const int32_t* vote_class,

@@ -725,6 +725,25 @@ void append_maximum(const std::vector<MSVote>& votes, const std::vector<V3>& vbb
 }
 
 // Voting::findMaxima tail (voting.cpp:272, 298-323, 441-462): sort, normalise, MinThreshold, BestK, outputs of one object
+// MaximaHandler::filterMaxima "Simple" = suppressNeighborMaxima2 (maxima_handler.cpp:227-268): greedy NMS over all classes
+void filter_maxima_simple(std::vector<Maximum>& maxima, float radius) {
+    std::vector<float> work;
+    for (auto& m : maxima) work.push_back(m.weight);
+    std::vector<Maximum> out;
+    for (;;) {
+        int mi = -1;
+        for (size_t i = 0; i < work.size(); ++i) if (work[i] != -1 && (mi < 0 || work[i] > work[mi])) mi = static_cast<int>(i);   // std::max_element: first largest
+        if (mi < 0) break;
+        out.push_back(maxima[mi]);
+        work[mi] = -1;
+        for (size_t i = 0; i < work.size(); ++i) {
+            const float dx = maxima[mi].pos[0] - maxima[i].pos[0], dy = maxima[mi].pos[1] - maxima[i].pos[1], dz = maxima[mi].pos[2] - maxima[i].pos[2];
+            if (std::sqrt(dx * dx + dy * dy + dz * dz) < radius) work[i] = -1;
+        }
+    }
+    maxima.swap(out);
+}
+
 void finish_object(std::vector<Maximum>& maxima, int o, int C, int cap, float min_threshold, int best_k,
                    int32_t* n_max_out, float* mpos, float* mw, int32_t* mcls, int32_t* minst, float* miw, float* mbs, int32_t* mnv, float* class_score) {
         // sort (stable; std::sort in the reference leaves equal weights unordered), voting.cpp:272
@@ -1114,6 +1133,7 @@ int ismref_find_maxima(int n_obj, const uint32_t* so, const float* vpos, const f
                 append_maximum(votes, vbbox, cluster, pos, c, P->min_votes_threshold, maxima);
             }
         }
+        if (P->max_filter == 1) filter_maxima_simple(maxima, P->bandwidth);
         finish_object(maxima, o, C, cap, P->min_threshold, P->best_k, n_max_out, mpos, mw, mcls, minst, miw, mbs, mnv, class_score);
     }
     return 0;
@@ -1217,6 +1237,7 @@ int ismref_hough3d_maxima(int n_obj, const uint32_t* so, const float* vpos, cons
                 append_maximum(votes, vbbox, kv.second.second, V3{cx / wsum, cy / wsum, cz / wsum}, c, P->min_votes_threshold, maxima);
             }
         }
+        if (P->max_filter == 1) filter_maxima_simple(maxima, P->bin_size / 2);
         finish_object(maxima, o, C, cap, P->min_threshold, P->best_k, n_max_out, mpos, mw, mcls, minst, miw, mbs, mnv, class_score);
     }
     return 0;

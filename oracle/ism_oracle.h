@@ -32,6 +32,7 @@ typedef struct ismref_maxima_params {
     float min_threshold;
     int   best_k;
     int   max_maxima;
+    int   max_filter;    /* 0 none, 1 "Simple" (MaximaHandler::filterMaxima, maxima_handler.cpp:272-296) */
 } ismref_maxima_params;
 
 void ismref_set_num_threads(int n);
@@ -115,6 +116,7 @@ typedef struct ismref_hough_params {
     float min_threshold;
     int   best_k;
     int   max_maxima;
+    int   max_filter;
 } ismref_hough_params;
 int  ismref_hough3d_maxima(int n_obj, const uint32_t* slot_offsets,
                            const float* vote_pos, const float* vote_weight, const int32_t* vote_class,

@@ -23,7 +23,7 @@ EXPORTS = [
     "ismhip_timers_enable", "ismhip_timers_reset", "ismhip_timer_get",
     "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids", "ismhip_estimate_normals",
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
-    "ismhip_compact_features", "ismhip_voxel_keypoints",
+    "ismhip_compact_features", "ismhip_voxel_keypoints", "ismhip_gather_columns",
     "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word",
     "ismhip_knn", "ismhip_knn_ratio", "ismhip_knn_rule", "ismhip_cast_votes", "ismhip_find_maxima", "ismhip_hough3d_maxima", "ismhip_train_activate",
 ]
@@ -33,13 +33,13 @@ class MaximaParams(C.Structure):
     _fields_ = [("n_classes", C.c_int), ("class_bandwidth_h", C.c_void_p), ("bandwidth", C.c_float),
                 ("threshold", C.c_float), ("max_iter", C.c_int), ("kernel", C.c_int), ("suppression", C.c_int),
                 ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int),
-                ("max_maxima", C.c_int)]
+                ("max_maxima", C.c_int), ("max_filter", C.c_int)]
 
 
 class HoughParams(C.Structure):
     _fields_ = [("n_classes", C.c_int), ("min_coord", C.c_float * 3), ("max_coord", C.c_float * 3), ("bin_size", C.c_float),
                 ("class_bin_h", C.c_void_p), ("use_interpolation", C.c_int), ("rel_threshold", C.c_float),
-                ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int), ("max_maxima", C.c_int)]
+                ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int), ("max_maxima", C.c_int), ("max_filter", C.c_int)]
 
 
 class IsmHipError(RuntimeError):
@@ -341,14 +341,14 @@ def cast_votes(ctx, cb, weight_flags, lrf, kpx, kpy, kpz, idx, dist, want_bbox=F
 
 def find_maxima(ctx, slot_offsets, votes, n_classes, bandwidth, threshold=1e-3, max_iter=1000, kernel=KERNEL_GAUSSIAN,
                 suppression=SUPPRESS_AVERAGE, min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16,
-                class_bandwidth=None):
+                class_bandwidth=None, max_filter=0):
     torch = _torch()
     so = _u32(slot_offsets)
     n_obj = len(so) - 1
     dev = votes["pos"].device
     cbw = None if class_bandwidth is None else np.ascontiguousarray(np.asarray(class_bandwidth, dtype=np.float32))
     P = MaximaParams(n_classes, cbw.ctypes.data if cbw is not None else None, bandwidth, threshold, max_iter, kernel, suppression,
-                     min_votes_threshold, min_threshold, best_k, max_maxima)
+                     min_votes_threshold, min_threshold, best_k, max_maxima, max_filter)
     out = dict(
         n=torch.empty((n_obj,), dtype=torch.int32, device=dev),
         pos=torch.empty((n_obj, max_maxima, 3), dtype=torch.float32, device=dev),
@@ -368,7 +368,7 @@ def find_maxima(ctx, slot_offsets, votes, n_classes, bandwidth, threshold=1e-3, 
 
 
 def hough3d_maxima(ctx, slot_offsets, votes, n_classes, bin_size, min_coord=(-5, -5, -5), max_coord=(5, 5, 5), use_interpolation=True,
-                   rel_threshold=0.8, min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16, class_bin=None):
+                   rel_threshold=0.8, min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16, class_bin=None, max_filter=0):
     """VotingHough3D on the device: same outputs as find_maxima"""
     torch = _torch()
     so = _u32(slot_offsets)
@@ -376,7 +376,7 @@ def hough3d_maxima(ctx, slot_offsets, votes, n_classes, bin_size, min_coord=(-5,
     dev = votes["pos"].device
     cb = None if class_bin is None else np.ascontiguousarray(np.asarray(class_bin, dtype=np.float32))
     P = HoughParams(n_classes, (C.c_float * 3)(*min_coord), (C.c_float * 3)(*max_coord), bin_size, cb.ctypes.data if cb is not None else None,
-                    1 if use_interpolation else 0, rel_threshold, min_votes_threshold, min_threshold, best_k, max_maxima)
+                    1 if use_interpolation else 0, rel_threshold, min_votes_threshold, min_threshold, best_k, max_maxima, max_filter)
     out = dict(
         n=torch.empty((n_obj,), dtype=torch.int32, device=dev),
         pos=torch.empty((n_obj, max_maxima, 3), dtype=torch.float32, device=dev),
@@ -410,3 +410,26 @@ def train_activate(ctx, metric, desc, lrf, kx, ky, kz, feat_class, feat_model, f
     m = nw.value; nv = int(vo[m])
     return dict(word_src=word_src[:m].copy(), vote_offsets=vo[:m + 1].copy(), vote_feature=vf[:nv].copy(), vote_xyz=vxyz[:nv].copy(),
                 vote_weight=vw[:nv].copy(), vote_class_weight=vcw[:nv].copy(), class_sigma=sig)
+
+
+PARTIAL_SHOT_SIGNATURES = {          # Codebook::getSignatureMask (codebook/codebook.cpp:952-1036): kept signatures of the 32
+    "front": range(8, 24), "dense_x": range(8, 24), "back": list(range(0, 8)) + list(range(24, 32)), "sparse_x": list(range(0, 8)) + list(range(24, 32)),
+    "left": range(16, 32), "positive_y": range(16, 32), "right": range(0, 16), "negative_y": range(0, 16),
+    "top": range(1, 32, 2), "dense_z": range(1, 32, 2), "bottom": range(0, 32, 2), "sparse_z": range(0, 32, 2),
+    "dense_x_or_z": sorted(set(range(8, 24)) | set(range(1, 32, 2))), "dense_x_and_z": range(9, 24, 2),
+    "front_turn_left": range(12, 28), "front_turn_right": range(4, 20),
+}
+
+
+def partial_shot_columns(kind):
+    """descriptor columns of SHOT-352 kept by UsePartialShot / PartialShotType (unknown type: the complete descriptor, with the reference's warning)"""
+    sig = PARTIAL_SHOT_SIGNATURES.get(kind, range(32))
+    return np.asarray([s * 11 + j for s in sig for j in range(11)], np.int32)
+
+
+def gather_columns(ctx, src, cols):
+    torch = _torch()
+    cols = np.ascontiguousarray(cols, np.int32)
+    out = torch.empty((src.shape[0], len(cols)), dtype=torch.float32, device=src.device)
+    ctx.check(lib().ismhip_gather_columns(ctx._h, C.c_int(src.shape[0]), C.c_int(src.shape[1]), _p(src), C.c_int(len(cols)), _p(cols), _p(out)), "ismhip_gather_columns")
+    return out

@@ -108,3 +108,28 @@ extern "C" int ismhip_compact_features(ismhip_ctx* ctx, int n_obj, const uint32_
     ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));   // keep_offsets_h_out is read by the caller right away; new_off copy must land
     return ISMHIP_OK;
 }
+
+
+// ---- partial descriptors: Codebook::castVotes with UsePartialShot (codebook/codebook.cpp:416-475) keeps the histograms of a subset
+//      of the 32 SHOT signatures (getSignatureMask, :952-1036); on the device that is a column gather of the descriptor matrix.
+namespace {
+__global__ void k_gather_columns(size_t total, int dim_in, int n_cols, const float* __restrict__ src, const int32_t* __restrict__ cols, float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t row = i / n_cols; const int c = (int)(i % n_cols);
+    dst[i] = src[row * dim_in + cols[c]];
+}
+}  // namespace
+
+extern "C" int ismhip_gather_columns(ismhip_ctx* ctx, int n_rows, int dim_in, const float* src, int n_cols, const int32_t* cols_h, float* dst) {
+    if (!ctx || n_rows < 0 || dim_in <= 0 || n_cols <= 0 || !src || !cols_h || !dst) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "gather_columns: bad argument");
+    for (int c = 0; c < n_cols; ++c) if (cols_h[c] < 0 || cols_h[c] >= dim_in) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "gather_columns: column out of range");
+    if (n_rows == 0) return ISMHIP_OK;
+    int32_t* cols = (int32_t*)ism_scratch(ctx, SCR_COMPACT_POS, (size_t)n_cols * 4);
+    if (!cols) return ISMHIP_ERR_NOMEM;
+    ISM_HIP(ctx, hipMemcpyAsync(cols, cols_h, (size_t)n_cols * 4, hipMemcpyHostToDevice, ctx->stream));
+    const size_t total = (size_t)n_rows * n_cols;
+    hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, total, dim_in, n_cols, src, cols, dst);
+    ISM_CHECK_LAUNCH(ctx, "k_gather_columns");
+    return ISMHIP_OK;
+}

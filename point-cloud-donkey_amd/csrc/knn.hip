@@ -1328,7 +1328,11 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     int n_splits, cand_per_split, n_cand, tiles_per_split;
     // candidate kernel for squared L2: f16 (default), bf16x3 (ISMHIP_KNN_MODE=bf16x3) or the exact-f32 MFMA contraction
     // (ISMHIP_KNN_MODE=f32); the last two are kept for A/B runs and as the reference points of the error model tests
-    const int mode = metric != ISMHIP_METRIC_L2SQ ? -1 : (ctx->knn_mode == 0 && cb->words_f16 ? 0 : (ctx->knn_mode <= 1 && cb->words_bf16_hi ? 1 : 2));
+    // short descriptors (FPFH-33: values up to 100, |q||c| ~ 1e4): the f16 error bound is of the order of the neighbour distances, most
+    // proofs fail and the exact scan takes over (measured: 135 ms of scan per 524288 queries). The exact-f32 MFMA contraction costs
+    // 2 Nq Nc D flop at ~125 TFLOP/s, which for D <= 64 is cheaper than the 16-bit kernels' fixed overheads -- and it proves everything.
+    const bool short_dim = cb->dim <= 64 && ctx->knn_mode == 0;
+    const int mode = metric != ISMHIP_METRIC_L2SQ ? -1 : (short_dim ? 2 : (ctx->knn_mode == 0 && cb->words_f16 ? 0 : (ctx->knn_mode <= 1 && cb->words_bf16_hi ? 1 : 2)));
     const bool use_lp = mode == 0 || mode == 1;
     const bool big_tile = use_lp && nq >= 4096 && cb->n_words_pad >= 4096 && !ctx->knn_small_tile;      // 256x256 tile, 8 waves
     const int BM = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BM) : CHI_B;
@@ -1589,7 +1593,7 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
     const bool wide = k > 2 || (metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi && ctx->knn_mode <= 1);
     // default for big squared-L2 launches with k <= 2 (every shipped configuration): the two-stage search (see run_knn_two_stage)
     if (metric == ISMHIP_METRIC_L2SQ && k <= 2 && ctx->knn_t == 0 && ctx->knn_mode == 0 && ctx->knn_two_stage && cb->words_f16t && nq >= 4096 &&
-        cb->n_words_pad >= 4096 && !ctx->knn_small_tile && !ctx->knn_no_ring)
+        cb->n_words_pad >= 4096 && !ctx->knn_small_tile && !ctx->knn_no_ring && cb->dim > 64)
         return run_knn_two_stage(ctx, cb, nq, q, k, idx_out, dist_out);
     if (ctx->knn_t == 1 && k <= 1) return run_knn<1>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
     if (ctx->knn_t == 3 && k <= 3) return run_knn<3>(ctx, cb, metric, nq, q, k, idx_out, dist_out);

@@ -23,7 +23,7 @@ namespace {
 struct MaxArgs {
     const uint32_t* slot_off; const float* vpos; const float* vw; const int32_t* vcls; const int32_t* vinst; const float* vbs;
     int n_classes; const float* class_bw; float bandwidth, threshold; int max_iter, kernel, suppression, min_votes;
-    float min_threshold; int best_k, max_maxima, cap;
+    float min_threshold; int best_k, max_maxima, cap; int max_filter; float filter_radius;
     int32_t* n_max; float* mpos; float* mw; int32_t* mcls; int32_t* minst; float* miw; float* mbs; int32_t* mnv; float* class_score;
     float* rec; int32_t* rec_count;      // per (object, class): up to MX_MAXM_C records of MX_REC floats
 };
@@ -329,6 +329,8 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
 __global__ __launch_bounds__(64) void k_finalize_maxima(MaxArgs a) {
     __shared__ float s_w[MX_MAXM], s_iw[MX_MAXM];
     __shared__ int s_src[MX_MAXM], s_cls[MX_MAXM], s_order[MX_MAXM];
+    __shared__ float s_tw[MX_MAXM], s_tiw[MX_MAXM];                 // scratch of the inter-class filter
+    __shared__ int s_tsrc[MX_MAXM], s_tcls[MX_MAXM], s_iw2[MX_MAXM];
     const int o = blockIdx.x;
     const int C = a.n_classes;
     if (threadIdx.x != 0) return;
@@ -339,6 +341,30 @@ __global__ __launch_bounds__(64) void k_finalize_maxima(MaxArgs a) {
             const float* r = a.rec + (((size_t)o * C + c) * MX_MAXM_C + m) * MX_REC;
             s_w[nm] = r[3]; s_iw[nm] = r[5]; s_src[nm] = c * MX_MAXM_C + m; s_cls[nm] = c; s_order[nm] = nm; ++nm;
         }
+    }
+    if (a.max_filter == ISMHIP_MAXFILTER_SIMPLE && nm > 1) {
+        // MaximaHandler::filterMaxima "Simple" -> suppressNeighborMaxima2 (maxima_handler.cpp:227-268): greedy non-maximum suppression
+        // over the maxima of ALL classes: take the heaviest one left (std::max_element: the first largest), drop everything closer
+        // than the search radius (itself included), repeat. Runs on the raw weights, before sorting / normalising (voting.cpp:262-272).
+        // s_order doubles as the work list here: >= 0 = still a candidate, -1 = gone; the survivors are compacted in selection order.
+        int kept = 0;
+        for (;;) {
+            int mi = -1;
+            for (int i = 0; i < nm; ++i) if (s_order[i] >= 0 && (mi < 0 || s_w[i] > s_w[mi])) mi = i;
+            if (mi < 0) break;
+            const float* rm = a.rec + ((size_t)o * C * MX_MAXM_C + s_src[mi]) * MX_REC;
+            const float cx = rm[0], cy = rm[1], cz = rm[2];
+            for (int i = 0; i < nm; ++i) {
+                if (s_order[i] < 0) continue;
+                const float* ri = a.rec + ((size_t)o * C * MX_MAXM_C + s_src[i]) * MX_REC;
+                if (i == mi || dist3(cx, cy, cz, ri[0], ri[1], ri[2]) < a.filter_radius) s_order[i] = -1;
+            }
+            s_iw2[kept++] = mi;
+        }
+        // move the survivors to the front (selection order = descending weight; the stable sort below keeps it)
+        for (int r = 0; r < kept; ++r) { const int i = s_iw2[r]; s_tw[r] = s_w[i]; s_tiw[r] = s_iw[i]; s_tsrc[r] = s_src[i]; s_tcls[r] = s_cls[i]; }
+        for (int r = 0; r < kept; ++r) { s_w[r] = s_tw[r]; s_iw[r] = s_tiw[r]; s_src[r] = s_tsrc[r]; s_cls[r] = s_tcls[r]; s_order[r] = r; }
+        nm = kept;
     }
     for (int i = 1; i < nm; ++i) {
         const int v = s_order[i]; int j = i - 1;
@@ -665,6 +691,8 @@ extern "C" int ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* sl
     a.n_classes = P->n_classes; a.class_bw = bw; a.bandwidth = P->bandwidth; a.threshold = P->threshold; a.max_iter = P->max_iter;
     a.kernel = P->kernel; a.suppression = P->suppression; a.min_votes = P->min_votes_threshold; a.min_threshold = P->min_threshold;
     a.best_k = P->best_k; a.max_maxima = P->max_maxima; a.cap = cap;
+    if (P->max_filter != ISMHIP_MAXFILTER_NONE && P->max_filter != ISMHIP_MAXFILTER_SIMPLE) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "find_maxima: MaxFilterType other than None / Simple not built");
+    a.max_filter = P->max_filter; a.filter_radius = P->bandwidth;      // MaximaHandler::m_radius = the configured bandwidth (voting_mean_shift.cpp:46)
     a.n_max = n_maxima_out; a.mpos = max_pos_out; a.mw = max_weight_out; a.mcls = max_class_out; a.minst = max_instance_out;
     a.miw = max_instance_weight_out; a.mbs = max_bbox_size_out; a.mnv = max_n_votes_out; a.class_score = class_score_out;
     if (!ctx->attr_done.count((const void*)k_find_maxima)) {      // the attribute is per device: remembered per ctx, not per process
@@ -730,6 +758,8 @@ extern "C" int ismhip_hough3d_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t*
     MaxArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n_classes = P->n_classes; a.min_threshold = P->min_threshold; a.best_k = P->best_k; a.max_maxima = P->max_maxima;
+    if (P->max_filter != ISMHIP_MAXFILTER_NONE && P->max_filter != ISMHIP_MAXFILTER_SIMPLE) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "hough3d_maxima: MaxFilterType other than None / Simple not built");
+    a.max_filter = P->max_filter; a.filter_radius = P->bin_size / 2;   // MaximaHandler::setRadius(BinSize[0] / 2) (voting_hough_3d.cpp:45)
     a.n_max = n_maxima_out; a.mpos = max_pos_out; a.mw = max_weight_out; a.mcls = max_class_out; a.minst = max_instance_out;
     a.miw = max_instance_weight_out; a.mbs = max_bbox_size_out; a.mnv = max_n_votes_out; a.class_score = class_score_out;
     a.rec = h.rec; a.rec_count = h.rec_count;

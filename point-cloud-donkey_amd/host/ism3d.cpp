@@ -345,13 +345,45 @@ bool Codebook::iChildConfigsFromJson(const Json& c) {
     return m_activationStrategy != nullptr;
 }
 
+// Codebook::getSignatureMask (codebook.cpp:952-1036) -> kept descriptor columns of SHOT-352 (11 per signature)
+static std::vector<int32_t> partialShotColumns(const std::string& type) {
+    std::vector<bool> m(32, false);
+    auto rng = [&](int a, int b) { for (int i = a; i <= b; ++i) m[i] = true; };
+    if (type == "front" || type == "dense_x") rng(8, 23);
+    else if (type == "back" || type == "sparse_x") { rng(0, 7); rng(24, 31); }
+    else if (type == "left" || type == "positive_y") rng(16, 31);
+    else if (type == "right" || type == "negative_y") rng(0, 15);
+    else if (type == "top" || type == "dense_z") { for (int i = 1; i < 32; i += 2) m[i] = true; }
+    else if (type == "bottom" || type == "sparse_z") { for (int i = 0; i < 32; i += 2) m[i] = true; }
+    else if (type == "dense_x_or_z") { rng(8, 23); for (int i = 1; i < 32; i += 2) m[i] = true; }
+    else if (type == "dense_x_and_z") { for (int i = 9; i <= 23; i += 2) m[i] = true; }
+    else if (type == "front_turn_left") rng(12, 27);
+    else if (type == "front_turn_right") rng(4, 19);
+    else { LOG_WARN("Unknown partial shot type: " << type << "! Using complete descriptor!"); m.assign(32, true); }
+    std::vector<int32_t> cols;
+    for (int sidx = 0; sidx < 32; ++sidx) if (m[sidx]) for (int j = 0; j < 11; ++j) cols.push_back(sidx * 11 + j);
+    return cols;
+}
+
 void Codebook::upload(DeviceSession& s) const {
     if (!m_dirty && m_dev && m_dev_session == &s) return;
     if (m_dev && m_dev_session) ismhip_codebook_destroy(m_dev_session->ctx, m_dev);
     m_dev = nullptr; m_dev_session = &s;
     const CodebookData& d = m_data;
     if (d.numWords() == 0) return;
-    s.check(ismhip_codebook_create(s.ctx, d.numWords(), d.dim, d.words.data(), d.word_weight.empty() ? nullptr : d.word_weight.data(),
+    std::vector<float> partial;
+    const float* words = d.words.data(); int dim = d.dim;
+    if (m_use_partial_shot) {
+        // iLoadData builds the partial codewords (codebook.cpp:862-930). Plain SHOT only: with CSHOT the reference's loop leaks hist_size = 31
+        // into the shape part of every feature after the first and produces descriptors of unequal length (:419, :458).
+        if (d.dim != ISMHIP_SHOT_DIM) throw RuntimeException("UsePartialShot is built for SHOT-352 codebooks only");
+        m_partial_cols = partialShotColumns(m_partial_shot_type);
+        dim = (int)m_partial_cols.size();
+        partial.resize((size_t)d.numWords() * dim);
+        for (int w = 0; w < d.numWords(); ++w) for (int c = 0; c < dim; ++c) partial[(size_t)w * dim + c] = d.words[(size_t)w * d.dim + m_partial_cols[c]];
+        words = partial.data();
+    } else m_partial_cols.clear();
+    s.check(ismhip_codebook_create(s.ctx, d.numWords(), dim, words, d.word_weight.empty() ? nullptr : d.word_weight.data(),
                                    d.vote_offsets.data(), d.vote_xyz.data(), d.vote_weight.empty() ? nullptr : d.vote_weight.data(),
                                    d.vote_class_weight.empty() ? nullptr : d.vote_class_weight.data(), d.vote_class.data(), d.vote_instance.data(),
                                    d.vote_bbox_quat.empty() ? nullptr : d.vote_bbox_quat.data(), d.vote_bbox_size.empty() ? nullptr : d.vote_bbox_size.data(),
@@ -361,22 +393,24 @@ void Codebook::upload(DeviceSession& s) const {
 }
 
 int ActivationStrategyKNN::activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric,
-                                       int32_t* idx_out, float* dist_out) const {     // activation_strategy_knn.h:41-126
+                                       int32_t* idx_out, float* dist_out, const float* desc) const {     // activation_strategy_knn.h:41-126
     if (m_k > 4) throw RuntimeException("KNN activation with K > 4 is not built");
     if (f.n == 0) return m_k;
+    if (!desc) desc = f.desc.as<float>();                        // desc: the (possibly partial, codebook.cpp:416-475) descriptors to match
     if (m_use_distance_ratio && m_is_detection && m_k == 1)
-        s.check(ismhip_knn_ratio(s.ctx, codewords, metric, (int)f.n, f.desc.as<float>(), m_distance_ratio_threshold, idx_out, dist_out), "ismhip_knn_ratio");
+        s.check(ismhip_knn_ratio(s.ctx, codewords, metric, (int)f.n, desc, m_distance_ratio_threshold, idx_out, dist_out), "ismhip_knn_ratio");
     else
-        s.check(ismhip_knn(s.ctx, codewords, metric, (int)f.n, f.desc.as<float>(), m_k, idx_out, dist_out), "ismhip_knn");
+        s.check(ismhip_knn(s.ctx, codewords, metric, (int)f.n, desc, m_k, idx_out, dist_out), "ismhip_knn");
     return m_k;
 }
 
 ActivationStrategyKnnRule::ActivationStrategyKnnRule() { addParameter(m_k, "K", 3); m_is_detection = false; m_k = 3; }   // activation_strategy_knn_rule.cpp:16-22
 int ActivationStrategyKnnRule::activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric,
-                                           int32_t* idx_out, float* dist_out) const {
+                                           int32_t* idx_out, float* dist_out, const float* desc) const {
     if (f.n == 0) return 1;
-    if (!m_is_detection) s.check(ismhip_knn(s.ctx, codewords, metric, (int)f.n, f.desc.as<float>(), 1, idx_out, dist_out), "ismhip_knn");
-    else s.check(ismhip_knn_rule(s.ctx, codewords, metric, (int)f.n, f.desc.as<float>(), m_distance_ratio_threshold, idx_out, dist_out), "ismhip_knn_rule");
+    if (!desc) desc = f.desc.as<float>();
+    if (!m_is_detection) s.check(ismhip_knn(s.ctx, codewords, metric, (int)f.n, desc, 1, idx_out, dist_out), "ismhip_knn");
+    else s.check(ismhip_knn_rule(s.ctx, codewords, metric, (int)f.n, desc, m_distance_ratio_threshold, idx_out, dist_out), "ismhip_knn_rule");
     return 1;
 }
 
@@ -476,7 +510,6 @@ void Codebook::castVotes(DeviceSession& s, const DeviceFeatures& f, int metric, 
     (void)voting;
     s.n_slots = 0; s.slot_off.assign(s.n_obj + 1, 0);
     if (isEmpty()) return;
-    if (m_use_partial_shot) throw RuntimeException("UsePartialShot is not built on the MI355X path");
     upload(s);
     m_activationStrategy->setIsDetection();
     const ActivationStrategy* knn = m_activationStrategy.get();
@@ -484,7 +517,16 @@ void Codebook::castVotes(DeviceSession& s, const DeviceFeatures& f, int metric, 
     const uint32_t n = f.n;
     if (n == 0) return;
     s.idx.reserve((size_t)n * 4 * 4); s.dist.reserve((size_t)n * 4 * 4);
-    const int k = knn->activateKNN(s, m_dev, f, metric, s.idx.as<int32_t>(), s.dist.as<float>());
+    const float* qdesc = nullptr;
+    DevBuf partial;
+    if (!m_partial_cols.empty()) {                              // reduce every feature the way the codewords were reduced (codebook.cpp:416-475)
+        if (f.dim != ISMHIP_SHOT_DIM) throw RuntimeException("UsePartialShot needs SHOT-352 features");
+        partial.reserve((size_t)n * m_partial_cols.size() * 4);
+        s.check(ismhip_gather_columns(s.ctx, (int)n, f.dim, f.desc.as<float>(), (int)m_partial_cols.size(), m_partial_cols.data(), partial.as<float>()), "ismhip_gather_columns");
+        qdesc = partial.as<float>();
+    }
+    const int k = knn->activateKNN(s, m_dev, f, metric, s.idx.as<int32_t>(), s.dist.as<float>(), qdesc);
+    if (qdesc) s.check(ismhip_sync(s.ctx), "ismhip_sync");     // the partial descriptors are released when this function returns
     const int maxv = ismhip_codebook_max_votes_per_word(m_dev);
     const size_t ns = (size_t)n * k * maxv;
     s.v_pos.reserve(ns * 12); s.v_w.reserve(ns * 4); s.v_cls.reserve(ns * 4); s.v_inst.reserve(ns * 4); s.v_cw.reserve(ns * 4); s.v_bs.reserve(ns * 12);
@@ -697,7 +739,7 @@ void Voting::clear() {}
 std::vector<std::vector<VotingMaximum>> Voting::findMaxima(DeviceSession& s) {
     if (m_use_global_features) throw RuntimeException("UseGlobalFeatures is out of scope of the MI355X path (SURVEY §2 row 10)");
     if (m_vote_filtering_with_ransac) throw RuntimeException("RansacVoteFiltering is not built on the MI355X path");
-    if (m_max_filter_type != "None") throw RuntimeException("MaxFilterType \"" + m_max_filter_type + "\" is not built (only \"None\")");
+    if (m_max_filter_type != "None" && m_max_filter_type != "Simple") throw RuntimeException("MaxFilterType \"" + m_max_filter_type + "\" is not built (built: \"None\", \"Simple\")");
     if (m_single_object_mode && m_max_type_param != "None" && m_max_type_param != "Default")
         throw RuntimeException("SingleObjectMaxType \"" + m_max_type_param + "\" is not built (only \"None\"/\"Default\")");
     std::vector<std::vector<VotingMaximum>> out(s.n_obj);
@@ -723,6 +765,7 @@ void VotingMeanShift::iFindMaxima(DeviceSession& s, std::vector<std::vector<Voti
     P.kernel = m_kernel == "Uniform" ? ISMHIP_KERNEL_UNIFORM : ISMHIP_KERNEL_GAUSSIAN;
     P.suppression = m_maxima_suppression_type == "Average" ? ISMHIP_SUPPRESS_AVERAGE : (m_maxima_suppression_type == "Suppress" ? ISMHIP_SUPPRESS_SUPPRESS : ISMHIP_SUPPRESS_NONE);
     P.min_votes_threshold = m_minVotesThreshold; P.min_threshold = m_minThreshold; P.best_k = m_bestK; P.max_maxima = M;
+    P.max_filter = (!m_single_object_mode && m_max_filter_type == "Simple") ? ISMHIP_MAXFILTER_SIMPLE : ISMHIP_MAXFILTER_NONE;   // voting.cpp:262-268
     MaximaBuffers B; B.M = M; B.reserve(s.n_obj, C);
     s.check(ismhip_find_maxima(s.ctx, s.n_obj, s.slot_off.data(), s.v_pos.as<float>(), s.v_w.as<float>(), s.v_cls.as<int32_t>(), s.v_inst.as<int32_t>(),
                                s.v_bs.as<float>(), &P, B.n_max.as<int32_t>(), B.pos.as<float>(), B.w.as<float>(), B.cls.as<int32_t>(), B.inst.as<int32_t>(),
@@ -769,6 +812,7 @@ void VotingHough3D::iFindMaxima(DeviceSession& s, std::vector<std::vector<Voting
     P.class_bin_h = class_bin.empty() ? nullptr : class_bin.data();
     P.use_interpolation = m_useInterpolation ? 1 : 0; P.rel_threshold = m_relThreshold;
     P.min_votes_threshold = m_minVotesThreshold; P.min_threshold = m_minThreshold; P.best_k = m_bestK;
+    P.max_filter = (!m_single_object_mode && m_max_filter_type == "Simple") ? ISMHIP_MAXFILTER_SIMPLE : ISMHIP_MAXFILTER_NONE;
     MaximaBuffers B; P.max_maxima = B.M; B.reserve(s.n_obj, C);
     s.check(ismhip_hough3d_maxima(s.ctx, s.n_obj, s.slot_off.data(), s.v_pos.as<float>(), s.v_w.as<float>(), s.v_cls.as<int32_t>(), s.v_inst.as<int32_t>(),
                                   s.v_bs.as<float>(), &P, B.n_max.as<int32_t>(), B.pos.as<float>(), B.w.as<float>(), B.cls.as<int32_t>(), B.inst.as<int32_t>(),

@@ -221,7 +221,7 @@ public:
     float distanceRatioThreshold() const { return m_distance_ratio_threshold; }
     virtual int getK() const = 0;
     // activates every feature of the batch; writes idx/dist [n x columns] on the device and returns the column count
-    virtual int activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric, int32_t* idx_out, float* dist_out) const = 0;
+    virtual int activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric, int32_t* idx_out, float* dist_out, const float* desc = nullptr) const = 0;
 protected:
     bool m_use_distance_ratio; float m_distance_ratio_threshold; bool m_is_detection = false;
 };
@@ -234,7 +234,7 @@ public:
     // activateKNN for a whole feature batch (activation_strategy_knn.h:41-126): idx/dist [n x K] on the device, exact search
     // (FLANNExactMatch semantics). With UseDistanceRatio at detection time and K == 1 the 2-NN ratio test discards matches
     // (idx -1). Returns K.
-    int activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric, int32_t* idx_out, float* dist_out) const override;
+    int activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric, int32_t* idx_out, float* dist_out, const float* desc = nullptr) const override;
 private:
     int m_k;
 };
@@ -245,7 +245,7 @@ public:
     std::string getType() const override { return getTypeStatic(); }
     int getK() const override { return m_k; }
     // training: plain 1-NN; detection: 3-NN + class-consistency rules. One column.
-    int activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric, int32_t* idx_out, float* dist_out) const override;
+    int activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric, int32_t* idx_out, float* dist_out, const float* desc = nullptr) const override;
 private:
     int m_k;
 };
@@ -296,6 +296,7 @@ private:
     bool m_use_random_codebook; float m_random_codebook_factor;
     std::unique_ptr<ActivationStrategy> m_activationStrategy;
     CodebookData m_data;
+    mutable std::vector<int32_t> m_partial_cols;    // kept descriptor columns when UsePartialShot (empty otherwise)
     mutable bool m_dirty = true;
     mutable ismhip_codebook* m_dev = nullptr;
     mutable DeviceSession* m_dev_session = nullptr;

@@ -38,6 +38,8 @@ class IsmConfig:
     min_threshold: float = 0.0
     best_k: int = -1
     max_maxima: int = 16
+    use_partial_shot: bool = False   # Codebook.UsePartialShot / PartialShotType (SHOT-352 only, codebook.cpp:416-475)
+    partial_shot_type: str = "front"
     voting: str = "MeanShift"        # Voting.Type: "MeanShift" | "Hough3D"
     hough_min_coord: tuple = (-5.0, -5.0, -5.0)   # Voting(Hough3D).MinCoord / MaxCoord / BinSize[0] / UseInterpolation / RelThreshold
     hough_max_coord: tuple = (5.0, 5.0, 5.0)
@@ -220,6 +222,14 @@ class Recognizer:
         if self.codebook is not None:
             self.codebook.close()
         self.cb_host = cb
+        self.partial_cols = None
+        if self.cfg.use_partial_shot:
+            # Codebook::iLoadData builds the partial codewords when the model is loaded (codebook.cpp:862-930); detection then masks every
+            # feature the same way. Only plain SHOT: the reference's CSHOT branch leaks hist_size = 31 into the next feature's shape part.
+            if self.cfg.feature != "SHOT":
+                raise capi.IsmHipError("UsePartialShot is built for SHOT-352 only (the reference's partial CSHOT yields descriptors of unequal length)")
+            self.partial_cols = capi.partial_shot_columns(self.cfg.partial_shot_type)
+            cb = dict(cb, words=np.ascontiguousarray(np.asarray(cb["words"], np.float32)[:, self.partial_cols]))
         self.codebook = capi.Codebook(self.ctx, cb["words"], cb["vote_offsets"], cb["vote_xyz"], cb["vote_class"], cb["vote_instance"],
                                       self.cfg.n_classes, cb["class_sigma"], word_weight=cb.get("word_weight"),
                                       vote_weight=cb.get("vote_weight"), vote_class_weight=cb.get("vote_class_weight"),
@@ -231,12 +241,13 @@ class Recognizer:
     def detect(self, b: DeviceBatch, keep_intermediates=False):
         c, ctx, cb = self.cfg, self.ctx, self.codebook
         f = self.compute_features(b)
+        q = f["desc"] if getattr(self, "partial_cols", None) is None else capi.gather_columns(ctx, f["desc"], self.partial_cols)
         if getattr(c, "activation", "KNN") == "KNNRule":
-            idx, dist = capi.knn_rule(ctx, cb, c.metric, f["desc"], c.distance_ratio_threshold)
+            idx, dist = capi.knn_rule(ctx, cb, c.metric, q, c.distance_ratio_threshold)
         elif c.use_distance_ratio and c.k == 1:
-            idx, dist = capi.knn_ratio(ctx, cb, c.metric, f["desc"], c.distance_ratio_threshold)
+            idx, dist = capi.knn_ratio(ctx, cb, c.metric, q, c.distance_ratio_threshold)
         else:
-            idx, dist = capi.knn(ctx, cb, c.metric, f["desc"], c.k)
+            idx, dist = capi.knn(ctx, cb, c.metric, q, c.k)
         votes = capi.cast_votes(ctx, cb, c.weight_flags, f["lrf"], f["kx"], f["ky"], f["kz"], idx, dist)
         slot_off = f["off"].astype(np.uint64) * (c.k * cb.max_votes)
         if c.voting == "Hough3D":

@@ -18,10 +18,15 @@ def detect(ora, cfg, cb, nb, n_classes):
     n_obj = len(nb["pt_off"]) - 1
     off = np.concatenate([[0], np.cumsum([ok[nb["kp_off"][o]:nb["kp_off"][o + 1]].sum() for o in range(n_obj)])]).astype(np.uint32)
     q = desc[ok]
+    words = cb["words"]
+    if getattr(cfg, "use_partial_shot", False):                  # codebook.cpp:416-475 / 862-930: the same signature mask on both sides
+        import importlib
+        cols = __import__("__graft_entry__").load_package().capi.partial_shot_columns(cfg.partial_shot_type)
+        q, words = np.ascontiguousarray(q[:, cols]), np.ascontiguousarray(np.asarray(words)[:, cols])
     if cfg.use_distance_ratio and cfg.k == 1:
-        idx, dist = ora.knn_ratio(cfg.metric, cb["words"], q, cfg.distance_ratio_threshold)
+        idx, dist = ora.knn_ratio(cfg.metric, words, q, cfg.distance_ratio_threshold)
     else:
-        idx, dist = ora.knn(cfg.metric, cb["words"], q, cfg.k)
+        idx, dist = ora.knn(cfg.metric, words, q, cfg.k)
     votes = ora.cast_votes(cb, cfg.weight_flags, lrf[ok], kx[ok], ky[ok], kz[ok], idx, dist)
     maxv = int(np.max(np.diff(np.asarray(cb["vote_offsets"], np.int64))))
     slot_off = (off.astype(np.int64) * idx.shape[1] * maxv).astype(np.uint32)
@@ -32,5 +37,5 @@ def detect(ora, cfg, cb, nb, n_classes):
         mx = ora.find_maxima(slot_off, votes, n_classes, cfg.bandwidth, cfg.threshold, cfg.max_iter, 0 if cfg.kernel == "Gaussian" else 1,
                              {"Average": 0, "Suppress": 1}.get(cfg.maxima_suppression, 2), cfg.min_votes_threshold, cfg.min_threshold, cfg.best_k,
                              cfg.max_maxima)
-    mx.update(desc=q, lrf=lrf[ok], off=off, idx=idx, dist=dist, votes=votes, keep=ok)
+    mx.update(desc=desc[ok], lrf=lrf[ok], off=off, idx=idx, dist=dist, votes=votes, keep=ok)
     return mx

@@ -100,6 +100,43 @@ def test_cfg1_with_hough3d_voting(pkg, gpu, ora):
     np.testing.assert_allclose(got["pos"].cpu().numpy(), want["pos"], atol=1e-4)
 
 
+@pytest.mark.parametrize("kind,n_cols", [("front", 176), ("top", 176), ("dense_x_or_z", 264), ("dense_x_and_z", 88)])
+def test_cfg1_with_partial_shot(pkg, gpu, ora, kind, n_cols):
+    """Codebook.UsePartialShot (codebook.cpp:416-475, 862-930, mask :952-1036): codewords and features are matched on the histograms
+    of a subset of the 32 SHOT signatures; the GPU pipeline against the oracle pipeline with the same column mask."""
+    assert len(pkg.capi.partial_shot_columns(kind)) == n_cols
+    cfg = pkg.pipeline.IsmConfig(feature="SHOT", n_classes=3, use_partial_shot=True, partial_shot_type=kind)
+    syn = pkg.synthetic
+    train = syn.Dataset(3, 6, split=0, n_points=8192, n_keypoints=384)
+    test = syn.Dataset(3, 3, split=1, n_points=8192, n_keypoints=384)
+    got, want, nb = _run(pkg, gpu, ora, cfg, train, test, 6, 3)
+    assert (got["cls"][:, 0].cpu().numpy() == nb["labels"]).all()
+
+
+def test_cfg1_knn_rule_activation_end_to_end(pkg, gpu, ora):
+    """ActivationStrategy KNNRule end to end: trained with plain 1-NN WITHOUT the K = 1 clean-up (multi-vote codewords keep their
+    computeWeights / term1*term2*term3 weights), detected with the class-consistency rule."""
+    cfg = pkg.pipeline.IsmConfig(feature="SHOT", n_classes=3, activation="KNNRule", distance_ratio_threshold=0.9, use_class_weight=True, use_vote_weight=True)
+    syn = pkg.synthetic
+    train = syn.Dataset(3, 6, split=0, n_points=8192, n_keypoints=384)
+    test = syn.Dataset(3, 3, split=1, n_points=8192, n_keypoints=384)
+    ctx, dev = gpu
+    rec = pkg.pipeline.Recognizer(ctx, cfg)
+    order = sorted(range(6), key=lambda i: (train.label(i), i))
+    cb = rec.train([pkg.pipeline.DeviceBatch(train.batch(order), dev)])
+    nb = test.batch(range(3))
+    got = rec.detect(pkg.pipeline.DeviceBatch(nb, dev), keep_intermediates=True)
+    f = got["features"]
+    q = f["desc"].cpu().numpy()
+    wi, wd = ora.knn_rule(cfg.metric, cb["words"], cb["word_class"], q, cfg.distance_ratio_threshold)
+    assert np.array_equal(got["idx"].cpu().numpy().reshape(-1), wi.reshape(-1))
+    votes = ora.cast_votes(cb, cfg.weight_flags, f["lrf"].cpu().numpy(), f["kx"].cpu().numpy(), f["ky"].cpu().numpy(), f["kz"].cpu().numpy(),
+                           wi.reshape(-1, 1), wd.reshape(-1, 1))
+    assert np.array_equal(got["votes"]["cls"].cpu().numpy(), votes["cls"])
+    np.testing.assert_allclose(got["votes"]["weight"].cpu().numpy(), votes["weight"], rtol=1e-5, atol=1e-9)
+    assert (got["cls"][:, 0].cpu().numpy() == nb["labels"]).all()
+
+
 def test_knn_rule_matches_oracle(pkg, gpu, ora):
     import torch
     ctx, dev = gpu

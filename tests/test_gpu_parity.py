@@ -546,6 +546,33 @@ def _vote_scene(rng, n_obj, n_classes, with_empty=True):
     return np.asarray(off, np.uint32), v
 
 
+def test_find_maxima_filter_and_class_bandwidths_match_oracle(pkg, gpu, ora):
+    """MaxFilterType "Simple" (greedy NMS over all classes inside the bandwidth, maxima_handler.cpp:227-268) and per-class
+    bandwidths (BinOrBandwidthType ObjectRadius / BoundingBoxMedian -> MaximaHandler::getSearchDistForClass, :509-521)"""
+    ctx, dev = gpu
+    rng = np.random.default_rng(77)
+    off, v = _vote_scene(rng, 12, 5)
+    # make different classes collide: copy every object's votes once more under another class, slightly shifted
+    v2 = {k: np.concatenate([a, a]) for k, a in v.items()}
+    n = len(v["weight"])
+    v2["cls"][n:] = np.where(v["cls"] >= 0, (v["cls"] + 1) % 5, -1); v2["pos"][n:] += 0.05; v2["weight"][n:] *= 0.7
+    off2 = np.concatenate([off, off[1:] + off[-1]]).astype(np.uint32)          # the copies form 12 further objects ...
+    order = np.concatenate([np.r_[off[o]:off[o + 1], n + off[o]:n + off[o + 1]] for o in range(12)])   # ... interleave them per object instead
+    v3 = {k: a[order] for k, a in v2.items()}
+    off3 = (2 * off.astype(np.int64)).astype(np.uint32)
+    tv = {k2: T(a, dev) for k2, a in v3.items()}
+    for kw in (dict(max_filter=1), dict(class_bandwidth=[0.3, 0.5, 0.8, 0.4, 0.6]), dict(max_filter=1, class_bandwidth=[0.3, 0.5, 0.8, 0.4, 0.6])):
+        kw = dict(n_classes=5, bandwidth=0.5, max_maxima=12, min_votes_threshold=2, **kw)
+        got = pkg.capi.find_maxima(ctx, off3, tv, **kw)
+        want = ora.find_maxima(off3, v3, **kw)
+        assert np.array_equal(got["n"].cpu().numpy(), want["n"]) and np.array_equal(got["cls"].cpu().numpy(), want["cls"]), kw
+        np.testing.assert_allclose(got["weight"].cpu().numpy(), want["weight"], atol=TOL)
+        np.testing.assert_allclose(got["pos"].cpu().numpy(), want["pos"], atol=2e-3)
+    plain = ora.find_maxima(off3, v3, n_classes=5, bandwidth=0.5, max_maxima=12, min_votes_threshold=2)
+    filt = ora.find_maxima(off3, v3, n_classes=5, bandwidth=0.5, max_maxima=12, min_votes_threshold=2, max_filter=1)
+    assert filt["n"].sum() < plain["n"].sum()                                  # the filter did remove colliding maxima
+
+
 @pytest.mark.parametrize("suppression,kernel", [(0, 0), (1, 0), (0, 1)])
 def test_find_maxima_matches_oracle(pkg, gpu, ora, suppression, kernel):
     import torch

@@ -345,6 +345,33 @@ def test_host_hough3d_voting_matches_python_harness(pkg, gpu):
 
 
 @pytest.mark.gpu
+def test_host_partial_shot_and_bandwidth_types(pkg, gpu, tmp_path):
+    """UsePartialShot / PartialShotType, BinOrBandwidthType ObjectRadius and MaxFilterType Simple through the C++ host (the size
+    hints travel in the .ismd): the model still tells the synthetic classes apart, and the per-class hints are the training objects'."""
+    train, test = _dataset(pkg, 3, 9, 6)
+    order = sorted(range(9), key=lambda i: (train.label(i), i))
+    m = hb.Model()
+    m.config_from_json(_cfg(**{"Children/Codebook/Parameters/UsePartialShot": True, "Children/Codebook/Parameters/PartialShotType": "top",
+                               "Children/Voting/Parameters/BinOrBandwidthType": "ObjectRadius", "Children/Voting/Parameters/BinOrBandwidthFactor": 0.6,
+                               "Children/Voting/Parameters/MaxFilterType": "Simple"}))
+    for i in order:
+        o = train.get(i)
+        m.add_training(o["xyz"], o["normals"], o["label"], i)
+    m.train()
+    d0 = m.dimensions(0)
+    radii = [np.linalg.norm(train.get(i)["xyz"] - train.get(i)["xyz"].mean(0), axis=1).max() for i in order if train.label(i) == 0]
+    assert abs(d0[0] - np.mean(radii)) < 1e-4 and d0[1] > 0
+    path = str(tmp_path / "p.ism")
+    m.write(path)
+    m2 = hb.Model()
+    m2.read(path)
+    assert np.allclose(m2.dimensions(0), d0)
+    nb = test.batch(range(6))
+    got = m2.detect_batch(nb["pt_off"], nb["xyz"], nb["normals"], max_maxima=4)
+    assert (got["cls"][:, 0] == nb["labels"]).all()
+
+
+@pytest.mark.gpu
 def test_host_clouds_without_normals_get_them_on_the_device(pkg, gpu):
     """Inputs whose first normal is zero/NaN count as normal-less (implicit_shape_model.cpp:615-625): the host layer then estimates
     normals on the device (ConsistentNormalsMethod 2: inverted z axis of a SHOT frame with NormalRadius at every point), drops points

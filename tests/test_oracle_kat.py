@@ -350,3 +350,14 @@ def test_hough3d_properties(ora):
     assert out["weight"][0, 0] > out["weight"][0, 1] and abs(out["weight"][0, :2].sum() - 1) < 1e-6
     e = ora.hough3d_maxima([0, 0, len(pos)], dict(v, cls=np.full(len(pos), -1, np.int32)), 3, 0.4, max_maxima=4)
     assert e["n"].tolist() == [0, 0]
+
+
+def test_max_filter_simple_keeps_the_heavier_of_two_colliding_classes(ora):
+    """MaximaHandler::filterMaxima "Simple": two classes peaking 0.1 apart (bandwidth 0.5) -> only the heavier maximum survives;
+    a third class far away is untouched; without the filter all three are reported."""
+    pos = [[0, 0, 0]] * 4 + [[0.1, 0, 0]] * 3 + [[5, 0, 0]] * 2
+    v = dict(pos=np.asarray(pos, np.float32), weight=np.ones(9, np.float32), cls=np.asarray([0] * 4 + [1] * 3 + [2] * 2, np.int32), inst=np.zeros(9, np.int32))
+    a = ora.find_maxima([0, 9], v, n_classes=3, bandwidth=0.5, max_maxima=8)
+    b = ora.find_maxima([0, 9], v, n_classes=3, bandwidth=0.5, max_maxima=8, max_filter=1)
+    assert a["n"][0] == 3 and b["n"][0] == 2 and b["cls"][0, :2].tolist() == [0, 2]
+    np.testing.assert_allclose(b["weight"][0, :2], [4 / 6, 2 / 6], atol=1e-6)
