@@ -97,6 +97,11 @@ int  ismhip_cloud_destroy(ismhip_ctx* ctx, ismhip_cloud* cloud);
  * The cloud may have been created with any normal arrays (their values are not read before this call); the outputs
  * (device, original point order, may alias the arrays given to ismhip_cloud_create) also replace the cloud's normals. */
 int  ismhip_estimate_normals(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, float* nx_out, float* ny_out, float* nz_out);
+/* ConsistentNormalsMethod 0 and 1 (implicit_shape_model.cpp:969-1011) -> pcl::NormalEstimationOMPWithEigVals
+ * (third_party/pcl_normal_3d_omp_with_eigenvalues): PCA normal of the NormalRadius neighbourhood (>= 3 points, else NaN), flipped
+ * towards the viewpoint. orientation 0: towards (0,0,0) (method 0); 1: away from the object's centroid (method 1). Outputs as
+ * ismhip_estimate_normals. */
+int  ismhip_estimate_normals_pca(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, int orientation, float* nx_out, float* ny_out, float* nz_out);
 /* per-object centroid (features_shot.cpp:45-51) -> centroid_out[n_obj*3] */
 int  ismhip_cloud_centroids(ismhip_ctx* ctx, const ismhip_cloud* cloud, float* centroid_out);
 

@@ -805,6 +805,95 @@ int ismref_radius_search(int n, const float* x, const float* y, const float* z, 
     return static_cast<int>(nb.size());
 }
 
+/* pcl::NormalEstimationOMPWithEigVals::computeFeature (third_party/pcl_normal_3d_omp_with_eigenvalues/normal_3d_omp_with_eigenvalues.hpp:
+ * 61-144, .h:112-180) as ImplicitShapeModel::computeNormals drives it for ConsistentNormalsMethod 0 / 1 (implicit_shape_model.cpp:
+ * 969-1011). EXTERNAL parts restated from PCL 1.10 (parity unpinned): computeMeanAndCovarianceMatrix = single-pass float sums of
+ * x*x .. z and x, y, z over the neighbours in search order (ascending distance), cov = E[ab] - E[a]E[b]; pcl::eigen33 = analytic
+ * roots of the scaled matrix, eigenvector of the smallest root from the largest cross product of rows of (A - lambda I).
+ * orientation 0: viewpoint (0,0,0); 1: the cloud shifted by its float centroid, viewpoint origin, normals inverted afterwards. */
+namespace {
+void pcl_roots2(float b, float c, float* r) { r[0] = 0.f; float d = b * b - 4.0f * c; if (d < 0.0f) d = 0.0f; const float sd = std::sqrt(d); r[2] = 0.5f * (b + sd); r[1] = 0.5f * (b - sd); }
+void pcl_roots(const float m[3][3], float* r) {
+    const float c0 = m[0][0] * m[1][1] * m[2][2] + 2.f * m[0][1] * m[0][2] * m[1][2] - m[0][0] * m[1][2] * m[1][2] - m[1][1] * m[0][2] * m[0][2] - m[2][2] * m[0][1] * m[0][1];
+    const float c1 = m[0][0] * m[1][1] - m[0][1] * m[0][1] + m[0][0] * m[2][2] - m[0][2] * m[0][2] + m[1][1] * m[2][2] - m[1][2] * m[1][2];
+    const float c2 = m[0][0] + m[1][1] + m[2][2];
+    if (std::fabs(c0) < std::numeric_limits<float>::epsilon()) { pcl_roots2(c2, c1, r); return; }
+    const float s_inv3 = 1.0f / 3.0f, s_sqrt3 = std::sqrt(3.0f);
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.f) a_over_3 = 0.f;
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.f) q = 0.f;
+    const float rho = std::sqrt(-a_over_3), theta = std::atan2(std::sqrt(-q), half_b) * s_inv3, ct = std::cos(theta), st = std::sin(theta);
+    r[0] = c2_over_3 + 2.f * rho * ct; r[1] = c2_over_3 - rho * (ct + s_sqrt3 * st); r[2] = c2_over_3 - rho * (ct - s_sqrt3 * st);
+    if (r[0] >= r[1]) std::swap(r[0], r[1]);
+    if (r[1] >= r[2]) { std::swap(r[1], r[2]); if (r[0] >= r[1]) std::swap(r[0], r[1]); }
+    if (r[0] <= 0) pcl_roots2(c2, c1, r);
+}
+}  // namespace
+int ismref_pca_normals(int n_obj, const uint32_t* po, const float* x, const float* y, const float* z, float radius, int orientation,
+                       float* nx, float* ny, float* nz) {
+    for (int o = 0; o < n_obj; ++o) {
+        const int n = static_cast<int>(po[o + 1] - po[o]);
+        if (n == 0) continue;
+        const float* X = x + po[o]; const float* Y = y + po[o]; const float* Z = z + po[o];
+        std::vector<float> sx(X, X + n), sy(Y, Y + n), sz(Z, Z + n);
+        if (orientation == 1) {                                   // pcl::compute3DCentroid into a Vector4f, then the shifted copy
+            float c[3] = {0, 0, 0}; int cnt = 0;
+            for (int i = 0; i < n; ++i) if (std::isfinite(X[i]) && std::isfinite(Y[i]) && std::isfinite(Z[i])) { c[0] += X[i]; c[1] += Y[i]; c[2] += Z[i]; ++cnt; }
+            for (int d = 0; d < 3; ++d) c[d] /= static_cast<float>(cnt ? cnt : 1);
+            for (int i = 0; i < n; ++i) { sx[i] -= c[0]; sy[i] -= c[1]; sz[i] -= c[2]; }
+        }
+        ObjGrid g; g.build(n, sx.data(), sy.data(), sz.data(), radius);
+#pragma omp parallel
+        {
+            std::vector<std::pair<float, int>> nb;
+#pragma omp for schedule(dynamic, 64)
+            for (int i = 0; i < n; ++i) {
+                float* out[3] = {nx + po[o] + i, ny + po[o] + i, nz + po[o] + i};
+                *out[0] = *out[1] = *out[2] = std::nanf("");
+                if (!(std::isfinite(sx[i]) && std::isfinite(sy[i]) && std::isfinite(sz[i]))) continue;
+                g.radius(sx[i], sy[i], sz[i], radius, nb);
+                if (nb.size() < 3) continue;
+                float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (auto& q : nb) {
+                    const float px = sx[q.second], py = sy[q.second], pz = sz[q.second];
+                    a[0] += px * px; a[1] += px * py; a[2] += px * pz; a[3] += py * py; a[4] += py * pz; a[5] += pz * pz; a[6] += px; a[7] += py; a[8] += pz;
+                }
+                const float cntf = static_cast<float>(nb.size());
+                for (float& v : a) v /= cntf;
+                float cov[3][3];
+                cov[0][0] = a[0] - a[6] * a[6]; cov[0][1] = a[1] - a[6] * a[7]; cov[0][2] = a[2] - a[6] * a[8];
+                cov[1][1] = a[3] - a[7] * a[7]; cov[1][2] = a[4] - a[7] * a[8]; cov[2][2] = a[5] - a[8] * a[8];
+                cov[1][0] = cov[0][1]; cov[2][0] = cov[0][2]; cov[2][1] = cov[1][2];
+                float scale = 0.f;
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) scale = std::max(scale, std::fabs(cov[r][c]));
+                if (scale <= std::numeric_limits<float>::min()) scale = 1.0f;
+                float sm[3][3];
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) sm[r][c] = cov[r][c] / scale;
+                float roots[3];
+                pcl_roots(sm, roots);
+                for (int d = 0; d < 3; ++d) sm[d][d] -= roots[0];
+                auto cross = [](const float* u, const float* v, float* w) { w[0] = u[1] * v[2] - u[2] * v[1]; w[1] = u[2] * v[0] - u[0] * v[2]; w[2] = u[0] * v[1] - u[1] * v[0]; };
+                float v1[3], v2[3], v3[3];
+                cross(sm[0], sm[1], v1); cross(sm[0], sm[2], v2); cross(sm[1], sm[2], v3);
+                const float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2], l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2], l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+                float nrm[3];
+                if (l1 >= l2 && l1 >= l3) { const float s_ = std::sqrt(l1); for (int d = 0; d < 3; ++d) nrm[d] = v1[d] / s_; }
+                else if (l2 >= l1 && l2 >= l3) { const float s_ = std::sqrt(l2); for (int d = 0; d < 3; ++d) nrm[d] = v2[d] / s_; }
+                else { const float s_ = std::sqrt(l3); for (int d = 0; d < 3; ++d) nrm[d] = v3[d] / s_; }
+                // flipNormalTowardsViewpointMod with the viewpoint at the origin of the (possibly shifted) cloud
+                const float cos_theta = (0.f - sx[i]) * nrm[0] + (0.f - sy[i]) * nrm[1] + (0.f - sz[i]) * nrm[2];
+                if (cos_theta < 0) { nrm[0] *= -1; nrm[1] *= -1; nrm[2] *= -1; }
+                if (orientation == 1) { nrm[0] *= -1; nrm[1] *= -1; nrm[2] *= -1; }
+                *out[0] = nrm[0]; *out[1] = nrm[1]; *out[2] = nrm[2];
+            }
+        }
+    }
+    return 0;
+}
+
 int ismref_shot_lrf(int n_obj, const uint32_t* po, const float* x, const float* y, const float* z,
                     const uint32_t* ko, const float* kpx, const float* kpy, const float* kpz,
                     float radius, float* lrf9_out) {

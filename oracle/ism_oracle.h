@@ -102,6 +102,10 @@ int  ismref_find_maxima(int n_obj, const uint32_t* slot_offsets,
                         int32_t* max_class_out, int32_t* max_instance_out, float* max_instance_weight_out,
                         float* max_bbox_size_out, int32_t* max_n_votes_out, float* class_score_out);
 
+/* ConsistentNormalsMethod 0 / 1: PCA normals of pcl::NormalEstimationOMPWithEigVals (implicit_shape_model.cpp:969-1011); original point order */
+int  ismref_pca_normals(int n_obj, const uint32_t* pt_offsets, const float* x, const float* y, const float* z, float radius, int orientation,
+                        float* nx_out, float* ny_out, float* nz_out);
+
 /* VotingHough3D (voting/voting_hough_3d.cpp:33-95) over pcl::recognition::HoughSpace3D; same outputs as
  * ismref_find_maxima. Layout identical to ismhip_hough_params. */
 typedef struct ismref_hough_params {

@@ -307,3 +307,11 @@ def activate(metric, feats, lrf, kp, feat_class, feat_model, feat_center, k=1, c
     m = nw.value; nv = int(vo[m])
     return dict(word_src=word_src[:m].copy(), vote_offsets=vo[:m + 1].copy(), vote_feature=vf[:nv].copy(), vote_xyz=vxyz[:nv].copy(),
                 vote_weight=vw[:nv].copy(), vote_class_weight=vcw[:nv].copy(), class_sigma=sig)
+
+
+def pca_normals(pt_off, x, y, z, radius, orientation):
+    po = _u(pt_off); x, y, z = map(_f, (x, y, z))
+    n = len(x)
+    nx = np.empty(n, np.float32); ny = np.empty(n, np.float32); nz = np.empty(n, np.float32)
+    lib().ismref_pca_normals(C.c_int(len(po) - 1), _p(po), _p(x), _p(y), _p(z), C.c_float(radius), C.c_int(orientation), _p(nx), _p(ny), _p(nz))
+    return np.stack([nx, ny, nz], 1)

@@ -21,7 +21,7 @@ ERR_NODEVICE = -5
 EXPORTS = [
     "ismhip_abi_version", "ismhip_ctx_create", "ismhip_ctx_create_on_stream", "ismhip_ctx_destroy", "ismhip_sync", "ismhip_last_error",
     "ismhip_timers_enable", "ismhip_timers_reset", "ismhip_timer_get",
-    "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids", "ismhip_estimate_normals",
+    "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids", "ismhip_estimate_normals", "ismhip_estimate_normals_pca",
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
     "ismhip_compact_features", "ismhip_voxel_keypoints", "ismhip_gather_columns",
     "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word",
@@ -257,6 +257,13 @@ def center_dist(ctx, cloud, kp_offsets, kpx, kpy, kpz):
 def estimate_normals(ctx, cloud, radius, nx, ny, nz):
     """ImplicitShapeModel::computeNormals (method 2): fills nx, ny, nz (device tensors, original order) and the cloud's own copies"""
     ctx.check(lib().ismhip_estimate_normals(ctx._h, cloud._h, C.c_float(radius), _p(nx), _p(ny), _p(nz)), "ismhip_estimate_normals")
+    cloud._keep = getattr(cloud, "_keep", ()) + (nx, ny, nz)
+    return nx, ny, nz
+
+
+def estimate_normals_pca(ctx, cloud, radius, orientation, nx, ny, nz):
+    """ConsistentNormalsMethod 0 (orientation 0: towards the origin) / 1 (orientation 1: away from the object's centroid)"""
+    ctx.check(lib().ismhip_estimate_normals_pca(ctx._h, cloud._h, C.c_float(radius), C.c_int(orientation), _p(nx), _p(ny), _p(nz)), "ismhip_estimate_normals_pca")
     cloud._keep = getattr(cloud, "_keep", ()) + (nx, ny, nz)
     return nx, ny, nz
 

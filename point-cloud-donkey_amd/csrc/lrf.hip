@@ -362,6 +362,86 @@ __global__ __launch_bounds__(256) void k_sorted_normals(const uint32_t* __restri
 }
 }  // namespace
 
+// ---- PCA normals: ImplicitShapeModel::computeNormals, ConsistentNormalsMethod 0 and 1 (implicit_shape_model.cpp:969-1011) ->
+// pcl::NormalEstimationOMPWithEigVals (third_party/pcl_normal_3d_omp_with_eigenvalues/normal_3d_omp_with_eigenvalues.hpp:61-144,
+// .h:112-180): neighbours within NormalRadius (the point itself included), fewer than 3 -> NaN; normal = eigenvector of the smallest
+// eigenvalue of the neighbourhood covariance, flipped towards the viewpoint. Method 0: viewpoint (0,0,0). Method 1: the cloud is
+// shifted by its centroid, normals are flipped towards the origin and then inverted, i.e. they point AWAY from the centroid.
+// One wave per (cell-sorted) point: FP64 moments of (p - q) per lane + wave reduction (the reference's single-pass float formula
+// E[xx] - E[x]E[x] on absolute coordinates loses ~4 digits on unit-sized objects; this is the better-conditioned evaluation of the
+// same covariance), Jacobi solver of eigen3.h, results scattered to the caller's (original-order) arrays and into the sorted copy.
+namespace {
+__global__ __launch_bounds__(256) void k_pca_normals(CloudView cv, float radius, float r2, int orientation,
+                                                     float* __restrict__ nx, float* __restrict__ ny, float* __restrict__ nz, float4* __restrict__ sn4) {
+    int o, bx;
+    if (!xcd_object_block(cv.nbx, cv.n_obj, o, bx)) return;
+    const GridMeta m = cv.meta[o];
+    const uint32_t sidx = (uint32_t)bx * 4 + (threadIdx.x >> 6);
+    if (sidx >= m.n_finite) return;
+    const int lane = lane_id();
+    const uint32_t base = cv.pt_off[o];
+    const float4 q = cv.sp4[base + sidx];
+    const uint32_t* cs = cv.cell_start + (size_t)o * ISM_GRID_STRIDE;
+    CellRange cr;
+    double sx = 0, sy = 0, sz = 0, xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+    int cnt = 0;
+    __shared__ WaveRows s_rows[4];
+    if (ball_cells(m, q.x, q.y, q.z, radius, cr))
+        ball_for_each(m, cs, cr, q.x, q.y, q.z, radius, lane, s_rows[threadIdx.x >> 6],
+                      [&](uint32_t t, bool v) { return v ? cv.sp4[base + t] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                      [&](const float4& p, uint32_t, bool v) {
+            if (!v) return;
+            if (sqdist3(p.x, p.y, p.z, q.x, q.y, q.z) < r2) {
+                const double dx = (double)p.x - (double)q.x, dy = (double)p.y - (double)q.y, dz = (double)p.z - (double)q.z;
+                sx += dx; sy += dy; sz += dz;
+                xx = fma(dx, dx, xx); xy = fma(dx, dy, xy); xz = fma(dx, dz, xz); yy = fma(dy, dy, yy); yz = fma(dy, dz, yz); zz = fma(dz, dz, zz);
+                cnt++;
+            }
+        });
+    sx = wave_sum_d(sx); sy = wave_sum_d(sy); sz = wave_sum_d(sz);
+    xx = wave_sum_d(xx); xy = wave_sum_d(xy); xz = wave_sum_d(xz); yy = wave_sum_d(yy); yz = wave_sum_d(yz); zz = wave_sum_d(zz);
+    cnt = wave_sum_i(cnt);
+    if (lane != 0) return;
+    const uint32_t orig = base + __float_as_uint(q.w);
+    float n0 = __builtin_nanf(""), n1 = n0, n2 = n0;
+    if (cnt >= 3) {
+        const double inv = 1.0 / (double)cnt, mx = sx * inv, my = sy * inv, mz = sz * inv;
+        double A[3][3] = {{xx * inv - mx * mx, xy * inv - mx * my, xz * inv - mx * mz}, {xy * inv - mx * my, yy * inv - my * my, yz * inv - my * mz},
+                          {xz * inv - mx * mz, yz * inv - my * mz, zz * inv - mz * mz}};
+        double w[3], V[3][3];
+        eigen_sym3(A, w, V);
+        n0 = (float)V[0][0]; n1 = (float)V[1][0]; n2 = (float)V[2][0];
+        // flipNormalTowardsViewpointMod (.h:162-180): flip when (viewpoint - point) . n < 0
+        const float vx = (orientation == 1 ? m.centroid[0] : 0.f) - q.x, vy = (orientation == 1 ? m.centroid[1] : 0.f) - q.y, vz = (orientation == 1 ? m.centroid[2] : 0.f) - q.z;
+        if (vx * n0 + vy * n1 + vz * n2 < 0) { n0 = -n0; n1 = -n1; n2 = -n2; }
+        if (orientation == 1) { n0 = -n0; n1 = -n1; n2 = -n2; }               // implicit_shape_model.cpp:996-1002
+    }
+    nx[orig] = n0; ny[orig] = n1; nz[orig] = n2;
+    sn4[base + sidx] = make_float4(n0, n1, n2, 0.f);
+}
+}  // namespace
+
+extern "C" int ismhip_estimate_normals_pca(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, int orientation, float* nx_out, float* ny_out, float* nz_out) {
+    if (!ctx || !cloud || !nx_out || !ny_out || !nz_out || !(radius > 0.f) || (orientation != 0 && orientation != 1))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "estimate_normals_pca: bad argument");
+    const uint32_t n = cloud->n_pts;
+    if (n == 0 || cloud->max_pts == 0) return ISMHIP_OK;
+    const int n_obj = cloud->n_obj;
+    const unsigned nbx = (cloud->max_pts + 3) / 4;
+    CloudView cv{cloud->pt_off, cloud->meta, cloud->cell_start, cloud->sp4, cloud->x, cloud->y, cloud->z, ctx->xcd_map ? n_obj : 0, (int)nbx};
+    const float r2 = (float)((double)radius * (double)radius);
+    TimerScope ts(ctx, "normals_pca");
+    // points that are not finite never enter the sorted copy: their normals are NaN
+    ISM_HIP(ctx, hipMemsetAsync(nx_out, 0xff, (size_t)n * 4, ctx->stream));
+    ISM_HIP(ctx, hipMemsetAsync(ny_out, 0xff, (size_t)n * 4, ctx->stream));
+    ISM_HIP(ctx, hipMemsetAsync(nz_out, 0xff, (size_t)n * 4, ctx->stream));
+    const dim3 grid(ctx->xcd_map ? xcd_object_grid(nbx, n_obj) : nbx * (unsigned)n_obj);
+    hipLaunchKernelGGL(k_pca_normals, grid, dim3(256), 0, ctx->stream, cv, radius, r2, orientation, nx_out, ny_out, nz_out, cloud->sn4);
+    ISM_CHECK_LAUNCH(ctx, "k_pca_normals");
+    cloud->nx = nx_out; cloud->ny = ny_out; cloud->nz = nz_out;
+    return ISMHIP_OK;
+}
+
 extern "C" int ismhip_estimate_normals(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, float* nx_out, float* ny_out, float* nz_out) {
     if (!ctx || !cloud || !nx_out || !ny_out || !nz_out || !(radius > 0.f)) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "estimate_normals: bad argument");
     const uint32_t n = cloud->n_pts;

@@ -985,9 +985,9 @@ std::shared_ptr<DeviceFeatures> ImplicitShapeModel::computeFeatures(const std::v
         std::vector<size_t> need;
         for (size_t i = 0; i < clouds.size(); ++i) if (!firstNormalValid(*clouds[i])) need.push_back(i);
         if (!need.empty()) {
-            if (m_consistent_normals_method != 2)
+            if (m_consistent_normals_method < 0 || m_consistent_normals_method > 2)
                 throw RuntimeException("input cloud has no normals and ConsistentNormalsMethod " + std::to_string(m_consistent_normals_method) +
-                                       " is not built (built: 2 = SHOT reference frames)");
+                                       " is not built (built: 0 = PCA towards the origin, 1 = PCA away from the centroid, 2 = SHOT reference frames)");
             std::vector<std::unique_ptr<PointCloud>> tmp;
             std::vector<const PointCloud*> part;
             for (size_t i : need) {
@@ -998,7 +998,11 @@ std::shared_ptr<DeviceFeatures> ImplicitShapeModel::computeFeatures(const std::v
             }
             const std::vector<KeypointSet> none(part.size());
             s.uploadBatch(part, &none, m_normal_radius * 0.5f, false);
-            s.check(ismhip_estimate_normals(s.ctx, s.cloud, m_normal_radius, s.nx.as<float>(), s.ny.as<float>(), s.nz.as<float>()), "ismhip_estimate_normals");
+            if (m_consistent_normals_method == 2)
+                s.check(ismhip_estimate_normals(s.ctx, s.cloud, m_normal_radius, s.nx.as<float>(), s.ny.as<float>(), s.nz.as<float>()), "ismhip_estimate_normals");
+            else                                                // :969-1003
+                s.check(ismhip_estimate_normals_pca(s.ctx, s.cloud, m_normal_radius, m_consistent_normals_method, s.nx.as<float>(), s.ny.as<float>(), s.nz.as<float>()),
+                        "ismhip_estimate_normals_pca");
             std::vector<float> hnx, hny, hnz;
             const size_t n_all = s.pt_off.back();
             s.d2h(hnx, s.nx, n_all); s.d2h(hny, s.ny, n_all); s.d2h(hnz, s.nz, n_all);

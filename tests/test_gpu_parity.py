@@ -455,6 +455,45 @@ def test_voxel_keypoints_match_oracle(pkg, gpu, ora, leaf, color):
     assert ko[2] - ko[1] == 0 and ko[3] - ko[2] == 1
 
 
+@pytest.mark.parametrize("orientation", [0, 1])
+def test_estimate_normals_pca(pkg, gpu, ora, orientation):
+    """ConsistentNormalsMethod 0 / 1: PCA normals (pcl::NormalEstimationOMPWithEigVals) flipped towards the origin / away from the
+    object's centroid. The oracle follows PCL's single-pass FLOAT covariance (E[ab] - E[a]E[b] on absolute coordinates) and analytic
+    eigen33; the device accumulates centred moments in double and uses the Jacobi solver -- same covariance, better conditioned --
+    so the normals agree to the precision of PCL's own arithmetic (2e-3 here), NaN pattern and orientation exactly."""
+    import torch
+    ctx, dev = gpu
+    rng = np.random.default_rng(50 + orientation)
+    o0 = make_cloud(rng, 4000, "ellipsoid")[0] + np.float32([1.5, -0.7, 0.4])       # off-origin: the origin is a real viewpoint
+    o1 = make_cloud(rng, 3000, "sphere", noise=0.005)[0] * 0.8 + np.float32([0.1, 0.2, 2.5])
+    o2 = np.array([[0, 0, 0], [5, 5, 5]], np.float32)                                # two isolated points: < 3 neighbours -> NaN
+    objs = [o0, o1, o2]
+    off = np.concatenate([[0], np.cumsum([len(o) for o in objs])]).astype(np.uint32)
+    P = np.concatenate(objs).astype(np.float32)
+    P[17] = np.nan
+    t = [T(P[:, i].copy(), dev) for i in range(3)]
+    zn = [torch.zeros(len(P), dtype=torch.float32, device=dev) for _ in range(3)]
+    cloud = pkg.capi.Cloud(ctx, off, *t, *zn, 0.06)
+    out = [torch.empty(len(P), dtype=torch.float32, device=dev) for _ in range(3)]
+    pkg.capi.estimate_normals_pca(ctx, cloud, 0.15, orientation, *out)
+    got = np.stack([a.cpu().numpy() for a in out], 1)
+    want = ora.pca_normals(off, P[:, 0], P[:, 1], P[:, 2], 0.15, orientation)
+    assert np.array_equal(np.isnan(got).any(1), np.isnan(want).any(1)) and np.isnan(got[-1]).all() and np.isnan(got[17]).all()
+    m = ~np.isnan(want).any(1)
+    dots = (got[m] * want[m]).sum(1)
+    assert (dots > 0).mean() > 0.999                              # same orientation (a flip needs cos_theta ~ 0)
+    ang = np.arccos(np.clip(np.abs(dots), 0, 1))
+    assert np.quantile(ang, 0.995) < 2e-3, np.quantile(ang, 0.995)
+    np.testing.assert_allclose(np.linalg.norm(got[m], axis=1), 1.0, atol=1e-5)
+    # the ellipsoid's analytic normals: PCA normals are close to them and point away from its centre (orientation 1) ...
+    c0 = o0.mean(0)
+    if orientation == 1:
+        assert ((got[:4000][~np.isnan(got[:4000]).any(1)] * (o0 - c0)[~np.isnan(got[:4000]).any(1)]).sum(1) > 0).mean() > 0.99
+    else:                                                         # ... or face the origin (orientation 0)
+        g0 = got[:4000]; ok = ~np.isnan(g0).any(1)
+        assert ((g0[ok] * (-P[:4000][ok])).sum(1) >= 0).all()
+
+
 def test_estimate_normals_from_shot_frames(pkg, gpu, ora):
     """ImplicitShapeModel::computeNormals, ConsistentNormalsMethod 2: normal = inverted z axis of the SHOT frame (radius NormalRadius)
     at every point, NaN where the frame is invalid. The cloud is created with zero normals; after the call its own (cell-sorted)

@@ -388,9 +388,18 @@ def test_host_clouds_without_normals_get_them_on_the_device(pkg, gpu):
     nb = test.batch(range(6))
     got = m.detect_batch(nb["pt_off"], nb["xyz"], np.zeros_like(nb["normals"]), max_maxima=4)
     assert (got["cls"][:, 0] == nb["labels"]).all()
-    m.config_from_json(_cfg(**{"Parameters/NormalRadius": 0.15, "Parameters/ConsistentNormalsMethod": 0}))
-    with pytest.raises(hb.HostError, match="ConsistentNormalsMethod 0 is not built"):
+    m.config_from_json(_cfg(**{"Parameters/NormalRadius": 0.15, "Parameters/ConsistentNormalsMethod": 7}))
+    with pytest.raises(hb.HostError, match="ConsistentNormalsMethod 7 is not built"):
         m.detect_batch(nb["pt_off"], nb["xyz"], np.zeros_like(nb["normals"]), max_maxima=4)
+    # method 1 (PCA normals pointing away from the centroid): train and detect without input normals
+    m1 = hb.Model()
+    m1.config_from_json(_cfg(**{"Parameters/NormalRadius": 0.15, "Parameters/ConsistentNormalsMethod": 1}))
+    for i in order:
+        o = train.get(i)
+        m1.add_training(o["xyz"], np.zeros_like(o["normals"]), o["label"], i)
+    m1.train()
+    got = m1.detect_batch(nb["pt_off"], nb["xyz"], np.zeros_like(nb["normals"]), max_maxima=4)
+    assert (got["cls"][:, 0] == nb["labels"]).all()
 
 
 @pytest.mark.gpu
