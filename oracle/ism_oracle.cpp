@@ -810,7 +810,9 @@ int ismref_radius_search(int n, const float* x, const float* y, const float* z, 
  * 969-1011). EXTERNAL parts restated from PCL 1.10 (parity unpinned): computeMeanAndCovarianceMatrix = single-pass float sums of
  * x*x .. z and x, y, z over the neighbours in search order (ascending distance), cov = E[ab] - E[a]E[b]; pcl::eigen33 = analytic
  * roots of the scaled matrix, eigenvector of the smallest root from the largest cross product of rows of (A - lambda I).
- * orientation 0: viewpoint (0,0,0); 1: the cloud shifted by its float centroid, viewpoint origin, normals inverted afterwards. */
+ * orientation 0: viewpoint (0,0,0); 1: the cloud shifted by its float centroid, viewpoint origin, normals inverted afterwards;
+ * 2: no flip at all = pcl::NormalEstimation::computePointNormal(cloud, indices, nx, ny, nz, curvature), the call
+ * NormalOrientation::processSHOTLRF makes for its patch-up loop (utils/normal_orientation.cpp:96-106). */
 namespace {
 void pcl_roots2(float b, float c, float* r) { r[0] = 0.f; float d = b * b - 4.0f * c; if (d < 0.0f) d = 0.0f; const float sd = std::sqrt(d); r[2] = 0.5f * (b + sd); r[1] = 0.5f * (b - sd); }
 void pcl_roots(const float m[3][3], float* r) {
@@ -885,7 +887,7 @@ int ismref_pca_normals(int n_obj, const uint32_t* po, const float* x, const floa
                 else { const float s_ = std::sqrt(l3); for (int d = 0; d < 3; ++d) nrm[d] = v3[d] / s_; }
                 // flipNormalTowardsViewpointMod with the viewpoint at the origin of the (possibly shifted) cloud
                 const float cos_theta = (0.f - sx[i]) * nrm[0] + (0.f - sy[i]) * nrm[1] + (0.f - sz[i]) * nrm[2];
-                if (cos_theta < 0) { nrm[0] *= -1; nrm[1] *= -1; nrm[2] *= -1; }
+                if (cos_theta < 0 && orientation != 2) { nrm[0] *= -1; nrm[1] *= -1; nrm[2] *= -1; }
                 if (orientation == 1) { nrm[0] *= -1; nrm[1] *= -1; nrm[2] *= -1; }
                 *out[0] = nrm[0]; *out[1] = nrm[1]; *out[2] = nrm[2];
             }

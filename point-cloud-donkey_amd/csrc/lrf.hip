@@ -338,17 +338,45 @@ extern "C" int ismhip_shot_lrf(ismhip_ctx* ctx, const ismhip_cloud* cloud, const
 // ---- normals from the SHOT frame (the step in front of the path) -------------------------------------------
 // Reference seam: ImplicitShapeModel::computeNormals with ConsistentNormalsMethod 2, the default (implicit_shape_model.cpp:
 // 1014-1018) -> NormalOrientation::processSHOTLRF (utils/normal_orientation.cpp:48-110): a SHOT frame with radius NormalRadius at
-// EVERY point of the cloud, normal = inverted z axis. Points whose frame is invalid (< 5 neighbours) get a NaN normal here and are
-// dropped as "points with NaN normals" later; the reference patches them through a mis-indexed loop (it recomputes the normals of
-// points 0..k-1 instead of the k invalid ones, normal_orientation.cpp:92-104) -- that accident is not reproduced.
+// EVERY point of the cloud, normal = inverted z axis. The arrays hold the PCA normals (flipped towards the origin) when this runs
+// (implicit_shape_model.cpp:1016), so a point whose frame is invalid (< 5 neighbours) KEEPS its PCA normal. The reference then means
+// to recompute the k invalid ones but indexes its loop with the loop counter (normal_orientation.cpp:96-106): points 0..k-1 of the
+// NaN-free cloud get NormalEstimation::computePointNormal's normal instead -- the same PCA normal WITHOUT the viewpoint flip (sign =
+// pcl::eigen33's) -- whether their frame was valid or not. Reproduced as is: one workgroup per object, finite points in input order.
 namespace {
-__global__ __launch_bounds__(256) void k_normals_from_lrf(uint32_t n, const float* __restrict__ lrf, float* __restrict__ nx, float* __restrict__ ny, float* __restrict__ nz) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float* f = lrf + (size_t)i * 9;
-    const bool ok = isfinite(f[0]) && isfinite(f[3]) && isfinite(f[6]);
-    const float q = __builtin_nanf("");
-    nx[i] = ok ? -f[6] : q; ny[i] = ok ? -f[7] : q; nz[i] = ok ? -f[8] : q;
+__global__ __launch_bounds__(256) void k_normals_from_lrf(const uint32_t* __restrict__ pt_off, const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ z, const float* __restrict__ lrf, const uint8_t* __restrict__ rawflip,
+                                                          float* __restrict__ nx, float* __restrict__ ny, float* __restrict__ nz) {
+    const uint32_t base = pt_off[blockIdx.x], n = pt_off[blockIdx.x + 1] - base;
+    __shared__ uint32_t s_cnt[4], s_inv;
+    auto finite_pt = [&](uint32_t i) { return isfinite(x[base + i]) && isfinite(y[base + i]) && isfinite(z[base + i]); };
+    auto frame_ok = [&](uint32_t i) { const float* f = lrf + (size_t)(base + i) * 9; return isfinite(f[0]) && isfinite(f[3]) && isfinite(f[6]); };
+    if (threadIdx.x == 0) s_inv = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) mine += (finite_pt(i) && !frame_ok(i)) ? 1u : 0u;
+    mine = (uint32_t)wave_sum_i((int)mine);
+    if (lane_id() == 0 && mine) atomicAdd(&s_inv, mine);
+    __syncthreads();
+    const uint32_t n_inv = s_inv;
+    uint32_t rank0 = 0;                                                         // finite points in front of this chunk
+    for (uint32_t c = 0; c < n; c += 256) {
+        const uint32_t i = c + threadIdx.x;
+        const bool fin = i < n && finite_pt(i);
+        const unsigned long long b = __ballot(fin);
+        if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t r = rank0 + (uint32_t)__popcll(b & ((1ull << lane_id()) - 1ull));
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) r += s_cnt[w];
+        const uint32_t chunk = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+        if (fin) {
+            const uint32_t g = base + i;
+            if (r < n_inv) { if (rawflip[g]) { nx[g] = -nx[g]; ny[g] = -ny[g]; nz[g] = -nz[g]; } }
+            else if (frame_ok(i)) { const float* f = lrf + (size_t)g * 9; nx[g] = -f[6]; ny[g] = -f[7]; nz[g] = -f[8]; }
+        }
+        rank0 += chunk;
+    }
 }
 // the cloud's cell-sorted normal copies follow (sorted position s of object o holds the original point in sp4[s].w)
 __global__ __launch_bounds__(256) void k_sorted_normals(const uint32_t* __restrict__ pt_off, const GridMeta* __restrict__ meta, const float4* __restrict__ sp4,
@@ -371,8 +399,12 @@ __global__ __launch_bounds__(256) void k_sorted_normals(const uint32_t* __restri
 // E[xx] - E[x]E[x] on absolute coordinates loses ~4 digits on unit-sized objects; this is the better-conditioned evaluation of the
 // same covariance), Jacobi solver of eigen3.h, results scattered to the caller's (original-order) arrays and into the sorted copy.
 namespace {
+__device__ __forceinline__ void cross3(const double* u, const double* v, double* w) {
+    w[0] = u[1] * v[2] - u[2] * v[1]; w[1] = u[2] * v[0] - u[0] * v[2]; w[2] = u[0] * v[1] - u[1] * v[0];
+}
 __global__ __launch_bounds__(256) void k_pca_normals(CloudView cv, float radius, float r2, int orientation,
-                                                     float* __restrict__ nx, float* __restrict__ ny, float* __restrict__ nz, float4* __restrict__ sn4) {
+                                                     float* __restrict__ nx, float* __restrict__ ny, float* __restrict__ nz, float4* __restrict__ sn4,
+                                                     uint8_t* __restrict__ rawflip) {
     int o, bx;
     if (!xcd_object_block(cv.nbx, cv.n_obj, o, bx)) return;
     const GridMeta m = cv.meta[o];
@@ -411,19 +443,35 @@ __global__ __launch_bounds__(256) void k_pca_normals(CloudView cv, float radius,
         double w[3], V[3][3];
         eigen_sym3(A, w, V);
         n0 = (float)V[0][0]; n1 = (float)V[1][0]; n2 = (float)V[2][0];
+        bool raw_neg = false;
+        if (rawflip) {
+            // the sign pcl::eigen33 gives its eigenvector (no viewpoint flip: NormalEstimation::computePointNormal): the largest of
+            // the three cross products of rows of (A / scale - lambda I)
+            double sc = 0;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) sc = fmax(sc, fabs(A[r][c]));
+            if (!(sc > 0)) sc = 1.0;
+            double B[3][3];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) B[r][c] = A[r][c] / sc - (r == c ? w[0] / sc : 0.0);
+            double c1[3], c2[3], c3[3];
+            cross3(B[0], B[1], c1); cross3(B[0], B[2], c2); cross3(B[1], B[2], c3);
+            const double l1 = c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2], l2 = c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2], l3 = c3[0] * c3[0] + c3[1] * c3[1] + c3[2] * c3[2];
+            const double* cb = (l1 >= l2 && l1 >= l3) ? c1 : (l2 >= l1 && l2 >= l3) ? c2 : c3;
+            raw_neg = cb[0] * V[0][0] + cb[1] * V[1][0] + cb[2] * V[2][0] < 0;
+        }
         // flipNormalTowardsViewpointMod (.h:162-180): flip when (viewpoint - point) . n < 0
         const float vx = (orientation == 1 ? m.centroid[0] : 0.f) - q.x, vy = (orientation == 1 ? m.centroid[1] : 0.f) - q.y, vz = (orientation == 1 ? m.centroid[2] : 0.f) - q.z;
-        if (vx * n0 + vy * n1 + vz * n2 < 0) { n0 = -n0; n1 = -n1; n2 = -n2; }
-        if (orientation == 1) { n0 = -n0; n1 = -n1; n2 = -n2; }               // implicit_shape_model.cpp:996-1002
+        bool neg = false;
+        if (vx * n0 + vy * n1 + vz * n2 < 0) neg = !neg;
+        if (orientation == 1) neg = !neg;                                      // implicit_shape_model.cpp:996-1002
+        if (neg) { n0 = -n0; n1 = -n1; n2 = -n2; }
+        if (rawflip) rawflip[orig] = (neg != raw_neg) ? 1 : 0;                 // 1: the stored normal is the negated eigen33 vector
     }
     nx[orig] = n0; ny[orig] = n1; nz[orig] = n2;
     sn4[base + sidx] = make_float4(n0, n1, n2, 0.f);
 }
 }  // namespace
 
-extern "C" int ismhip_estimate_normals_pca(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, int orientation, float* nx_out, float* ny_out, float* nz_out) {
-    if (!ctx || !cloud || !nx_out || !ny_out || !nz_out || !(radius > 0.f) || (orientation != 0 && orientation != 1))
-        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "estimate_normals_pca: bad argument");
+static int pca_normals(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, int orientation, float* nx_out, float* ny_out, float* nz_out, uint8_t* rawflip) {
     const uint32_t n = cloud->n_pts;
     if (n == 0 || cloud->max_pts == 0) return ISMHIP_OK;
     const int n_obj = cloud->n_obj;
@@ -436,21 +484,30 @@ extern "C" int ismhip_estimate_normals_pca(ismhip_ctx* ctx, ismhip_cloud* cloud,
     ISM_HIP(ctx, hipMemsetAsync(ny_out, 0xff, (size_t)n * 4, ctx->stream));
     ISM_HIP(ctx, hipMemsetAsync(nz_out, 0xff, (size_t)n * 4, ctx->stream));
     const dim3 grid(ctx->xcd_map ? xcd_object_grid(nbx, n_obj) : nbx * (unsigned)n_obj);
-    hipLaunchKernelGGL(k_pca_normals, grid, dim3(256), 0, ctx->stream, cv, radius, r2, orientation, nx_out, ny_out, nz_out, cloud->sn4);
+    hipLaunchKernelGGL(k_pca_normals, grid, dim3(256), 0, ctx->stream, cv, radius, r2, orientation, nx_out, ny_out, nz_out, cloud->sn4, rawflip);
     ISM_CHECK_LAUNCH(ctx, "k_pca_normals");
     cloud->nx = nx_out; cloud->ny = ny_out; cloud->nz = nz_out;
     return ISMHIP_OK;
+}
+extern "C" int ismhip_estimate_normals_pca(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, int orientation, float* nx_out, float* ny_out, float* nz_out) {
+    if (!ctx || !cloud || !nx_out || !ny_out || !nz_out || !(radius > 0.f) || (orientation != 0 && orientation != 1))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "estimate_normals_pca: bad argument");
+    return pca_normals(ctx, cloud, radius, orientation, nx_out, ny_out, nz_out, nullptr);
 }
 
 extern "C" int ismhip_estimate_normals(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, float* nx_out, float* ny_out, float* nz_out) {
     if (!ctx || !cloud || !nx_out || !ny_out || !nz_out || !(radius > 0.f)) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "estimate_normals: bad argument");
     const uint32_t n = cloud->n_pts;
     if (n == 0) return ISMHIP_OK;
-    float* lrf = (float*)ism_scratch(ctx, SCR_FPFH_SPFH, (size_t)n * 9 * sizeof(float));
+    float* lrf = (float*)ism_scratch(ctx, SCR_FPFH_SPFH, (size_t)n * 9 * sizeof(float) + n);
     if (!lrf) return ISMHIP_ERR_NOMEM;
-    int rc = ismhip_shot_lrf(ctx, cloud, cloud->pt_off_h.data(), cloud->x, cloud->y, cloud->z, radius, lrf);
+    uint8_t* rawflip = (uint8_t*)(lrf + (size_t)n * 9);
+    int rc = pca_normals(ctx, cloud, radius, 0, nx_out, ny_out, nz_out, rawflip);
     if (rc != ISMHIP_OK) return rc;
-    hipLaunchKernelGGL(k_normals_from_lrf, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, lrf, nx_out, ny_out, nz_out);
+    rc = ismhip_shot_lrf(ctx, cloud, cloud->pt_off_h.data(), cloud->x, cloud->y, cloud->z, radius, lrf);
+    if (rc != ISMHIP_OK) return rc;
+    hipLaunchKernelGGL(k_normals_from_lrf, dim3(cloud->n_obj), dim3(256), 0, ctx->stream, cloud->pt_off, cloud->x, cloud->y, cloud->z, lrf, rawflip,
+                       nx_out, ny_out, nz_out);
     ISM_CHECK_LAUNCH(ctx, "k_normals_from_lrf");
     hipLaunchKernelGGL(k_sorted_normals, dim3((cloud->max_pts + 255) / 256, cloud->n_obj), dim3(256), 0, ctx->stream, cloud->pt_off, cloud->meta, cloud->sp4,
                        nx_out, ny_out, nz_out, cloud->sn4);

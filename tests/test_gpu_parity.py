@@ -495,16 +495,22 @@ def test_estimate_normals_pca(pkg, gpu, ora, orientation):
 
 
 def test_estimate_normals_from_shot_frames(pkg, gpu, ora):
-    """ImplicitShapeModel::computeNormals, ConsistentNormalsMethod 2: normal = inverted z axis of the SHOT frame (radius NormalRadius)
-    at every point, NaN where the frame is invalid. The cloud is created with zero normals; after the call its own (cell-sorted)
-    normals must be the estimated ones too: SHOT-352 computed on that cloud has to match the oracle fed with the oracle's normals."""
+    """ImplicitShapeModel::computeNormals, ConsistentNormalsMethod 2 (implicit_shape_model.cpp:1014-1018 -> utils/normal_orientation.cpp:
+    48-110): PCA normals flipped to the origin first; normal = inverted z axis of the SHOT frame (radius NormalRadius) where the frame
+    is valid; a point with an invalid frame (< 5 neighbours) keeps its PCA normal (NaN below 3 neighbours); and the reference's
+    mis-indexed patch loop: with k invalid frames in an object, its points 0..k-1 carry the UNFLIPPED PCA normal instead.
+    The cloud is created with zero normals; after the call its own (cell-sorted) normals must be the estimated ones too: SHOT-352
+    computed on that cloud has to match the oracle fed with the same normals."""
     ctx, dev = gpu
     syn = pkg.synthetic
     ds = syn.Dataset(3, 3, split=0, n_points=3000, n_keypoints=64)
     nb = ds.batch(range(3))
     xyz = nb["xyz"].copy()
-    xyz[5] += 50.0                                                        # an isolated point: invalid frame -> NaN normal
     po = nb["pt_off"]
+    xyz[5] += 50.0                                                        # object 0: an isolated point: no frame, no PCA normal
+    tri = np.float32([[0, 0, 0], [0.05, 0.01, 0], [0.01, 0.04, 0.02]])
+    for j, at in enumerate((100, 200)):                                   # object 1: two far-off triplets: PCA normal, no frame
+        xyz[po[1] + at:po[1] + at + 3] = xyz[po[1]:po[1] + 3].mean(0) + np.float32([1.5 + j, 1.0, -0.5]) + tri
     x, y, z = (T(xyz[:, i].copy(), dev) for i in range(3))
     zeros = [T(np.zeros(len(xyz), np.float32), dev) for _ in range(3)]
     r_n = 0.12
@@ -512,14 +518,30 @@ def test_estimate_normals_from_shot_frames(pkg, gpu, ora):
     nx, ny, nz = pkg.capi.estimate_normals(ctx, cloud, r_n, *zeros)
     got = np.stack([nx.cpu().numpy(), ny.cpu().numpy(), nz.cpu().numpy()], 1)
     frames = ora.shot_lrf(po, xyz[:, 0], xyz[:, 1], xyz[:, 2], po, xyz[:, 0], xyz[:, 1], xyz[:, 2], r_n)
-    want = -frames[:, 6:9]
+    pca = ora.pca_normals(po, xyz[:, 0], xyz[:, 1], xyz[:, 2], r_n, 0)
+    raw = ora.pca_normals(po, xyz[:, 0], xyz[:, 1], xyz[:, 2], r_n, 2)
     bad = ~np.isfinite(frames[:, 0])
-    want[bad] = np.nan
+    want = np.where(bad[:, None], pca, -frames[:, 6:9])
+    from_frame = ~bad
+    k_inv = [int(bad[po[o]:po[o + 1]].sum()) for o in range(3)]
+    assert k_inv[0] >= 1 and k_inv[1] >= 6, k_inv                        # the synthetic clouds have sparse spots of their own
+    for o in range(3):
+        want[po[o]:po[o] + k_inv[o]] = raw[po[o]:po[o] + k_inv[o]]
+        from_frame[po[o]:po[o] + k_inv[o]] = False
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got[5]).all()
-    ok = ~np.isnan(want[:, 0])
-    # an eigenvector of a near-degenerate covariance may flip or rotate in the last bits; all but a handful agree to 1e-5
-    err = np.abs(got[ok] - want[ok]).max(1)
+    # an eigenvector of a near-degenerate covariance may flip or rotate in the last bits; all but a handful agree to 1e-4
+    err = np.abs(got[from_frame] - want[from_frame]).max(1)
     assert (err < 1e-4).mean() > 0.999, (err > 1e-4).sum()
+    # PCA-derived entries (kept fallbacks, and the first k of each object): PCL's float covariance limits the agreement
+    pc = ~from_frame & ~np.isnan(want).any(1)
+    assert pc.sum() >= 13
+    dots = (got[pc] * want[pc]).sum(1)
+    print("method 2: PCA-derived normals", int(pc.sum()), "of", len(want), "min |dot|", float(np.abs(dots).min()), "sign mismatches", int((dots < 0).sum()))
+    assert (np.abs(dots) > 1 - 1e-4).mean() > 0.95 and (dots > 0).mean() > 0.95, np.sort(dots)[:10]
+    # the triplets' normal is the normal of their plane
+    nrm = np.cross(tri[1] - tri[0], tri[2] - tri[0]); nrm /= np.linalg.norm(nrm)
+    for at in (100, 200):
+        assert (np.abs(got[po[1] + at:po[1] + at + 3] @ nrm) > 1 - 1e-4).all()
     # descriptors on the same cloud use the refreshed normals
     kp, ko = nb["kp"], nb["kp_off"]
     kx, ky, kz = (T(kp[:, i].copy(), dev) for i in range(3))
