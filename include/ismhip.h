@@ -249,7 +249,7 @@ int  ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* slot_offsets
  *      features in the order the reference iterates them); feat_*_h are host arrays ([n], centre [n*3] = the model's bounding-box
  *      centre). Outputs are HOST arrays: word_src_out[n] (training feature of every kept codeword, ascending = codeword order),
  *      vote_offsets_out[n+1] (CSR), vote_feature_out / vote_weight_out / vote_class_weight_out [n*k], vote_xyz_out[n*k*3],
- *      class_sigma_out[n_classes]. The call synchronises. k <= 4. */
+ *      class_sigma_out[n_classes]. The call synchronises. k <= 16. */
 int  ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim, const float* desc, const float* lrf9,
                            const float* kpx, const float* kpy, const float* kpz,
                            const uint32_t* feat_class_h, const uint32_t* feat_model_h, const float* feat_center_h,

@@ -1164,7 +1164,9 @@ __host__ __device__ inline uint32_t knn_fb_parts(uint32_t n_items) {
     const uint32_t p = KNN_FB_UNITS / n_items;
     return p > 256u ? 256u : p;
 }
+#define KNN_MAX_K 16
 #define KNN_FB_MAXJ 84          // dim_pad <= 1344 -> at most 84 elements per lane of a 16-lane row group
+template <int KM>   // KM = capacity of the per-item result lists: 4 (k <= 4, every shipped configuration) or KNN_MAX_K
 __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ words, int dim, int dim_pad, int n_words,
                                                       const float* __restrict__ q, int ldq, int metric, int k, int tiles_per_split, int n_tiles,
                                                       int tile_rows, int wr_rows /* rows per wave-row block = MI*32 (L2) */,
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
     // With few items a wave per item would leave the chip idle behind a handful of long scans: every item is cut into P row
     // ranges (P * n_items <= KNN_FB_UNITS), each range leaves its own k best in part_out and the merge kernel folds them.
     const uint32_t P = knn_fb_parts(n_items);
-    unsigned long long* outp = P > 1 ? item_out + 4 * part_base : item_out;
+    unsigned long long* outp = P > 1 ? item_out + KM * part_base : item_out;
     for (uint32_t u = gw; u < n_items * P; u += nw) {
         const uint32_t it = u / P, part_i = u % P;
         const int qi = (int)items[2 * (size_t)it], b = (int)items[2 * (size_t)it + 1];
@@ -1193,7 +1195,9 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
         const int wr = lay16 ? (b >> 2) & 1 : (b >> 1) & 1, h = b & 1, fq = b & 3;
         const int mt0 = split * tiles_per_split, mt1 = min(n_tiles, mt0 + tiles_per_split);
         const int total = (mt1 - mt0) * rows_per_tile;
-        unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        unsigned long long best[KM];
+#pragma unroll
+        for (int j = 0; j < KM; ++j) best[j] = ~0ull;
         float thr = __builtin_inff();
         {
             const int id = idx_in[(size_t)qi * k + (k - 1)];
@@ -1226,35 +1230,44 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
                 unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)rr;
                 if (d != d) key = (0x7fc00000ull << 32) | (unsigned)rr;             // NaN sorts after every finite distance and keeps ITS row
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (j < k && key < best[j]) { const unsigned long long tmp = best[j]; best[j] = key; key = tmp; }
-                if (best[k - 1] != ~0ull) thr = fminf(thr, __uint_as_float((unsigned)(best[k - 1] >> 32)));
+                for (int j = 0; j < KM; ++j) if (j < k && key < best[j]) { const unsigned long long tmp = best[j]; best[j] = key; key = tmp; }
+                unsigned long long kth = ~0ull;
+#pragma unroll
+                for (int j = 0; j < KM; ++j) if (j == k - 1) kth = best[j];
+                if (kth != ~0ull) thr = fminf(thr, __uint_as_float((unsigned)(kth >> 32)));
             }
         }
-        if (lane < 4) outp[4 * (size_t)u + lane] = lane == 0 ? best[0] : (lane == 1 ? best[1] : (lane == 2 ? best[2] : best[3]));
+#pragma unroll
+        for (int j = 0; j < KM; ++j) if (lane == j) outp[KM * (size_t)u + j] = best[j];
     }
 }
 
 // one wave per unproven query: the lanes fold the per-unit results (and the re-ranked candidates) into private sorted lists, k
 // rounds of a wave-wide minimum then pick the result; a row reached through two paths is taken once
+template <int KM>
 __global__ __launch_bounds__(256) void k_knn_fallback_merge(int k, const uint32_t* __restrict__ flag_count, const uint32_t* __restrict__ qrec,
                                      const unsigned long long* __restrict__ item_out, size_t part_base, int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
     const uint32_t n_q = flag_count[0];
     const uint32_t P = knn_fb_parts(flag_count[1]);
-    const unsigned long long* outp = P > 1 ? item_out + 4 * part_base : item_out;
+    const unsigned long long* outp = P > 1 ? item_out + KM * part_base : item_out;
     const int lane = threadIdx.x & 63;
     for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < n_q; t += gridDim.x * 4) {
         const int qi = (int)qrec[3 * (size_t)t]; const uint32_t ibase = qrec[3 * (size_t)t + 1], ni = qrec[3 * (size_t)t + 2];
-        unsigned long long fin[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        unsigned long long fin[KM];
+#pragma unroll
+        for (int j = 0; j < KM; ++j) fin[j] = ~0ull;
         auto ins = [&](unsigned long long key) {
-            for (int j = 0; j < 4; ++j) if (fin[j] != ~0ull && (fin[j] & 0xffffffffull) == (key & 0xffffffffull)) return;   // same row twice
-            for (int j = 0; j < 4; ++j) if (key < fin[j]) { const unsigned long long tmp = fin[j]; fin[j] = key; key = tmp; }
+#pragma unroll
+            for (int j = 0; j < KM; ++j) if (fin[j] != ~0ull && (fin[j] & 0xffffffffull) == (key & 0xffffffffull)) return;   // same row twice
+#pragma unroll
+            for (int j = 0; j < KM; ++j) if (key < fin[j]) { const unsigned long long tmp = fin[j]; fin[j] = key; key = tmp; }
         };
         if (lane < k) {
             const int id = idx_out[(size_t)qi * k + lane];
             if (id >= 0) ins(((unsigned long long)__float_as_uint(dist_out[(size_t)qi * k + lane]) << 32) | (unsigned)id);
         }
         for (uint32_t i = lane; i < ni * P; i += 64)
-            for (int j = 0; j < k; ++j) { const unsigned long long key = outp[4 * ((size_t)ibase * P + i) + j]; if (key != ~0ull) ins(key); }
+            for (int j = 0; j < k; ++j) { const unsigned long long key = outp[KM * ((size_t)ibase * P + i) + j]; if (key != ~0ull) ins(key); }
         for (int j = 0; j < k; ++j) {
             unsigned long long mn = fin[0];
 #pragma unroll
@@ -1265,9 +1278,13 @@ __global__ __launch_bounds__(256) void k_knn_fallback_merge(int k, const uint32_
             }
             if (mn == ~0ull) continue;
             // drop the chosen row from every private list (it can sit in several lanes, with the same key)
-            unsigned long long kept[4] = {~0ull, ~0ull, ~0ull, ~0ull}; int c = 0;
-            for (int x = 0; x < 4; ++x) if (fin[x] != ~0ull && (fin[x] & 0xffffffffull) != (mn & 0xffffffffull)) kept[c++] = fin[x];
-            for (int x = 0; x < 4; ++x) fin[x] = kept[x];
+            // (a private list is sorted and holds a row at most once: shift the tail down over the hit)
+            bool gone = false;
+#pragma unroll
+            for (int x = 0; x < KM; ++x) {
+                if (!gone && fin[x] != ~0ull && (fin[x] & 0xffffffffull) == (mn & 0xffffffffull)) gone = true;
+                if (gone) fin[x] = x + 1 < KM ? fin[x + 1] : ~0ull;
+            }
         }
     }
 }
@@ -1360,6 +1377,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         const int n_qt = (nq + CHI_B - 1) / CHI_B, n_mt = cb->n_words_pad / CHI_B;
         const int max_s = 64 / T;
         n_splits = std::max(1, std::min(std::min(max_s, n_mt), (2048 + n_qt - 1) / n_qt));
+        if (k > T) n_splits = std::max(n_splits, std::min(std::min(max_s, n_mt), (2 * k + T - 1) / T));    // at least 2k candidates to re-rank
         tiles_per_split = (n_mt + n_splits - 1) / n_splits;
         n_splits = (n_mt + tiles_per_split - 1) / tiles_per_split;
         cand_per_split = T;
@@ -1370,7 +1388,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     int* cand_idx = (int*)ism_scratch(ctx, SCR_KNN_CAND_IDX, (size_t)nq * (n_cand + (merged ? KNN_MERGE_KEEP : 0)) * sizeof(int));
     // queue of unproven work: 16 counters | query records [nq*3] | items [nq*n_bound*2] | item results [nq*n_bound*4] u64
     const size_t q_items = (size_t)nq * n_bound;
-    uint32_t* flags = (uint32_t*)ism_scratch(ctx, SCR_KNN_FLAGS, (16 + 3 * (size_t)nq + 2 * q_items) * sizeof(uint32_t) + 8 + (q_items + KNN_FB_UNITS) * 4 * sizeof(unsigned long long));
+    uint32_t* flags = (uint32_t*)ism_scratch(ctx, SCR_KNN_FLAGS, (16 + 3 * (size_t)nq + 2 * q_items) * sizeof(uint32_t) + 8 + (q_items + KNN_FB_UNITS) * (k > 4 ? KNN_MAX_K : 4) * sizeof(unsigned long long));
     if (!cand_val || !cand_idx || !flags) return ISMHIP_ERR_NOMEM;
     float* cand_bound = cand_val + (size_t)nq * n_cand;
     uint32_t* flag_count = flags; uint32_t* qrec = flags + 16; uint32_t* items = qrec + 3 * (size_t)nq;
@@ -1491,11 +1509,14 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     if (stage1) { stage1->flag_count = flag_count; stage1->qrec = qrec; return ISMHIP_OK; }
     {
         TimerScope ts(ctx, "knn_fallback");
-        hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad,
-                           cb->n_words, qq, ldq, metric, k, merged ? cb->n_words_pad / BM : tiles_per_split, cb->n_words_pad / BM, BM, merged ? -2 : (ring16 ? -1 : wr_rows),
-                           flag_count, items, idx_out, dist_out, item_out, q_items);
+        const int fb_tps = merged ? cb->n_words_pad / BM : tiles_per_split, fb_lay = merged ? -2 : (ring16 ? -1 : wr_rows);
+        if (k <= 4) hipLaunchKernelGGL(k_knn_fallback<4>, dim3(1024), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words, qq, ldq, metric, k,
+                                       fb_tps, cb->n_words_pad / BM, BM, fb_lay, flag_count, items, idx_out, dist_out, item_out, q_items);
+        else hipLaunchKernelGGL(k_knn_fallback<KNN_MAX_K>, dim3(1024), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words, qq, ldq, metric, k,
+                                fb_tps, cb->n_words_pad / BM, BM, fb_lay, flag_count, items, idx_out, dist_out, item_out, q_items);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback");
-        hipLaunchKernelGGL(k_knn_fallback_merge, dim3(256), dim3(256), 0, ctx->stream, k, flag_count, qrec, item_out, q_items, idx_out, dist_out);
+        if (k <= 4) hipLaunchKernelGGL(k_knn_fallback_merge<4>, dim3(256), dim3(256), 0, ctx->stream, k, flag_count, qrec, item_out, q_items, idx_out, dist_out);
+        else hipLaunchKernelGGL(k_knn_fallback_merge<KNN_MAX_K>, dim3(256), dim3(256), 0, ctx->stream, k, flag_count, qrec, item_out, q_items, idx_out, dist_out);
         ISM_CHECK_LAUNCH(ctx, "k_knn_fallback_merge");
     }
     if (ctx->timers_on) ISM_HIP(ctx, hipMemcpyAsync(ctx->knn_stats, flag_count, 8, hipMemcpyDeviceToHost, ctx->stream));   // read back after a sync
@@ -1585,7 +1606,10 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
                int32_t* idx_out, float* dist_out) {
     if (!ctx || !cb || !q || !idx_out || !dist_out || nq < 0 || k <= 0 || (metric != ISMHIP_METRIC_L2SQ && metric != ISMHIP_METRIC_CHI2))
         return ism_set_err(ctx, ISMHIP_ERR_INVALID, "knn: bad argument");
-    if (k > 4) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: k > 4 not built");
+    // k <= 4 is what the candidate slots (T <= 4 per slot) are sized for. Up to KNN_MAX_K the same kernels serve: the re-rank takes
+    // the k best of the <= 64 candidates, the proof asks every slot's dropped-score bound to clear the k-th exact distance -- which
+    // fails whenever one slot held more than T of the true k best -- and the exact scan of those slots finishes the query.
+    if (k > KNN_MAX_K) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: k > 16 not built");
     if (nq == 0) return ISMHIP_OK;
     TimerScope ts(ctx, "knn");
     // T = candidates kept per slot. The bf16x3 candidate scores carry a larger error bound, so more are kept (T = 4): the proof

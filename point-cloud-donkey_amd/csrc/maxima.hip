@@ -26,7 +26,44 @@ struct MaxArgs {
     float min_threshold; int best_k, max_maxima, cap; int max_filter; float filter_radius;
     int32_t* n_max; float* mpos; float* mw; int32_t* mcls; int32_t* minst; float* miw; float* mbs; int32_t* mnv; float* class_score;
     float* rec; int32_t* rec_count;      // per (object, class): up to MX_MAXM_C records of MX_REC floats
+    unsigned char* work; const uint32_t* work_off; const uint32_t* class_count;   // big objects: per-(object, class) vote arrays in HBM
 };
+#define MX_LDS_SLOTS 2048  // vote slots per object that fit the LDS-resident kernels
+#define MX_WORK_STRIDE 72  // bytes of workspace per vote slot (65 used by k_find_maxima, 37 by k_hough3d)
+__device__ __forceinline__ int pow2_cap(uint32_t n) { int c = 64; while ((uint32_t)c < n) c <<= 1; return c; }
+
+// Objects with more than MX_LDS_SLOTS vote slots: the votes of one class no longer fit LDS with their work arrays, so every
+// (object, class) workgroup gets a private region of a global workspace instead, sized from its class's vote count:
+// k_class_counts tallies the counts, k_work_offsets lays the regions out (offsets in slots, power-of-two sizes, prefix sum).
+__global__ __launch_bounds__(256) void k_class_counts(int n_classes, const uint32_t* __restrict__ slot_off, const int32_t* __restrict__ vcls, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_c[MX_MAXC];
+    const int o = blockIdx.x;
+    for (int c = threadIdx.x; c < n_classes; c += 256) s_c[c] = 0;
+    __syncthreads();
+    for (uint32_t s = slot_off[o] + threadIdx.x; s < slot_off[o + 1]; s += 256) { const int c = vcls[s]; if (c >= 0 && c < n_classes) atomicAdd(&s_c[c], 1u); }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n_classes; c += 256) counts[(size_t)o * n_classes + c] = s_c[c];
+}
+__global__ __launch_bounds__(1024) void k_work_offsets(uint32_t n_oc, const uint32_t* __restrict__ counts, uint32_t* __restrict__ work_off) {
+    __shared__ uint32_t s_w[16], s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n_oc; c0 += 1024) {
+        const uint32_t i = c0 + threadIdx.x;
+        const uint32_t v = i < n_oc && counts[i] ? (uint32_t)pow2_cap(counts[i]) : 0u;
+        uint32_t inc = v;                                         // inclusive wave scan
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane_id() >= d) inc += t; }
+        if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t off = s_base;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += s_w[w];
+        if (i < n_oc) work_off[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_base = off + inc;
+        __syncthreads();
+    }
+}
 
 __device__ __forceinline__ float ms_kernel(int kernel, float u) {          // voting_mean_shift.cpp:378-417
     // the reference evaluates exp(-0.5 * x) in double and rounds to float; expf differs by <= 2 ulp (2e-7 relative), far inside
@@ -60,10 +97,14 @@ __device__ __forceinline__ int block_sum_i(int v, int* s_red) {
     return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
+template <bool GM>      // GM: the vote arrays live in the global workspace (objects with more than MX_LDS_SLOTS slots)
 __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int cap = a.cap;                                   // power of two >= max votes of one object
-    float* vx = (float*)smem;               float* vy = vx + cap; float* vz = vy + cap; float* vw = vz + cap;
+    // power of two >= max votes of one object (LDS) / >= the votes of this (object, class) (workspace)
+    const int cap = GM ? pow2_cap(a.class_count[(size_t)blockIdx.x * a.n_classes + blockIdx.y]) : a.cap;
+    unsigned char* arrays = smem;
+    if constexpr (GM) arrays = a.work + (size_t)a.work_off[(size_t)blockIdx.x * a.n_classes + blockIdx.y] * MX_WORK_STRIDE;
+    float* vx = (float*)arrays;             float* vy = vx + cap; float* vz = vy + cap; float* vw = vz + cap;
     int* vinst = (int*)(vw + cap);          int* vslot = vinst + cap;
     unsigned long long* keys = (unsigned long long*)(vslot + cap);
     float4* ctr = (float4*)(keys + cap);    float4* ctr2 = ctr + cap;
@@ -416,6 +457,7 @@ struct HoughArgs {
     const uint32_t* slot_off; const float* vpos; const float* vw; const int32_t* vcls; const int32_t* vinst; const float* vbs;
     int n_classes; const float* class_bin; float bin; float minc[3], maxc[3]; int use_int; float rel; int min_votes, cap, tile_edge;
     float* rec; int32_t* rec_count; int32_t* overflow;
+    unsigned char* work; const uint32_t* work_off; const uint32_t* class_count;
 };
 struct HgBin { int c[3]; int dir[3]; float wc[3]; bool in; };
 __device__ __forceinline__ HgBin hg_bin(const HoughArgs& a, double bin, const int cnt[3], float px, float py, float pz) {
@@ -435,15 +477,18 @@ __device__ __forceinline__ HgBin hg_bin(const HoughArgs& a, double bin, const in
     return b;
 }
 
+template <bool GM>
 __global__ __launch_bounds__(256) void k_hough3d(HoughArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int cap = a.cap;
-    float* vx = (float*)smem;               float* vy = vx + cap; float* vz = vy + cap; float* vw = vz + cap;
+    const int cap = GM ? pow2_cap(a.class_count[(size_t)blockIdx.x * a.n_classes + blockIdx.y]) : a.cap;
+    unsigned char* arrays = smem;
+    if constexpr (GM) arrays = a.work + (size_t)a.work_off[(size_t)blockIdx.x * a.n_classes + blockIdx.y] * MX_WORK_STRIDE;
+    float* vx = (float*)arrays;             float* vy = vx + cap; float* vz = vy + cap; float* vw = vz + cap;
     int* vinst = (int*)(vw + cap);          int* vslot = vinst + cap;
     unsigned long long* hval = (unsigned long long*)(vslot + cap);      // instance tally (values)
     int* hkey = (int*)(hval + cap);                                       // instance tally (keys)
     unsigned char* member = (unsigned char*)(hkey + cap);
-    unsigned long long* tile = (unsigned long long*)(member + cap);     // tile_edge^3 bins
+    unsigned long long* tile = GM ? (unsigned long long*)smem : (unsigned long long*)(member + cap);     // tile_edge^3 bins, always in LDS
     __shared__ int s_n, s_nmax, s_lo[3], s_hi[3], s_nm;
     __shared__ int s_wcnt[4];
     __shared__ float s_redf[4];
@@ -657,6 +702,25 @@ __global__ __launch_bounds__(256) void k_hough3d(HoughArgs a) {
 
 uint32_t* ism_upload_offsets(ismhip_ctx* ctx, int slot, const uint32_t* off_h, int n);
 
+// workspace of the big-object kernels: counts[n_oc] | offsets[n_oc] | regions (<= 2 * slots + nothing for absent classes)
+static int big_object_workspace(ismhip_ctx* ctx, int n_obj, int n_classes, const uint32_t* slot_offsets_h, const uint32_t* slot_off_d, const int32_t* vote_class,
+                                unsigned char** work, const uint32_t** work_off, const uint32_t** class_count) {
+    const size_t n_oc = (size_t)n_obj * n_classes;
+    const size_t total = slot_offsets_h[n_obj];
+    const size_t region_slots = 2 * total + 64 * std::min(n_oc, total);          // pow2_cap(n) <= max(64, 2 n - 1), absent classes take nothing
+    if (region_slots >= (1ull << 32)) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "find_maxima: more than 2^31 vote slots in one call not built");
+    const size_t head = (2 * n_oc * sizeof(uint32_t) + 255) / 256 * 256;
+    unsigned char* w = (unsigned char*)ism_scratch(ctx, SCR_MAX_WORK, head + region_slots * MX_WORK_STRIDE);
+    if (!w) return ISMHIP_ERR_NOMEM;
+    uint32_t* counts = (uint32_t*)w; uint32_t* offs = counts + n_oc;
+    hipLaunchKernelGGL(k_class_counts, dim3(n_obj), dim3(256), 0, ctx->stream, n_classes, slot_off_d, vote_class, counts);
+    ISM_CHECK_LAUNCH(ctx, "k_class_counts");
+    hipLaunchKernelGGL(k_work_offsets, dim3(1), dim3(1024), 0, ctx->stream, (uint32_t)n_oc, counts, offs);
+    ISM_CHECK_LAUNCH(ctx, "k_work_offsets");
+    *work = w + head; *work_off = offs; *class_count = counts;
+    return ISMHIP_OK;
+}
+
 extern "C" int ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* slot_offsets_h,
                                   const float* vote_pos, const float* vote_weight, const int32_t* vote_class,
                                   const int32_t* vote_instance, const float* vote_bbox_size,
@@ -676,8 +740,8 @@ extern "C" int ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* sl
         max_slots = std::max(max_slots, slot_offsets_h[o + 1] - slot_offsets_h[o]);
     }
     int cap = 64; while ((uint32_t)cap < max_slots) cap <<= 1;
-    if (cap > 2048) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "find_maxima: more than 2048 vote slots per object not built");
-    const size_t dyn = (size_t)cap * (4 * 4 + 2 * 4 + 8 + 16 + 16 + 1);
+    const bool big = cap > MX_LDS_SLOTS;
+    const size_t dyn = big ? 0 : (size_t)cap * (4 * 4 + 2 * 4 + 8 + 16 + 16 + 1);
     uint32_t* so = ism_upload_offsets(ctx, SCR_SLOT_OFF, slot_offsets_h, n_obj + 1);
     if (!so) return ISMHIP_ERR_HIP;
     float* bw = nullptr;
@@ -695,16 +759,19 @@ extern "C" int ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* sl
     a.max_filter = P->max_filter; a.filter_radius = P->bandwidth;      // MaximaHandler::m_radius = the configured bandwidth (voting_mean_shift.cpp:46)
     a.n_max = n_maxima_out; a.mpos = max_pos_out; a.mw = max_weight_out; a.mcls = max_class_out; a.minst = max_instance_out;
     a.miw = max_instance_weight_out; a.mbs = max_bbox_size_out; a.mnv = max_n_votes_out; a.class_score = class_score_out;
-    if (!ctx->attr_done.count((const void*)k_find_maxima)) {      // the attribute is per device: remembered per ctx, not per process
-        ISM_HIP(ctx, hipFuncSetAttribute((const void*)k_find_maxima, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-        ctx->attr_done.insert((const void*)k_find_maxima);
+    if (!ctx->attr_done.count((const void*)k_find_maxima<false>)) {      // the attribute is per device: remembered per ctx, not per process
+        ISM_HIP(ctx, hipFuncSetAttribute((const void*)k_find_maxima<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        ctx->attr_done.insert((const void*)k_find_maxima<false>);
     }
+    a.work = nullptr; a.work_off = nullptr; a.class_count = nullptr;
+    if (big) { int rc = big_object_workspace(ctx, n_obj, P->n_classes, slot_offsets_h, so, vote_class, &a.work, &a.work_off, &a.class_count); if (rc != ISMHIP_OK) return rc; }
     const size_t n_oc = (size_t)n_obj * P->n_classes;
     a.rec = (float*)ism_scratch(ctx, SCR_MAX_REC, n_oc * MX_MAXM_C * MX_REC * sizeof(float) + n_oc * sizeof(int32_t));
     if (!a.rec) return ISMHIP_ERR_NOMEM;
     a.rec_count = (int32_t*)(a.rec + n_oc * MX_MAXM_C * MX_REC);
     TimerScope ts(ctx, "maxima");
-    hipLaunchKernelGGL(k_find_maxima, dim3(n_obj, P->n_classes), dim3(256), dyn, ctx->stream, a);
+    if (big) hipLaunchKernelGGL(k_find_maxima<true>, dim3(n_obj, P->n_classes), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_find_maxima<false>, dim3(n_obj, P->n_classes), dim3(256), dyn, ctx->stream, a);
     ISM_CHECK_LAUNCH(ctx, "k_find_maxima");
     hipLaunchKernelGGL(k_finalize_maxima, dim3(n_obj), dim3(64), 0, ctx->stream, a);
     ISM_CHECK_LAUNCH(ctx, "k_finalize_maxima");
@@ -732,9 +799,9 @@ extern "C" int ismhip_hough3d_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t*
         max_slots = std::max(max_slots, slot_offsets_h[o + 1] - slot_offsets_h[o]);
     }
     int cap = 64; while ((uint32_t)cap < max_slots) cap <<= 1;
-    if (cap > 2048) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "hough3d_maxima: more than 2048 vote slots per object not built");
+    const bool big = cap > MX_LDS_SLOTS;
     // LDS: 37 B per vote slot; the rest of ~150 KB holds the accumulator tile (edge 16 .. 24 bins including the halo)
-    const size_t vote_bytes = (size_t)cap * (4 * 4 + 2 * 4 + 8 + 4 + 1);
+    const size_t vote_bytes = big ? 0 : (size_t)cap * (4 * 4 + 2 * 4 + 8 + 4 + 1);
     int edge = 24;
     while (edge > 8 && ((vote_bytes + 15) / 16 * 16 + (size_t)edge * edge * edge * 8) > 150 * 1024) --edge;
     const size_t dyn = (vote_bytes + 15) / 16 * 16 + (size_t)edge * edge * edge * 8 + 16;
@@ -763,13 +830,17 @@ extern "C" int ismhip_hough3d_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t*
     a.n_max = n_maxima_out; a.mpos = max_pos_out; a.mw = max_weight_out; a.mcls = max_class_out; a.minst = max_instance_out;
     a.miw = max_instance_weight_out; a.mbs = max_bbox_size_out; a.mnv = max_n_votes_out; a.class_score = class_score_out;
     a.rec = h.rec; a.rec_count = h.rec_count;
-    if (!ctx->attr_done.count((const void*)k_hough3d)) {
-        ISM_HIP(ctx, hipFuncSetAttribute((const void*)k_hough3d, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        ctx->attr_done.insert((const void*)k_hough3d);
+    const void* hk = big ? (const void*)k_hough3d<true> : (const void*)k_hough3d<false>;
+    if (!ctx->attr_done.count(hk)) {
+        ISM_HIP(ctx, hipFuncSetAttribute(hk, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        ctx->attr_done.insert(hk);
     }
+    h.work = nullptr; h.work_off = nullptr; h.class_count = nullptr;
+    if (big) { int rc = big_object_workspace(ctx, n_obj, P->n_classes, slot_offsets_h, so, vote_class, &h.work, &h.work_off, &h.class_count); if (rc != ISMHIP_OK) return rc; }
     TimerScope ts(ctx, "hough3d");
     ISM_HIP(ctx, hipMemsetAsync(h.overflow, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_hough3d, dim3(n_obj, P->n_classes), dim3(256), dyn, ctx->stream, h);
+    if (big) hipLaunchKernelGGL(k_hough3d<true>, dim3(n_obj, P->n_classes), dim3(256), dyn, ctx->stream, h);
+    else hipLaunchKernelGGL(k_hough3d<false>, dim3(n_obj, P->n_classes), dim3(256), dyn, ctx->stream, h);
     ISM_CHECK_LAUNCH(ctx, "k_hough3d");
     hipLaunchKernelGGL(k_finalize_maxima, dim3(n_obj), dim3(64), 0, ctx->stream, a);
     ISM_CHECK_LAUNCH(ctx, "k_finalize_maxima");

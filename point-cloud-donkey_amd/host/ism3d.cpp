@@ -394,7 +394,7 @@ void Codebook::upload(DeviceSession& s) const {
 
 int ActivationStrategyKNN::activateKNN(DeviceSession& s, const ismhip_codebook* codewords, const DeviceFeatures& f, int metric,
                                        int32_t* idx_out, float* dist_out, const float* desc) const {     // activation_strategy_knn.h:41-126
-    if (m_k > 4) throw RuntimeException("KNN activation with K > 4 is not built");
+    if (m_k > 16) throw RuntimeException("KNN activation with K > 16 is not built");
     if (f.n == 0) return m_k;
     if (!desc) desc = f.desc.as<float>();                        // desc: the (possibly partial, codebook.cpp:416-475) descriptors to match
     if (m_use_distance_ratio && m_is_detection && m_k == 1)
@@ -459,7 +459,7 @@ void Codebook::activate(DeviceSession& s, const DeviceFeatures& f, const std::ve
     const ActivationStrategy* knn = m_activationStrategy.get();
     const bool is_knn = m_activationStrategy->getType() == "KNN";
     const int k = is_knn ? knn->getK() : 1;                      // KNNRule trains with plain 1-NN (activation_strategy_knn_rule.h:70-74)
-    if (k > 4) throw RuntimeException("KNN activation with K > 4 is not built");
+    if (k > 16) throw RuntimeException("KNN activation with K > 16 is not built");
     // the whole of Codebook::activate runs on the device (ismhip_train_activate): self-kNN, class sigma^2, K = 1 clean-up,
     // vote CSR, computeWeights and the statistical class weights. Features must be class-major, as train() collects them.
     std::vector<float> words, centers((size_t)n * 3), lrf, kx, ky, kz;
@@ -513,7 +513,7 @@ void Codebook::castVotes(DeviceSession& s, const DeviceFeatures& f, int metric, 
     upload(s);
     m_activationStrategy->setIsDetection();
     const ActivationStrategy* knn = m_activationStrategy.get();
-    if (knn->getK() > 4) throw RuntimeException("KNN activation with K > 4 is not built");
+    if (knn->getK() > 16) throw RuntimeException("KNN activation with K > 16 is not built");
     const uint32_t n = f.n;
     if (n == 0) return;
     s.idx.reserve((size_t)n * 4 * 4); s.dist.reserve((size_t)n * 4 * 4);

@@ -272,6 +272,36 @@ def test_knn_matches_oracle_on_clustered_unit_vectors(pkg, gpu, ora):
         assert np.array_equal(dist.cpu().numpy(), wdist)
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("shape,k", [((6000, 352, 5000), 5), ((6000, 352, 5000), 16), ((300, 33, 200), 9), ((12, 16, 40), 16), ((3000, 96, 600), 8)])
+def test_knn_more_than_four_neighbours(pkg, gpu, ora, metric, shape, k):
+    """KNN activation with K > 4 (activation_strategy_knn.h:57-72 takes any K): the candidate slots keep at most 4 rows each, so a
+    slot that held more of the true K best fails its proof and the exact scan of that slot finishes the query. Bit-exact against the
+    oracle, descriptor-like clustered rows included (several of the K best in one slot); n_words < K pads with -1 / NaN."""
+    ctx, dev = gpu
+    n_words, dim, nq = shape
+    rng = np.random.default_rng(n_words + dim + k + metric)
+    centres = rng.random((max(2, n_words // 40), dim)).astype(np.float32)
+    words = (centres[rng.integers(0, len(centres), n_words)] + 0.05 * rng.random((n_words, dim))).astype(np.float32)
+    words /= np.linalg.norm(words, axis=1, keepdims=True)
+    q = (centres[rng.integers(0, len(centres), nq)] + 0.05 * rng.random((nq, dim))).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    words[7 % n_words] = words[3 % n_words]                               # a tie: the lower row first
+    host, cb = _cb(pkg, gpu, words)
+    ctx.timers_enable(True); ctx.timers_reset()
+    idx, dist = pkg.capi.knn(ctx, cb, metric, T(q, dev), k)
+    ctx.sync()
+    print(f"k={k} metric={metric} {shape}: unproven queries / slots {_knn_flagged(ctx)}")
+    ctx.timers_enable(False)
+    widx, wdist = ora.knn(metric, words, q, k)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    got = dist.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(wdist))
+    assert np.array_equal(got[~np.isnan(got)], wdist[~np.isnan(wdist)])
+    if n_words < k:
+        assert (widx[:, n_words:] == -1).all()
+
+
 def _knn_flagged(ctx):
     return int(ctx.timer("knn_flagged_queries")[0]), int(ctx.timer("knn_flagged_items")[0])
 
@@ -580,15 +610,15 @@ def test_cast_votes_matches_oracle(pkg, gpu, ora, flags):
         np.testing.assert_allclose(got[key].cpu().numpy(), want[key], atol=1e-5, rtol=1e-5, err_msg=key)
 
 
-def _vote_scene(rng, n_obj, n_classes, with_empty=True):
+def _vote_scene(rng, n_obj, n_classes, with_empty=True, big=()):
     pos, w, cls, inst, bs, off = [], [], [], [], [], [0]
     for o in range(n_obj):
         if with_empty and o == 1:
             off.append(off[-1]); continue
-        n_blobs = rng.integers(1, 4)
+        n_blobs = rng.integers(1, 4) + (3 if o in big else 0)
         for b in range(n_blobs):
             c = rng.integers(0, n_classes)
-            m = rng.integers(5, 120)
+            m = rng.integers(5, 120) * (12 if o in big else 1)
             centre = rng.uniform(-2, 2, 3)
             pos.append(centre + 0.15 * rng.normal(size=(m, 3))); w.append(rng.uniform(0.2, 1.0, m))
             cls.append(np.full(m, c)); inst.append(rng.integers(0, 4, m)); bs.append(rng.uniform(0.5, 1.5, (m, 3)))
@@ -654,6 +684,37 @@ def test_find_maxima_matches_oracle(pkg, gpu, ora, suppression, kernel):
     np.testing.assert_allclose(got["bbox_size"].cpu().numpy(), want["bbox_size"], atol=1e-3)
     np.testing.assert_allclose(got["class_score"].cpu().numpy(), want["class_score"], atol=TOL)
     assert want["n"][1] == 0 and want["n"].max() >= 2
+
+
+def test_maxima_of_objects_with_more_slots_than_fit_lds(pkg, gpu, ora):
+    """More than 2048 vote slots in one object (codewords with many votes, K > 1): the per-class vote arrays move from LDS to a
+    workspace in HBM, laid out per (object, class) from a class tally. Same oracle, same tolerances as the LDS-resident kernels;
+    small and empty objects ride in the same call."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(314)
+    off, v = _vote_scene(rng, 6, 4, big=(0, 3))
+    sizes = np.diff(off.astype(np.int64))
+    assert sizes.max() > 2048 and sizes[1] == 0 and sizes[2] < 600, sizes
+    tv = {k2: T(a, dev) for k2, a in v.items()}
+    kw = dict(n_classes=4, bandwidth=0.5, max_maxima=16, min_votes_threshold=2)
+    got = pkg.capi.find_maxima(ctx, off, tv, **kw)
+    want = ora.find_maxima(off, v, **kw)
+    for key in ("n", "cls", "inst", "n_votes"):
+        assert np.array_equal(got[key].cpu().numpy(), want[key]), key
+    np.testing.assert_allclose(got["weight"].cpu().numpy(), want["weight"], atol=TOL)
+    np.testing.assert_allclose(got["inst_weight"].cpu().numpy(), want["inst_weight"], atol=TOL)
+    np.testing.assert_allclose(got["pos"].cpu().numpy(), want["pos"], atol=2e-3)
+    np.testing.assert_allclose(got["class_score"].cpu().numpy(), want["class_score"], atol=TOL)
+    assert want["n"][0] >= 2 and want["n"][3] >= 2
+    kw = dict(n_classes=4, bin_size=0.25, use_interpolation=True, rel_threshold=0.2, max_maxima=16, min_votes_threshold=2)
+    got = pkg.capi.hough3d_maxima(ctx, off, tv, **kw)
+    want = ora.hough3d_maxima(off, v, **kw)
+    for key in ("n", "cls", "inst", "n_votes"):
+        assert np.array_equal(got[key].cpu().numpy(), want[key]), key
+    np.testing.assert_allclose(got["weight"].cpu().numpy(), want["weight"], atol=TOL)
+    np.testing.assert_allclose(got["pos"].cpu().numpy(), want["pos"], atol=1e-4)
+    np.testing.assert_allclose(got["class_score"].cpu().numpy(), want["class_score"], atol=TOL)
+    assert want["n"][0] >= 1
 
 
 def test_find_maxima_two_blobs_property(pkg, gpu):
@@ -957,7 +1018,7 @@ def test_errors_are_loud(pkg, gpu):
     words = np.eye(8, dtype=np.float32)
     _, cb = _cb(pkg, gpu, words)
     with pytest.raises(pkg.capi.IsmHipError):
-        pkg.capi.knn(ctx, cb, 0, T(words, dev), 5)          # k > 4 is not built -> ISMHIP_ERR_UNSUPPORTED, not a silent fallback
+        pkg.capi.knn(ctx, cb, 0, T(words, dev), 17)         # k > 16 is not built -> ISMHIP_ERR_UNSUPPORTED, not a silent fallback
     x = T(np.arange(8, dtype=np.float32), dev)
     with pytest.raises(pkg.capi.IsmHipError, match="bad argument"):
         pkg.capi.voxel_keypoints(ctx, [0, 8], x, x, x, 0.0)                     # leaf must be positive
