@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ISMHIP_ABI_VERSION 2
+#define ISMHIP_ABI_VERSION 3
 
 #define ISMHIP_OK               0
 #define ISMHIP_ERR_INVALID     -1   /* bad argument (null pointer, negative size, unsupported value) */
@@ -241,21 +241,40 @@ int  ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* slot_offsets
                         float* max_bbox_size_out /* may be NULL */, int32_t* max_n_votes_out,
                         float* class_score_out);
 
-/* ---- training: Codebook::activate (codebook/codebook.cpp:64-368) with one codeword per training feature (clustering_none.cpp:25-35):
- *      exact kNN activation of every feature in the codebook of all features, class sigma^2 (:94-193), K = 1 clean-up (:201-224),
- *      vote = rotateInto(centre - keypoint, LRF) (codeword_distribution.cpp:37-71), CodewordDistribution::computeWeights
- *      (:169-243) and the statistical class weights term1 * term2 * term3 (:226-368, including m_term3 being keyed by class only).
+/* ---- training: Codebook::activate (codebook/codebook.cpp:64-368): exact kNN activation of every training feature in the
+ *      codebook, class sigma^2 (:94-193), K = 1 clean-up (:201-224), vote = rotateInto(centre - keypoint, LRF)
+ *      (codeword_distribution.cpp:37-71), CodewordDistribution::computeWeights (:169-243) and the statistical class weights
+ *      term1 * term2 * term3 (:226-368, including m_term3 being keyed by class only).
+ *      The codewords are the rows of `codewords` (device [n_codewords * dim]: the cluster centres of ismhip_kmeans,
+ *      implicit_shape_model.cpp:445-475), or, with codewords == NULL, the training features themselves (clustering_none.cpp:25-35).
  *      desc / lrf9 / kp* are device arrays of the n training features in CLASS-MAJOR order (classes ascending, models and
  *      features in the order the reference iterates them); feat_*_h are host arrays ([n], centre [n*3] = the model's bounding-box
- *      centre). Outputs are HOST arrays: word_src_out[n] (training feature of every kept codeword, ascending = codeword order),
- *      vote_offsets_out[n+1] (CSR), vote_feature_out / vote_weight_out / vote_class_weight_out [n*k], vote_xyz_out[n*k*3],
- *      class_sigma_out[n_classes]. The call synchronises. k <= 16. */
+ *      centre). Outputs are HOST arrays with m = number of codewords: word_src_out[m] (row of `codewords` behind every kept
+ *      codeword, ascending = codeword order), vote_offsets_out[m+1] (CSR), vote_feature_out / vote_weight_out /
+ *      vote_class_weight_out [n*k], vote_xyz_out[n*k*3], class_sigma_out[n_classes]. The call synchronises. k <= 16;
+ *      a codeword with more than 32768 votes is refused (ISMHIP_ERR_UNSUPPORTED). */
 int  ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim, const float* desc, const float* lrf9,
                            const float* kpx, const float* kpy, const float* kpz,
                            const uint32_t* feat_class_h, const uint32_t* feat_model_h, const float* feat_center_h,
+                           int n_codewords, const float* codewords /* device, may be NULL */,
                            int k, int clean_up_single_vote, int n_classes,
                            int32_t* n_words_out, uint32_t* word_src_out, uint32_t* vote_offsets_out, uint32_t* vote_feature_out,
                            float* vote_xyz_out, float* vote_weight_out, float* vote_class_weight_out, float* class_sigma_out);
+
+/* ---- k-means codebook clustering: ClusteringKMeans::cluster (clustering/clustering_kmeans.h:53-131) =
+ *      flann::hierarchicalClustering with branching == the cluster count (one level of Lloyd k-means: centre chooser, then
+ *      [means -> reassign, ties to the lowest centre -> refill empty clusters] until nothing moves or max_iterations), followed by
+ *      the nearest centre of every feature. FLANN is EXTERNAL and draws from rand(): the random draws, the integer form of the
+ *      k-means++ sampling and of the means, and the exact final search are this library's own definitions (csrc/kmeans.hip,
+ *      restated in oracle/; parity with the reference unpinned). desc: device [n * dim]. n_clusters is clipped to n.
+ *      centers_out: device [n_clusters * dim]; assign_out: device [n] (row of centers_out); dist_out: device [n] or NULL (functor
+ *      distance to that centre); *n_clusters_out <= n_clusters (fewer when the distinct points run out). Synchronises. */
+#define ISMHIP_CENTERS_RANDOM   0
+#define ISMHIP_CENTERS_GONZALES 1
+#define ISMHIP_CENTERS_KMEANSPP 2
+int  ismhip_kmeans(ismhip_ctx* ctx, int metric, int n, int dim, const float* desc, int n_clusters, int max_iterations,
+                   int centers_init, unsigned long long seed, float* centers_out, int32_t* assign_out, float* dist_out,
+                   int32_t* n_clusters_out, int32_t* iterations_out /* may be NULL */);
 
 /* ---- discrete Hough space: VotingHough3D::iFindMaxima (voting/voting_hough_3d.cpp:33-95) over pcl::recognition::HoughSpace3D
  *      (bins ceil((max-min)/bin) per axis; trilinear voteInt; findMaxima(-RelThreshold): bins >= rel * max with no strictly

@@ -1439,18 +1439,21 @@ int ismref_class_sigmas(int metric, int dim, int n_feat, const float* feats, con
  * Outputs: kept codewords in ascending id (word_src = its training feature), votes as CSR (vote_feature = activating feature). */
 int ismref_activate(int metric, int dim, int n, const float* feats, const float* lrf9, const float* kx, const float* ky, const float* kz,
                     const uint32_t* feat_class, const uint32_t* feat_model, const float* feat_center,
+                    int n_codewords, const float* codewords,
                     int k, int clean_up, int n_classes,
                     int32_t* n_words_out, uint32_t* word_src, uint32_t* vote_off, uint32_t* vote_feature, float* vote_xyz,
                     float* vote_weight, float* vote_class_weight, float* class_sigma) {
     if (n <= 0 || k <= 0) return -1;
-    // exact kNN of every feature in the codebook of all features
+    if (!codewords) { codewords = feats; n_codewords = n; }     // clustering_none.cpp:25-35; else the cluster centres (implicit_shape_model.cpp:445-475)
+    if (n_codewords < k) k = n_codewords;                       // FLANN returns as many neighbours as the index has rows
+    // exact kNN of every feature in the codebook
     std::vector<int32_t> act(static_cast<size_t>(n) * k, -1);
     std::vector<float> actd(static_cast<size_t>(n) * k, 0.f);
-    ismref_knn(metric, n, dim, feats, n, feats, k, act.data(), actd.data());
+    ismref_knn(metric, n_codewords, dim, codewords, n, feats, k, act.data(), actd.data());
     // iteration order of the reference: classes ascending, models as they come, features as they come
     std::vector<int> order;
     for (int c = 0; c < n_classes; ++c) for (int i = 0; i < n; ++i) if (static_cast<int>(feat_class[i]) == c) order.push_back(i);
-    std::vector<std::vector<int>> dist(n);                    // per codeword: activating features in activation order
+    std::vector<std::vector<int>> dist(n_codewords);          // per codeword: activating features in activation order
     for (int c = 0; c < n_classes; ++c) {
         class_sigma[c] = std::nanf("");
         std::vector<int> ids;
@@ -1473,7 +1476,7 @@ int ismref_activate(int metric, int dim, int n, const float* feats, const float*
         }
         float sum = 0; std::vector<float> ds;
         for (int fi : allFeat) for (int w : allWords) {
-            const float d = dist_any(metric, feats + static_cast<size_t>(fi) * dim, feats + static_cast<size_t>(w) * dim, dim);
+            const float d = dist_any(metric, feats + static_cast<size_t>(fi) * dim, codewords + static_cast<size_t>(w) * dim, dim);
             sum += d; ds.push_back(d);
         }
         const int num = static_cast<int>(allFeat.size() * allWords.size());
@@ -1485,7 +1488,7 @@ int ismref_activate(int metric, int dim, int n, const float* feats, const float*
     }
     // clean-up + CSR in ascending codeword id
     std::vector<int> kept;
-    for (int w = 0; w < n; ++w) { if (dist[w].empty()) continue; if (clean_up && dist[w].size() != 1) continue; kept.push_back(w); }
+    for (int w = 0; w < n_codewords; ++w) { if (dist[w].empty()) continue; if (clean_up && dist[w].size() != 1) continue; kept.push_back(w); }
     *n_words_out = static_cast<int32_t>(kept.size());
     vote_off[0] = 0;
     std::vector<int> vote_word;
@@ -1546,6 +1549,113 @@ int ismref_activate(int metric, int dim, int n, const float* feats, const float*
         for (uint32_t vi = vote_off[e]; vi < vote_off[e + 1]; ++vi) { const int c = static_cast<int>(feat_class[vote_feature[vi]]); vote_class_weight[vi] = term1[c] * term2 * term3[c]; }
     }
     (void)order;
+    return 0;
+}
+
+
+/* ClusteringKMeans::cluster (clustering/clustering_kmeans.h:53-131) = one level of FLANN 1.9.1's k-means (EXTERNAL: kmeans_index.h
+ * computeClustering, center_chooser.h), followed by the nearest centre of every feature. Restated with the SAME build-defined
+ * choices as csrc/kmeans.hip (randomness = splitmix64(seed + draw), integer k-means++ potentials, integer means, float centres,
+ * exact functor distances with ties to the lowest row): written independently from that kernel file, sequential and plain.
+ * centers_out[n_clusters * dim], assign_out[n], dist_out[n] or NULL. Returns 0; *n_clusters_out <= n_clusters. */
+namespace {
+uint64_t km_mix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+uint64_t km_mulhi(uint64_t a, uint64_t b) { return static_cast<uint64_t>((static_cast<unsigned __int128>(a) * b) >> 64); }
+}  // namespace
+int ismref_kmeans(int metric, int n, int dim, const float* feats, int n_clusters, int max_iterations, int centers_init, uint64_t seed,
+                  float* centers_out, int32_t* assign_out, float* dist_out, int32_t* n_clusters_out, int32_t* iterations_out) {
+    if (n <= 0 || dim <= 0 || n_clusters <= 0) return -1;
+    const int k = std::min(n_clusters, n);
+    auto row = [&](int i) { return feats + static_cast<size_t>(i) * dim; };
+    // ---- centre choosers
+    std::vector<int> chosen;
+    std::vector<float> closest(n, 3.3895314e38f);             // bit pattern 0x7f7f7f7f, as the device initialises it
+    auto update = [&](int c) { for (int i = 0; i < n; ++i) { const float d = dist_any(metric, row(i), row(c), dim); if (d < closest[i]) closest[i] = d; } };
+    if (centers_init == 0) {                                  // RANDOM: seeded permutation, skip points that coincide with a centre
+        std::vector<uint32_t> p(n); std::iota(p.begin(), p.end(), 0u);
+        for (int i = n - 1; i > 0; --i) std::swap(p[i], p[km_mix(seed + static_cast<uint64_t>(n - i)) % static_cast<uint64_t>(i + 1)]);
+        chosen.push_back(static_cast<int>(p[0]));
+        size_t cur = 1;
+        while (static_cast<int>(chosen.size()) < k) {
+            update(chosen.back());
+            while (cur < p.size() && closest[p[cur]] < 1e-16f) ++cur;
+            if (cur >= p.size()) break;
+            chosen.push_back(static_cast<int>(p[cur++]));
+        }
+    } else {
+        chosen.push_back(static_cast<int>(km_mix(seed) % static_cast<uint64_t>(n)));
+        float dmax0 = 0.f;
+        for (int step = 1; step < k; ++step) {
+            update(chosen.back());
+            if (step == 1) for (int i = 0; i < n; ++i) if (closest[i] == closest[i] && closest[i] > dmax0) dmax0 = closest[i];
+            if (centers_init == 1) {                          // GONZALES: the farthest point, lowest index on ties, distance > 0
+                int best = -1; float bv = 0.f;
+                for (int i = 0; i < n; ++i) if (closest[i] > bv) { bv = closest[i]; best = i; }
+                if (best < 0) break;
+                chosen.push_back(best);
+            } else {                                          // KMEANSPP, one local try, integer potentials
+                auto pot = [&](float d) -> uint64_t {
+                    if (!(d > 0.f) || !(dmax0 > 0.f)) return 0;
+                    return static_cast<uint64_t>(static_cast<double>(d) / static_cast<double>(dmax0) * static_cast<double>(1ull << 40));
+                };
+                uint64_t total = 0;
+                for (int i = 0; i < n; ++i) total += pot(closest[i]);
+                if (total == 0) break;
+                const uint64_t r = km_mulhi(km_mix(seed + static_cast<uint64_t>(step)), total);
+                uint64_t run = 0; int pick = -1;
+                for (int i = 0; i < n; ++i) { const uint64_t q = pot(closest[i]); if (q && run + q > r) { pick = i; break; } run += q; }
+                if (pick < 0) break;
+                chosen.push_back(pick);
+            }
+        }
+    }
+    const int kc = static_cast<int>(chosen.size());
+    for (int c = 0; c < kc; ++c) std::copy(row(chosen[c]), row(chosen[c]) + dim, centers_out + static_cast<size_t>(c) * dim);
+    // ---- Lloyd
+    float amax = 0.f;
+    for (size_t t = 0; t < static_cast<size_t>(n) * dim; ++t) { const float a = std::fabs(feats[t]); if (a <= std::numeric_limits<float>::infinity() && a > amax) amax = a; }
+    int e = 0;
+    if (amax > 0.f && std::isfinite(amax)) std::frexp(amax, &e);
+    const double scale = std::ldexp(1.0, 40 - e);
+    std::vector<int32_t> belongs(n), nearest(n);
+    std::vector<float> nd(n);
+    ismref_knn(metric, kc, dim, centers_out, n, feats, 1, belongs.data(), nd.data());
+    std::vector<long long> sums(static_cast<size_t>(kc) * dim);
+    std::vector<uint32_t> counts(kc);
+    int it = 0; bool converged = false;
+    while (!converged && it < max_iterations) {
+        ++it; converged = true;
+        std::fill(sums.begin(), sums.end(), 0ll); std::fill(counts.begin(), counts.end(), 0u);
+        for (int i = 0; i < n; ++i) {
+            const int c = belongs[i];
+            if (c < 0) continue;
+            for (int j = 0; j < dim; ++j) { const double v = static_cast<double>(row(i)[j]) * scale; if (v == v) sums[static_cast<size_t>(c) * dim + j] += std::llrint(v); }
+            counts[c]++;
+        }
+        for (int c = 0; c < kc; ++c) if (counts[c]) for (int j = 0; j < dim; ++j)
+            centers_out[static_cast<size_t>(c) * dim + j] = static_cast<float>((static_cast<double>(sums[static_cast<size_t>(c) * dim + j]) / scale) / static_cast<double>(counts[c]));
+        ismref_knn(metric, kc, dim, centers_out, n, feats, 1, nearest.data(), nd.data());
+        for (int i = 0; i < n; ++i) if (nearest[i] >= 0 && nearest[i] != belongs[i]) {
+            if (belongs[i] >= 0) counts[belongs[i]]--;
+            counts[nearest[i]]++; belongs[i] = nearest[i]; converged = false;
+        }
+        if (n > kc) for (int i = 0; i < kc; ++i) if (counts[i] == 0) {
+            int j = (i + 1) % kc;
+            for (int t = 0; t < kc && counts[j] <= 1; ++t) j = (j + 1) % kc;
+            if (counts[j] <= 1) continue;
+            for (int p = 0; p < n; ++p) if (belongs[p] == j) { belongs[p] = i; counts[j]--; counts[i]++; break; }
+            converged = false;
+        }
+    }
+    std::vector<float> dtmp(n);
+    ismref_knn(metric, kc, dim, centers_out, n, feats, 1, assign_out, dist_out ? dist_out : dtmp.data());
+    *n_clusters_out = kc;
+    if (iterations_out) *iterations_out = it;
     return 0;
 }
 

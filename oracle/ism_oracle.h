@@ -148,12 +148,18 @@ int  ismref_class_sigmas(int metric, int dim, int n_feat, const float* feats, co
 
 /* Codebook::activate (codebook/codebook.cpp:64-368) for one codeword per training feature: exact kNN activation, class sigma^2,
  * K = 1 clean-up, vote CSR, CodewordDistribution::computeWeights, statistical class weights (term1 * term2 * term3).
- * Capacities: word_src[n], vote_off[n+1], vote_feature / vote_weight / vote_class_weight [n*k], vote_xyz[n*k*3]. */
+ * Capacities (m = number of codewords): word_src[m], vote_off[m+1], vote_feature / vote_weight / vote_class_weight [n*k], vote_xyz[n*k*3]. */
 int  ismref_activate(int metric, int dim, int n, const float* feats, const float* lrf9, const float* kx, const float* ky, const float* kz,
                      const uint32_t* feat_class, const uint32_t* feat_model, const float* feat_center,
+                     int n_codewords, const float* codewords /* NULL: the features themselves */,
                      int k, int clean_up, int n_classes,
                      int32_t* n_words_out, uint32_t* word_src, uint32_t* vote_off, uint32_t* vote_feature, float* vote_xyz,
                      float* vote_weight, float* vote_class_weight, float* class_sigma);
+
+/* ClusteringKMeans::cluster (clustering/clustering_kmeans.h:53-131): one level of FLANN's k-means + nearest centre per feature;
+ * centers_init 0 RANDOM, 1 GONZALES, 2 KMEANSPP. FLANN is EXTERNAL and random: the draws and integer sums are the build's own (see .cpp). */
+int  ismref_kmeans(int metric, int n, int dim, const float* feats, int n_clusters, int max_iterations, int centers_init, uint64_t seed,
+                   float* centers_out, int32_t* assign_out, float* dist_out, int32_t* n_clusters_out, int32_t* iterations_out);
 
 #ifdef __cplusplus
 }

@@ -290,23 +290,39 @@ def class_sigmas(metric, feats, feat_class, feat_model, activated_word, words, n
     return out
 
 
-def activate(metric, feats, lrf, kp, feat_class, feat_model, feat_center, k=1, clean_up=True, n_classes=None):
-    """Codebook::activate for one codeword per training feature -> dict(word_src, vote_offsets, vote_feature, vote_xyz, vote_weight,
-    vote_class_weight, class_sigma)"""
+def activate(metric, feats, lrf, kp, feat_class, feat_model, feat_center, k=1, clean_up=True, n_classes=None, codewords=None):
+    """Codebook::activate (codewords None: one codeword per training feature) -> dict(word_src, vote_offsets, vote_feature, vote_xyz,
+    vote_weight, vote_class_weight, class_sigma)"""
     feats, lrf, kp, feat_center = _f(feats), _f(lrf), _f(kp), _f(feat_center)
     n, dim = feats.shape
     fc, fm = _u(feat_class), _u(feat_model)
     C_ = int(n_classes if n_classes is not None else fc.max() + 1)
     kx, ky, kz = (np.ascontiguousarray(kp[:, i]) for i in range(3))
+    cw = None if codewords is None else _f(codewords)
+    ncw = n if cw is None else len(cw)
     nw = C.c_int32(0)
-    word_src = np.empty(n, np.uint32); vo = np.empty(n + 1, np.uint32); vf = np.empty(n * k, np.uint32)
+    word_src = np.empty(ncw, np.uint32); vo = np.empty(ncw + 1, np.uint32); vf = np.empty(n * k, np.uint32)
     vxyz = np.empty((n * k, 3), np.float32); vw = np.empty(n * k, np.float32); vcw = np.empty(n * k, np.float32); sig = np.empty(C_, np.float32)
     rc = lib().ismref_activate(C.c_int(metric), C.c_int(dim), C.c_int(n), _p(feats), _p(lrf), _p(kx), _p(ky), _p(kz), _p(fc), _p(fm), _p(feat_center),
+                               C.c_int(ncw), _p(cw) if cw is not None else C.c_void_p(0),
                                C.c_int(k), C.c_int(1 if clean_up else 0), C.c_int(C_), C.byref(nw), _p(word_src), _p(vo), _p(vf), _p(vxyz), _p(vw), _p(vcw), _p(sig))
     assert rc == 0
     m = nw.value; nv = int(vo[m])
     return dict(word_src=word_src[:m].copy(), vote_offsets=vo[:m + 1].copy(), vote_feature=vf[:nv].copy(), vote_xyz=vxyz[:nv].copy(),
                 vote_weight=vw[:nv].copy(), vote_class_weight=vcw[:nv].copy(), class_sigma=sig)
+
+
+def kmeans(metric, feats, n_clusters, max_iterations=1000, centers_init=2, seed=0):
+    """ClusteringKMeans::cluster -> (centers [m, dim], assign [n], dist [n], iterations)"""
+    feats = _f(feats)
+    n, dim = feats.shape
+    kc = min(int(n_clusters), n)
+    centers = np.empty((kc, dim), np.float32); assign = np.empty(n, np.int32); dist = np.empty(n, np.float32)
+    m = C.c_int32(0); it = C.c_int32(0)
+    rc = lib().ismref_kmeans(C.c_int(metric), C.c_int(n), C.c_int(dim), _p(feats), C.c_int(kc), C.c_int(max_iterations), C.c_int(centers_init),
+                             C.c_uint64(seed), _p(centers), _p(assign), _p(dist), C.byref(m), C.byref(it))
+    assert rc == 0
+    return centers[:m.value].copy(), assign, dist, it.value
 
 
 def pca_normals(pt_off, x, y, z, radius, orientation):

@@ -25,7 +25,7 @@ EXPORTS = [
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
     "ismhip_compact_features", "ismhip_voxel_keypoints", "ismhip_gather_columns",
     "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word",
-    "ismhip_knn", "ismhip_knn_ratio", "ismhip_knn_rule", "ismhip_cast_votes", "ismhip_find_maxima", "ismhip_hough3d_maxima", "ismhip_train_activate",
+    "ismhip_knn", "ismhip_knn_ratio", "ismhip_knn_rule", "ismhip_cast_votes", "ismhip_find_maxima", "ismhip_hough3d_maxima", "ismhip_train_activate", "ismhip_kmeans",
 ]
 
 
@@ -402,21 +402,41 @@ def hough3d_maxima(ctx, slot_offsets, votes, n_classes, bin_size, min_coord=(-5,
     return out
 
 
-def train_activate(ctx, metric, desc, lrf, kx, ky, kz, feat_class, feat_model, feat_center, k=1, clean_up=True, n_classes=None):
-    """Codebook::activate on the device (features class-major) -> dict of host arrays (word_src, vote_offsets, vote_feature, vote_xyz, vote_weight, vote_class_weight, class_sigma)"""
+def train_activate(ctx, metric, desc, lrf, kx, ky, kz, feat_class, feat_model, feat_center, k=1, clean_up=True, n_classes=None, codewords=None):
+    """Codebook::activate on the device (features class-major; codewords = device matrix of cluster centres, None = the features
+    themselves) -> dict of host arrays (word_src, vote_offsets, vote_feature, vote_xyz, vote_weight, vote_class_weight, class_sigma)"""
     n, dim = desc.shape
     fc, fm = _u32(feat_class), _u32(feat_model)
     ctr = np.ascontiguousarray(np.asarray(feat_center, dtype=np.float32))
     C_ = int(n_classes if n_classes is not None else fc.max() + 1)
+    ncw = n if codewords is None else int(codewords.shape[0])
     nw = C.c_int32(0)
-    word_src = np.empty(n, np.uint32); vo = np.empty(n + 1, np.uint32); vf = np.empty(n * k, np.uint32)
+    word_src = np.empty(ncw, np.uint32); vo = np.empty(ncw + 1, np.uint32); vf = np.empty(n * k, np.uint32)
     vxyz = np.empty((n * k, 3), np.float32); vw = np.empty(n * k, np.float32); vcw = np.empty(n * k, np.float32); sig = np.empty(C_, np.float32)
     ctx.check(lib().ismhip_train_activate(ctx._h, C.c_int(metric), C.c_int(n), C.c_int(dim), _p(desc), _p(lrf), _p(kx), _p(ky), _p(kz), _p(fc), _p(fm),
-                                          _p(ctr), C.c_int(k), C.c_int(1 if clean_up else 0), C.c_int(C_), C.byref(nw), _p(word_src), _p(vo), _p(vf),
-                                          _p(vxyz), _p(vw), _p(vcw), _p(sig)), "ismhip_train_activate")
+                                          _p(ctr), C.c_int(ncw), _p(codewords), C.c_int(k), C.c_int(1 if clean_up else 0), C.c_int(C_), C.byref(nw), _p(word_src),
+                                          _p(vo), _p(vf), _p(vxyz), _p(vw), _p(vcw), _p(sig)), "ismhip_train_activate")
     m = nw.value; nv = int(vo[m])
     return dict(word_src=word_src[:m].copy(), vote_offsets=vo[:m + 1].copy(), vote_feature=vf[:nv].copy(), vote_xyz=vxyz[:nv].copy(),
                 vote_weight=vw[:nv].copy(), vote_class_weight=vcw[:nv].copy(), class_sigma=sig)
+
+
+CENTERS_INIT = {"FLANN_CENTERS_RANDOM": 0, "FLANN_CENTERS_GONZALES": 1, "FLANN_CENTERS_KMEANSPP": 2}
+
+
+def kmeans(ctx, metric, desc, n_clusters, max_iterations=1000, centers_init="FLANN_CENTERS_KMEANSPP", seed=0):
+    """ClusteringKMeans::cluster on the device -> (centers [m, dim] device, assign [n] device int32, dist [n] device, iterations)"""
+    torch = _torch()
+    n, dim = desc.shape
+    kc = min(int(n_clusters), n)
+    centers = torch.empty((kc, dim), dtype=torch.float32, device=desc.device)
+    assign = torch.empty(n, dtype=torch.int32, device=desc.device)
+    dist = torch.empty(n, dtype=torch.float32, device=desc.device)
+    m = C.c_int32(0); it = C.c_int32(0)
+    ctx.check(lib().ismhip_kmeans(ctx._h, C.c_int(metric), C.c_int(n), C.c_int(dim), _p(desc), C.c_int(kc), C.c_int(max_iterations),
+                                  C.c_int(CENTERS_INIT[centers_init] if isinstance(centers_init, str) else int(centers_init)), C.c_ulonglong(seed),
+                                  _p(centers), _p(assign), _p(dist), C.byref(m), C.byref(it)), "ismhip_kmeans")
+    return centers[:m.value], assign, dist, it.value
 
 
 PARTIAL_SHOT_SIGNATURES = {          # Codebook::getSignatureMask (codebook/codebook.cpp:952-1036): kept signatures of the 32

@@ -119,7 +119,7 @@ struct ismhip_ctx {
 enum ScratchSlot {
     SCR_KP_OFF = 1, SCR_TIE_LIST, SCR_TIE_REC, SCR_TIE_KEYS, SCR_COUNTERS, SCR_KNN_CAND_IDX, SCR_KNN_CAND_VAL,
     SCR_QNORM, SCR_FPFH_FLAG, SCR_FPFH_LIST, SCR_FPFH_SPFH, SCR_FPFH_LOOKUP, SCR_SLOT_OFF, SCR_CLASS_BW,
-    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK
+    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK, SCR_KMEANS
 };
 
 int  ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg);

@@ -105,8 +105,8 @@ __global__ void k_tr_tail(const uint32_t* __restrict__ n_words_p, const uint32_t
 // sigma sample: pair p of class c = (feature sf[f0 + p / nw], codeword act[sw[w0 + p % nw]]) in the reference's loop order
 struct SigmaClass { uint32_t f0, nf, w0, nw, d0; };      // offsets into the sample lists and the distance buffer
 __global__ __launch_bounds__(256) void k_tr_sigma_dist(int n_classes, const SigmaClass* __restrict__ sc, const uint32_t* __restrict__ sf,
-                                                       const int32_t* __restrict__ sw, int metric, const float* __restrict__ feats, int dim,
-                                                       float* __restrict__ dist) {
+                                                       const int32_t* __restrict__ sw, int metric, const float* __restrict__ feats,
+                                                       const float* __restrict__ words, int dim, float* __restrict__ dist) {
     __shared__ __attribute__((aligned(16))) float s_terms[4][1344];
     const int c = blockIdx.y;
     const SigmaClass s = sc[c];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_tr_sigma_dist(int n_classes, const Sigm
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     for (uint32_t p = blockIdx.x * 4 + wv; p < np; p += gridDim.x * 4) {
         const uint32_t fi = sf[s.f0 + p / s.nw]; const int w = sw[s.w0 + p % s.nw];
-        const float d = wave_functor(metric, feats + (size_t)fi * dim, feats + (size_t)w * dim, dim, lane, s_terms[wv]);
+        const float d = wave_functor(metric, feats + (size_t)fi * dim, words + (size_t)w * dim, dim, lane, s_terms[wv]);
         if (lane == 0) dist[s.d0 + p] = d;
     }
 }
@@ -136,6 +136,7 @@ __global__ void k_tr_sigma(int n_classes, const SigmaClass* __restrict__ sc, con
 // computeWeights: one wave per vote; weights of the word's m activating features -> median (rank selection by bisection over
 // the float bits: the weights are in [0, 1], non-negative floats order like unsigned integers)
 #define TR_MAXM 2048
+#define TR_MAXM_BIG 32768
 __global__ __launch_bounds__(256) void k_tr_weights(uint32_t n_votes_cap, const uint32_t* __restrict__ n_votes_p, const uint32_t* __restrict__ vote_word,
                                                     const uint32_t* __restrict__ vote_off, const uint32_t* __restrict__ vote_feature,
                                                     const float* __restrict__ vote_xyz, const float* __restrict__ lrf,
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void k_tr_weights(uint32_t n_votes_cap, const 
         const uint32_t fi_i = vote_feature[vi];
         const float vx = vote_xyz[(size_t)vi * 3], vy = vote_xyz[(size_t)vi * 3 + 1], vz = vote_xyz[(size_t)vi * 3 + 2];
         const float mcx = center[fi_i * 3], mcy = center[fi_i * 3 + 1], mcz = center[fi_i * 3 + 2];
-        if (m > TR_MAXM) { if (lane == 0) { atomicAdd(overflow, 1u); vote_weight[vi] = __builtin_nanf(""); } continue; }
+        if (m > TR_MAXM) { if (m > TR_MAXM_BIG && lane == 0) { atomicAdd(overflow, 1u); vote_weight[vi] = __builtin_nanf(""); } continue; }   // k_tr_weights_big
         for (uint32_t j = lane; j < m; j += 64) {
             const uint32_t fj = vote_feature[v0 + j];
             const Quat q = rot_quaternion(lrf + (size_t)fj * 9);
@@ -179,6 +180,52 @@ __global__ __launch_bounds__(256) void k_tr_weights(uint32_t n_votes_cap, const 
         else med = __uint_as_float(select(m / 2));
         if (lane == 0) vote_weight[vi] = med;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+// the same for the votes of big codewords (clustered codebooks: TR_MAXM < m <= TR_MAXM_BIG): a workgroup per vote, weights in 128 KB of LDS
+__global__ __launch_bounds__(256) void k_tr_weights_big(const uint32_t* __restrict__ n_votes_p, const uint32_t* __restrict__ vote_word,
+                                                        const uint32_t* __restrict__ vote_off, const uint32_t* __restrict__ vote_feature,
+                                                        const float* __restrict__ vote_xyz, const float* __restrict__ lrf,
+                                                        const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ kz,
+                                                        const float* __restrict__ center, float* __restrict__ vote_weight) {
+    extern __shared__ uint32_t s_big[];
+    __shared__ int s_cnt[4];
+    const uint32_t nv = *n_votes_p;
+    for (uint32_t vi = blockIdx.x; vi < nv; vi += gridDim.x) {
+        const uint32_t e = vote_word[vi];
+        const uint32_t v0 = vote_off[e], v1 = vote_off[e + 1], m = v1 - v0;
+        if (m <= TR_MAXM || m > TR_MAXM_BIG) continue;                               // uniform across the workgroup
+        const uint32_t fi_i = vote_feature[vi];
+        const float vx = vote_xyz[(size_t)vi * 3], vy = vote_xyz[(size_t)vi * 3 + 1], vz = vote_xyz[(size_t)vi * 3 + 2];
+        const float mcx = center[fi_i * 3], mcy = center[fi_i * 3 + 1], mcz = center[fi_i * 3 + 2];
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < m; j += 256) {
+            const uint32_t fj = vote_feature[v0 + j];
+            const Quat q = rot_quaternion(lrf + (size_t)fj * 9);
+            const Quat r = qmul(qmul(qconj(q), Quat{0.f, vx, vy, vz}), q);
+            const float cx = kx[fj] + r.x, cy = ky[fj] + r.y, cz = kz[fj] + r.z;
+            const float dx = cx - mcx, dy = cy - mcy, dz = cz - mcz;
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            s_big[j] = __float_as_uint((float)exp((double)((-1 * (d * d)) / (0.5f * 0.5f))));
+        }
+        __syncthreads();
+        auto select = [&](uint32_t rank) -> uint32_t {
+            uint32_t sel = 0u;
+            for (int bit = 30; bit >= 0; --bit) {
+                const uint32_t cand = sel | (1u << bit);
+                int c = 0;
+                for (uint32_t j = threadIdx.x; j < m; j += 256) c += s_big[j] < cand;
+                c = wave_sum_i(c);
+                __syncthreads();
+                if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = c;
+                __syncthreads();
+                c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+                if ((uint32_t)c <= rank) sel = cand;
+            }
+            return sel;
+        };
+        const float med = m % 2 == 0 ? (__uint_as_float(select(m / 2 - 1)) + __uint_as_float(select(m / 2))) / 2 : __uint_as_float(select(m / 2));
+        if (threadIdx.x == 0) vote_weight[vi] = med;
     }
 }
 // vote -> word (one thread per word fills its range) and per-class vote counts
@@ -232,9 +279,22 @@ __global__ void k_tr_stats3(const uint32_t* __restrict__ n_votes_p, const uint32
 
 }  // namespace
 
+// a codebook that only serves ismhip_knn: rows from a device matrix, one dummy vote per word
+int ism_knn_only_codebook(ismhip_ctx* ctx, int n_words, int dim, const float* words_d, ismhip_codebook** out) {
+    std::vector<float> words_h((size_t)n_words * dim);
+    ISM_HIP(ctx, hipMemcpyAsync(words_h.data(), words_d, words_h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> ones((size_t)n_words + 1); std::iota(ones.begin(), ones.end(), 0u);
+    std::vector<float> zxyz((size_t)n_words * 3, 0.f), sig1(1, 1.f);
+    std::vector<uint32_t> zc((size_t)n_words, 0u);
+    return ismhip_codebook_create(ctx, n_words, dim, words_h.data(), nullptr, ones.data(), zxyz.data(), nullptr, nullptr, zc.data(), zc.data(), nullptr, nullptr,
+                                  1, sig1.data(), out);
+}
+
 extern "C" int ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim, const float* desc, const float* lrf9,
                                      const float* kpx, const float* kpy, const float* kpz,
                                      const uint32_t* feat_class_h, const uint32_t* feat_model_h, const float* feat_center_h,
+                                     int n_codewords, const float* codewords,
                                      int k, int clean_up, int n_classes,
                                      int32_t* n_words_out, uint32_t* word_src_out, uint32_t* vote_offsets_out, uint32_t* vote_feature_out,
                                      float* vote_xyz_out, float* vote_weight_out, float* vote_class_weight_out, float* class_sigma_out) {
@@ -247,17 +307,15 @@ extern "C" int ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim
         if ((int)feat_class_h[i] >= n_classes) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "train_activate: class id out of range");
         if (i && feat_class_h[i] < feat_class_h[i - 1]) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "train_activate: features must be class-major (the reference iterates classes in ascending order)");
     }
+    // the codewords: cluster centres (implicit_shape_model.cpp:445-475), or the features themselves (clustering_none.cpp:25-35)
+    if (!codewords) { codewords = desc; n_codewords = n; }
+    if (n_codewords <= 0) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "train_activate: no codewords");
+    if (n_codewords < k) k = n_codewords;            // FLANN returns as many neighbours as there are rows: every feature activates every codeword
     const size_t na = (size_t)n * k;
-    // ---- step 1a: every feature activates its k nearest codewords of the all-features codebook (exact, ties -> lowest row)
-    std::vector<float> words_h((size_t)n * dim);
-    ISM_HIP(ctx, hipMemcpyAsync(words_h.data(), desc, words_h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<uint32_t> ones((size_t)n + 1); std::iota(ones.begin(), ones.end(), 0u);
-    std::vector<float> zxyz((size_t)n * 3, 0.f), sig1((size_t)n_classes, 1.f);
-    std::vector<uint32_t> zc((size_t)n, 0u);
+    const int nw_in = n_codewords;
+    // ---- step 1a: every feature activates its k nearest codewords (exact, ties -> lowest row)
     ismhip_codebook* cb = nullptr;
-    int rc = ismhip_codebook_create(ctx, n, dim, words_h.data(), nullptr, ones.data(), zxyz.data(), nullptr, nullptr, zc.data(), zc.data(), nullptr, nullptr,
-                                    n_classes, sig1.data(), &cb);
+    int rc = ism_knn_only_codebook(ctx, nw_in, dim, codewords, &cb);
     if (rc != ISMHIP_OK) return rc;
     // scratch: activation list + CSR work arrays, carved from one slot (two passes: size, then pointers)
     unsigned long long* term3_key = nullptr; int32_t* act = nullptr; float* actd = nullptr;
@@ -272,9 +330,9 @@ extern "C" int ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim
         auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 15) / 16 * 16; return p; };
         term3_key = (unsigned long long*)take((size_t)n_classes * 8);
         act = (int32_t*)take(na * 4); actd = (float*)take(na * 4); rank = (uint32_t*)take(na * 4);
-        cnt = (uint32_t*)take(((size_t)n + 1) * 4); keep = (uint32_t*)take(((size_t)n + 1) * 4); kcnt = (uint32_t*)take(((size_t)n + 1) * 4);
-        all_off = (uint32_t*)take(((size_t)n + 1) * 4); word_idx = (uint32_t*)take(((size_t)n + 1) * 4); vote_off_w = (uint32_t*)take(((size_t)n + 1) * 4);
-        members = (uint32_t*)take(na * 4); word_src = (uint32_t*)take(((size_t)n + 1) * 4); vote_off = (uint32_t*)take(((size_t)n + 1) * 4);
+        cnt = (uint32_t*)take(((size_t)nw_in + 1) * 4); keep = (uint32_t*)take(((size_t)nw_in + 1) * 4); kcnt = (uint32_t*)take(((size_t)nw_in + 1) * 4);
+        all_off = (uint32_t*)take(((size_t)nw_in + 1) * 4); word_idx = (uint32_t*)take(((size_t)nw_in + 1) * 4); vote_off_w = (uint32_t*)take(((size_t)nw_in + 1) * 4);
+        members = (uint32_t*)take(na * 4); word_src = (uint32_t*)take(((size_t)nw_in + 1) * 4); vote_off = (uint32_t*)take(((size_t)nw_in + 1) * 4);
         vote_feature = (uint32_t*)take(na * 4); vote_word = (uint32_t*)take(na * 4); feat_class = (uint32_t*)take((size_t)n * 4);
         num_features = (uint32_t*)take((size_t)n_classes * 8 + 32);             // num_features | words_per_class | overflow (zeroed together)
         vote_xyz = (float*)take(na * 12); vote_weight = (float*)take(na * 4); vote_class_weight = (float*)take(na * 4);
@@ -293,22 +351,22 @@ extern "C" int ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim
 #define TR_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { ism_set_err(ctx, ISMHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); return done(ISMHIP_ERR_HIP); } } while (0)
     TR_HIP(hipMemcpyAsync(feat_class, feat_class_h, (size_t)n * 4, hipMemcpyHostToDevice, st));
     TR_HIP(hipMemcpyAsync(center, feat_center_h, (size_t)n * 12, hipMemcpyHostToDevice, st));
-    TR_HIP(hipMemsetAsync(cnt, 0, ((size_t)n + 1) * 4, st));
+    TR_HIP(hipMemsetAsync(cnt, 0, ((size_t)nw_in + 1) * 4, st));
     TR_HIP(hipMemsetAsync(num_features, 0, (size_t)n_classes * 8 + 32, st));      // num_features, words_per_class, overflow
     TR_HIP(hipMemsetAsync(term3_key, 0, (size_t)n_classes * 8, st));
     // ---- distributions: CSR in activation order, clean-up, votes
-    const unsigned ga = (unsigned)((na + 255) / 256), gn = (unsigned)((n + 255) / 256);
+    const unsigned ga = (unsigned)((na + 255) / 256), gn = (unsigned)((nw_in + 255) / 256);
     hipLaunchKernelGGL(k_tr_count, dim3(ga), dim3(256), 0, st, (int)na, act, cnt, rank);
-    hipLaunchKernelGGL(k_tr_flags, dim3(gn), dim3(256), 0, st, n, clean_up, cnt, keep, kcnt);
-    hipLaunchKernelGGL(k_tr_scan, dim3(1), dim3(1024), 0, st, n, cnt, all_off, keep, word_idx, kcnt, vote_off_w);
+    hipLaunchKernelGGL(k_tr_flags, dim3(gn), dim3(256), 0, st, nw_in, clean_up, cnt, keep, kcnt);
+    hipLaunchKernelGGL(k_tr_scan, dim3(1), dim3(1024), 0, st, nw_in, cnt, all_off, keep, word_idx, kcnt, vote_off_w);
     hipLaunchKernelGGL(k_tr_members, dim3(ga), dim3(256), 0, st, (int)na, act, all_off, rank, members);
     hipLaunchKernelGGL(k_tr_votes, dim3(ga), dim3(256), 0, st, (int)na, k, act, all_off, members, keep, word_idx, vote_off_w, lrf9, kpx, kpy, kpz, center,
                        word_src, vote_off, vote_feature, vote_xyz);
-    hipLaunchKernelGGL(k_tr_tail, dim3(1), dim3(1), 0, st, word_idx + n, vote_off_w + n, vote_off);
+    hipLaunchKernelGGL(k_tr_tail, dim3(1), dim3(1), 0, st, word_idx + nw_in, vote_off_w + nw_in, vote_off);
     // vote_off[n_words] = n_votes: the totals of the scans
-    TR_HIP(hipMemcpyAsync(n_words_out, word_idx + n, 4, hipMemcpyDeviceToHost, st));
+    TR_HIP(hipMemcpyAsync(n_words_out, word_idx + nw_in, 4, hipMemcpyDeviceToHost, st));
     uint32_t n_votes_h = 0;
-    TR_HIP(hipMemcpyAsync(&n_votes_h, vote_off_w + n, 4, hipMemcpyDeviceToHost, st));
+    TR_HIP(hipMemcpyAsync(&n_votes_h, vote_off_w + nw_in, 4, hipMemcpyDeviceToHost, st));
     // ---- class sigma^2: sample lists from the (host) class / model ids, distances and sequential sums on the device
     {
         std::vector<SigmaClass> sc((size_t)n_classes);
@@ -356,15 +414,23 @@ extern "C" int ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim
             }
         }
         if (d0) {
-            hipLaunchKernelGGL(k_tr_sigma_dist, dim3(1024, n_classes), dim3(256), 0, st, n_classes, d_sc, d_sf, d_sw, metric, desc, dim, d_dist);
+            hipLaunchKernelGGL(k_tr_sigma_dist, dim3(1024, n_classes), dim3(256), 0, st, n_classes, d_sc, d_sf, d_sw, metric, desc, codewords, dim, d_dist);
         }
         hipLaunchKernelGGL(k_tr_sigma, dim3((n_classes + 63) / 64), dim3(64), 0, st, n_classes, d_sc, d_dist, sigma);
     }
     // ---- weights
-    const uint32_t* n_words_p = word_idx + n; const uint32_t* n_votes_p = vote_off_w + n;
+    const uint32_t* n_words_p = word_idx + nw_in; const uint32_t* n_votes_p = vote_off_w + nw_in;
     hipLaunchKernelGGL(k_tr_stats1, dim3(gn), dim3(256), 0, st, n_words_p, vote_off, vote_feature, feat_class, vote_word, num_features, words_per_class);
     hipLaunchKernelGGL(k_tr_weights, dim3(2048), dim3(256), 0, st, (uint32_t)na, n_votes_p, vote_word, vote_off, vote_feature, vote_xyz, lrf9, kpx, kpy, kpz, center,
                        vote_weight, overflow);
+    if (codewords != desc) {                                          // clustered codebooks can have codewords with thousands of votes
+        if (!ctx->attr_done.count((const void*)k_tr_weights_big)) {
+            TR_HIP(hipFuncSetAttribute((const void*)k_tr_weights_big, hipFuncAttributeMaxDynamicSharedMemorySize, TR_MAXM_BIG * 4));
+            ctx->attr_done.insert((const void*)k_tr_weights_big);
+        }
+        hipLaunchKernelGGL(k_tr_weights_big, dim3(1024), dim3(256), TR_MAXM_BIG * 4, st, n_votes_p, vote_word, vote_off, vote_feature, vote_xyz, lrf9, kpx, kpy, kpz, center,
+                           vote_weight);
+    }
     hipLaunchKernelGGL(k_tr_stats2, dim3(gn), dim3(256), 0, st, n_words_p, vote_off, vote_feature, feat_class, num_features, term3_key);
     hipLaunchKernelGGL(k_tr_stats3, dim3(ga), dim3(256), 0, st, n_votes_p, vote_word, vote_off, vote_feature, feat_class, words_per_class, term3_key, vote_class_weight);
     {
@@ -376,7 +442,7 @@ extern "C" int ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim
     // vote_off[n_words] was not written by any activation: it is the total
     uint32_t ovf = 0;
     TR_HIP(hipMemcpy(&ovf, overflow, 4, hipMemcpyDeviceToHost));
-    if (ovf) { ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "train_activate: a codeword with more than 2048 votes is not built"); return done(ISMHIP_ERR_UNSUPPORTED); }
+    if (ovf) { ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "train_activate: a codeword with more than 32768 votes is not built"); return done(ISMHIP_ERR_UNSUPPORTED); }
     if (nw > 0) {
         TR_HIP(hipMemcpy(word_src_out, word_src, (size_t)nw * 4, hipMemcpyDeviceToHost));
         TR_HIP(hipMemcpy(vote_offsets_out, vote_off, (size_t)nw * 4, hipMemcpyDeviceToHost));

@@ -451,8 +451,9 @@ static float hostDistance(int metric, const float* a, const float* b, int n) {
 
 void Codebook::activate(DeviceSession& s, const DeviceFeatures& f, const std::vector<unsigned>& feat_class, const std::vector<unsigned>& feat_instance,
                         const std::vector<unsigned>& feat_model, const std::vector<std::array<float, 3>>& feat_center,
-                        const std::vector<std::array<float, 3>>& feat_bbox_size, int metric, int n_classes) {
-    // codebook.cpp:64-368 for Clustering "None" (one codeword per training feature, clustering_none.cpp:25-35) and KNN activation.
+                        const std::vector<std::array<float, 3>>& feat_bbox_size, int metric, int n_classes, const Clustering& clustering) {
+    // codebook.cpp:64-368 with KNN / KNNRule activation; codewords = cluster centres (implicit_shape_model.cpp:445-475), or one per
+    // training feature for Clustering "None" (clustering_none.cpp:25-35)
     const uint32_t n = f.n;
     const int D = f.dim;
     if (n == 0) throw RuntimeException("no training features");
@@ -462,15 +463,22 @@ void Codebook::activate(DeviceSession& s, const DeviceFeatures& f, const std::ve
     if (k > 16) throw RuntimeException("KNN activation with K > 16 is not built");
     // the whole of Codebook::activate runs on the device (ismhip_train_activate): self-kNN, class sigma^2, K = 1 clean-up,
     // vote CSR, computeWeights and the statistical class weights. Features must be class-major, as train() collects them.
-    std::vector<float> words, centers((size_t)n * 3), lrf, kx, ky, kz;
-    s.d2h(words, f.desc, (size_t)n * D); s.d2h(lrf, f.lrf, (size_t)n * 9); s.d2h(kx, f.kx, n); s.d2h(ky, f.ky, n); s.d2h(kz, f.kz, n);
+    const bool clustered = clustering.hasCenters();
+    const uint32_t n_cw = clustered ? (uint32_t)clustering.getNumCenters() : n;
+    std::vector<uint32_t> cluster_size(n_cw, 1u);                // Codeword::m_numFeatures = clusters[i].size() (:453-473)
+    if (clustered) { std::fill(cluster_size.begin(), cluster_size.end(), 0u); for (int ci : clustering.getClusterIndices()) if (ci >= 0 && (uint32_t)ci < n_cw) cluster_size[ci]++; }
+    std::vector<float> words((size_t)n_cw * D), centers((size_t)n * 3), lrf, kx, ky, kz;
+    if (hipMemcpy(words.data(), clustered ? clustering.getClusterCentersDevice() : f.desc.as<float>(), words.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        throw RuntimeException("hipMemcpy (codewords) failed");
+    s.d2h(lrf, f.lrf, (size_t)n * 9); s.d2h(kx, f.kx, n); s.d2h(ky, f.ky, n); s.d2h(kz, f.kz, n);
     for (uint32_t i = 0; i < n; ++i) for (int d = 0; d < 3; ++d) centers[(size_t)i * 3 + d] = feat_center[i][d];
     const bool clean_up = is_knn && k == 1;                     // codebook.cpp:201-224
     int32_t n_words = 0;
-    std::vector<uint32_t> word_src(n), vote_off((size_t)n + 1), vote_feature((size_t)n * k);
+    std::vector<uint32_t> word_src(n_cw), vote_off((size_t)n_cw + 1), vote_feature((size_t)n * k);
     std::vector<float> vote_xyz((size_t)n * k * 3), vote_weight((size_t)n * k), vote_cw((size_t)n * k), sigma((size_t)std::max(1, n_classes));
     s.check(ismhip_train_activate(s.ctx, metric, (int)n, D, f.desc.as<float>(), f.lrf.as<float>(), f.kx.as<float>(), f.ky.as<float>(), f.kz.as<float>(),
-                                  feat_class.data(), feat_model.data(), centers.data(), k, clean_up ? 1 : 0, std::max(1, n_classes), &n_words, word_src.data(),
+                                  feat_class.data(), feat_model.data(), centers.data(), (int)n_cw, clustered ? clustering.getClusterCentersDevice() : nullptr,
+                                  k, clean_up ? 1 : 0, std::max(1, n_classes), &n_words, word_src.data(),
                                   vote_off.data(), vote_feature.data(), vote_xyz.data(), vote_weight.data(), vote_cw.data(), sigma.data()), "ismhip_train_activate");
     std::vector<uint32_t> kept(word_src.begin(), word_src.begin() + n_words);
     std::vector<uint32_t> sel(kept.size());
@@ -487,8 +495,10 @@ void Codebook::activate(DeviceSession& s, const DeviceFeatures& f, const std::ve
         const uint32_t w = kept[e];
         out.words.insert(out.words.end(), words.begin() + (size_t)w * D, words.begin() + (size_t)(w + 1) * D);
         out.word_weight.push_back(1.0f);
-        out.word_class.push_back(feat_class[w]);                 // Codeword::getClassId: class of the feature the word was made from
-        out.word_id.push_back((int32_t)w); out.word_num_features.push_back(1);          // clustering_none.cpp:25-35: one feature per codeword
+        // Codeword(centre, clusters[i].size(), 1.0f, keypoint and class of FEATURE i) (implicit_shape_model.cpp:466-475): with a
+        // clustered codebook that is the i-th feature, not a member of cluster i -- kept as the reference has it
+        out.word_class.push_back(feat_class[w]);
+        out.word_id.push_back((int32_t)w); out.word_num_features.push_back((int32_t)cluster_size[w]);
         out.word_keypoint.push_back(kx[w]); out.word_keypoint.push_back(ky[w]); out.word_keypoint.push_back(kz[w]);
         for (uint32_t v = vote_off[e]; v < vote_off[e + 1]; ++v) {
             const uint32_t fi = vote_feature[v];
@@ -844,6 +854,93 @@ template <> Voting* Factory<Voting>::createByType(const std::string& type) {
     throw RuntimeException("voting type \"" + type + "\" is not built (built: MeanShift, Hough3D)");
 }
 template <> Codebook* Factory<Codebook>::createByType(const std::string&) { return new Codebook(); }
+template <> Clustering* Factory<Clustering>::createByType(const std::string& type) {       // clustering_factory.h
+    if (type == ClusteringNone::getTypeStatic()) return new ClusteringNone();
+    if (type == ClusteringKMeansCount::getTypeStatic()) return new ClusteringKMeansCount();
+    if (type == ClusteringKMeansFactor::getTypeStatic()) return new ClusteringKMeansFactor();
+    if (type == ClusteringKMeansThumbRule::getTypeStatic()) return new ClusteringKMeansThumbRule();
+    if (type == ClusteringKMeansHartigan::getTypeStatic()) return new ClusteringKMeansHartigan();
+    throw RuntimeException("clustering type \"" + type + "\" is not built (built: None, KMeansCount, KMeansFactor, KMeansThumbRule, KMeansHartigan)");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Clustering (clustering/*.cpp): k-means runs on the device (ismhip_kmeans)
+// ---------------------------------------------------------------------------------------------------------------
+struct ClusterCenters { DevBuf buf; };
+Clustering::Clustering() {}
+Clustering::~Clustering() {}
+void Clustering::clear() { m_n_centers = 0; m_indices.clear(); m_distances.clear(); }
+const float* Clustering::getClusterCentersDevice() const { return m_centers ? m_centers->buf.as<float>() : nullptr; }
+void ClusteringNone::process(DeviceSession&, const DeviceFeatures& f, int) {
+    m_indices.resize(f.n);
+    std::iota(m_indices.begin(), m_indices.end(), 0);
+}
+ClusteringKMeans::ClusteringKMeans() {             // clustering_kmeans.cpp:18-26
+    addParameter(m_iterations, "Iterations", 1000);
+    addParameter(m_centersInit, "CentersInit", std::string("FLANN_CENTERS_KMEANSPP"));
+    addParameter(m_cbIndex, "CbIndex", 0.5f);      // FLANN's cluster-boundary index: search-time only, without effect on the exact search here
+    addParameter(m_seed, "Seed", 0);               // this build's random draws (the reference draws from rand())
+}
+void ClusteringKMeans::cluster(DeviceSession& s, const DeviceFeatures& f, int metric, int clusterCount) {   // clustering_kmeans.cpp:32-52, .h:53-131
+    if (f.n == 0) return;
+    if (clusterCount == 0) clusterCount = 1;
+    int init;
+    if (m_centersInit == "FLANN_CENTERS_RANDOM") init = ISMHIP_CENTERS_RANDOM;
+    else if (m_centersInit == "FLANN_CENTERS_GONZALES") init = ISMHIP_CENTERS_GONZALES;
+    else if (m_centersInit == "FLANN_CENTERS_KMEANSPP") init = ISMHIP_CENTERS_KMEANSPP;
+    else throw BadParamExceptionType<std::string>("invalid flann centers init", m_centersInit);
+    if (clusterCount > (int)f.n) {
+        LOG_WARN("Desired clusters is higher than available feature count. Creating " << f.n << " individual clusters.");
+        clusterCount = (int)f.n;
+    }
+    LOG_INFO("clustering " << f.n << " features into " << clusterCount << " clusters");
+    if (metric != ISMHIP_METRIC_L2SQ)
+        LOG_WARN("The k-means algorithm is only defined on euclidean distance. Using other distance metrics may lead to unexpected results.");
+    if (!m_centers) m_centers.reset(new ClusterCenters());
+    m_centers->buf.reserve((size_t)clusterCount * f.dim * sizeof(float));
+    DevBuf assign, dist;
+    assign.reserve((size_t)f.n * 4); dist.reserve((size_t)f.n * 4);
+    int32_t count = 0, iters = 0;
+    s.check(ismhip_kmeans(s.ctx, metric, (int)f.n, f.dim, f.desc.as<float>(), clusterCount, m_iterations, init, (unsigned long long)(long long)m_seed,
+                          m_centers->buf.as<float>(), assign.as<int32_t>(), dist.as<float>(), &count, &iters), "ismhip_kmeans");
+    if (count != clusterCount) LOG_WARN("Requested " << clusterCount << " but extracted " << count << " clusters instead");
+    LOG_INFO("k-means: " << iters << " iterations");
+    m_n_centers = count;
+    std::vector<int32_t> idx; s.d2h(idx, assign, f.n);
+    m_indices.assign(idx.begin(), idx.end());
+    s.d2h(m_distances, dist, f.n);
+}
+ClusteringKMeansCount::ClusteringKMeansCount() { addParameter(m_clusterCount, "ClusterCount", 10); }
+void ClusteringKMeansCount::process(DeviceSession& s, const DeviceFeatures& f, int metric) { cluster(s, f, metric, m_clusterCount); }
+ClusteringKMeansFactor::ClusteringKMeansFactor() { addParameter(m_clusterFactor, "ClusterFactor", 0.2f); }
+void ClusteringKMeansFactor::process(DeviceSession& s, const DeviceFeatures& f, int metric) {
+    if (m_clusterFactor > 1) { LOG_WARN("cluster count factor has to be in range [0, 1], setting to 0.5"); m_clusterFactor = 0.5f; }
+    cluster(s, f, metric, (int)std::round(f.n * m_clusterFactor));
+}
+void ClusteringKMeansThumbRule::process(DeviceSession& s, const DeviceFeatures& f, int metric) {
+    cluster(s, f, metric, (int)std::round(std::sqrt(f.n / 2.0f)));     // Mardia, Multivariate Analysis, p. 365
+}
+ClusteringKMeansHartigan::ClusteringKMeansHartigan() { addParameter(m_maxK, "MaxK", 10); }
+void ClusteringKMeansHartigan::process(DeviceSession& s, const DeviceFeatures& f, int metric) {   // clustering_kmeans_hartigan.cpp:27-66
+    const int maxK = std::max(1, m_maxK);
+    std::vector<float> dispersions(maxK);
+    for (int i = 0; i < maxK; ++i) {
+        cluster(s, f, metric, i + 1);
+        float compactness = 0.0f;                   // withinClusterSumOfSquares: distance of every feature to its nearest centre
+        for (float d : m_distances) compactness += d;
+        dispersions[i] = compactness;
+    }
+    int bestK = 0; float maxValue = 0;
+    for (int i = 0; i + 1 < maxK; ++i) {
+        const int numClusters = i + 1;
+        const float factor = (float)((int)f.n - numClusters - 1);
+        const float index = ((dispersions[i] / dispersions[i + 1]) - 1) * factor;
+        if (index > maxValue) { maxValue = index; bestK = i + 1; }
+    }
+    if (bestK < 1) bestK = 1;                       // the reference would index centers[-1] here
+    LOG_INFO("best value for k: " << bestK);
+    cluster(s, f, metric, bestK);                   // same seed, same data: the clustering of that pass again
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // ImplicitShapeModel (implicit_shape_model.cpp)
@@ -884,7 +981,7 @@ Json ImplicitShapeModel::iChildConfigsToJson() const {   // :1070-1083
     c["Keypoints"] = m_keypoints_detector->configToJson();
     c["Features"] = m_feature_descriptor->configToJson();
     if (!m_global_features_cfg.isNull()) c["GlobalFeatures"] = m_global_features_cfg;
-    c["Clustering"] = m_clustering_cfg.isNull() ? Json::parse("{\"Type\":\"None\"}") : m_clustering_cfg;
+    c["Clustering"] = m_clustering ? m_clustering->configToJson() : Json::parse("{\"Type\":\"None\"}");
     c["Voting"] = m_voting->configToJson();
     c["FeatureWeighting"] = m_feature_ranking_cfg.isNull() ? Json::parse("{\"Type\":\"Uniform\"}") : m_feature_ranking_cfg;
     return c;
@@ -897,14 +994,12 @@ bool ImplicitShapeModel::iChildConfigsFromJson(const Json& c) {   // :1085-1142
     m_keypoints_detector.reset(Factory<Keypoints>::create(*kp));
     m_feature_descriptor.reset(Factory<Features>::create(*ft));
     m_voting.reset(Factory<Voting>::create(*vo));
-    m_clustering_cfg = *cl; m_feature_ranking_cfg = *fw;
+    m_clustering.reset(Factory<Clustering>::create(*cl)); m_feature_ranking_cfg = *fw;
     if (const Json* gf = c.find("GlobalFeatures")) m_global_features_cfg = *gf;
-    const Json* ct = cl->find("Type");
-    if (!ct || ct->str != "None") throw RuntimeException("clustering type \"" + (ct ? ct->str : std::string()) + "\" is out of scope (training-only; built: None)");
     const Json* rt = fw->find("Type");
     if (!rt || rt->str != "Uniform") throw RuntimeException("feature ranking type \"" + (rt ? rt->str : std::string()) + "\" is out of scope (built: Uniform)");
     if (m_use_smoothing || m_use_sor || m_use_ror || m_use_voxel_filtering) throw RuntimeException("point cloud pre-filters (smoothing / outlier removal / voxel filtering) are not built");
-    return m_codebook && m_keypoints_detector && m_feature_descriptor && m_voting;
+    return m_codebook && m_keypoints_detector && m_feature_descriptor && m_voting && m_clustering;
 }
 
 void ImplicitShapeModel::iSaveData(std::ostream& os) const {      // :1144-1179, as a Boost binary archive (boost_archive.h)
@@ -1104,7 +1199,10 @@ void ImplicitShapeModel::train() {                // :252-500
     DeviceSession::h2d(all->desc, hdesc); DeviceSession::h2d(all->lrf, hlrf); DeviceSession::h2d(all->kx, hkx); DeviceSession::h2d(all->ky, hky); DeviceSession::h2d(all->kz, hkz);
     LOG_INFO("activating codewords with " << all->n << " training features");
     m_voting->forwardBoxesAndRadii(box_sizes, object_radii);     // :433: bandwidth hints per class, persisted with the model
-    m_codebook->activate(s, *all, fclass, finst, fmodel, fcenter, fbox, met, m_n_classes);
+    LOG_INFO("clustering");                                      // :445-449
+    if (!m_clustering) m_clustering.reset(new ClusteringNone());
+    (*m_clustering)(s, *all, met);
+    m_codebook->activate(s, *all, fclass, finst, fmodel, fcenter, fbox, met, m_n_classes, *m_clustering);
     LOG_INFO("training done");
 }
 

@@ -250,6 +250,75 @@ private:
     int m_k;
 };
 
+// ---- Clustering (clustering/clustering.h:31-99) ----------------------------------------------------------------------------
+// operator() clusters the descriptors of all training features; getClusterCenters / getClusterIndices as in the reference, with
+// the centres left on the device (they are the rows of the activation codebook). "None": one cluster per feature, no centre matrix.
+struct ClusterCenters;         // device matrix [n x dim] (ism3d.cpp)
+class Clustering : public JSONObject {
+public:
+    Clustering();
+    virtual ~Clustering();
+    void operator()(DeviceSession& s, const DeviceFeatures& f, int metric) { clear(); process(s, f, metric); }
+    virtual void clear();
+    bool hasCenters() const { return m_n_centers > 0; }
+    int getNumCenters() const { return m_n_centers; }
+    const float* getClusterCentersDevice() const;
+    const std::vector<int>& getClusterIndices() const { return m_indices; }
+protected:
+    virtual void process(DeviceSession& s, const DeviceFeatures& f, int metric) = 0;
+    std::unique_ptr<ClusterCenters> m_centers;
+    int m_n_centers = 0;
+    std::vector<int> m_indices;
+    std::vector<float> m_distances;            // functor distance of every feature to its centre
+};
+class ClusteringNone : public Clustering {        // clustering_none.cpp:25-35: every feature is its own centre
+public:
+    static std::string getTypeStatic() { return "None"; }
+    std::string getType() const override { return getTypeStatic(); }
+protected:
+    void process(DeviceSession& s, const DeviceFeatures& f, int metric) override;
+};
+class ClusteringKMeans : public Clustering {      // clustering_kmeans.{h,cpp}: Iterations, CentersInit, CbIndex (+ Seed: this build's draws)
+protected:
+    ClusteringKMeans();
+    void cluster(DeviceSession& s, const DeviceFeatures& f, int metric, int clusterCount);
+    int m_iterations; std::string m_centersInit; float m_cbIndex; int m_seed;
+};
+class ClusteringKMeansCount : public ClusteringKMeans {         // clustering_kmeans_count.cpp
+public:
+    ClusteringKMeansCount();
+    static std::string getTypeStatic() { return "KMeansCount"; }
+    std::string getType() const override { return getTypeStatic(); }
+protected:
+    void process(DeviceSession& s, const DeviceFeatures& f, int metric) override;
+    int m_clusterCount;
+};
+class ClusteringKMeansFactor : public ClusteringKMeans {        // clustering_kmeans_factor.cpp
+public:
+    ClusteringKMeansFactor();
+    static std::string getTypeStatic() { return "KMeansFactor"; }
+    std::string getType() const override { return getTypeStatic(); }
+protected:
+    void process(DeviceSession& s, const DeviceFeatures& f, int metric) override;
+    float m_clusterFactor;
+};
+class ClusteringKMeansThumbRule : public ClusteringKMeans {     // clustering_kmeans_thumb_rule.cpp
+public:
+    static std::string getTypeStatic() { return "KMeansThumbRule"; }
+    std::string getType() const override { return getTypeStatic(); }
+protected:
+    void process(DeviceSession& s, const DeviceFeatures& f, int metric) override;
+};
+class ClusteringKMeansHartigan : public ClusteringKMeans {      // clustering_kmeans_hartigan.cpp
+public:
+    ClusteringKMeansHartigan();
+    static std::string getTypeStatic() { return "KMeansHartigan"; }
+    std::string getType() const override { return getTypeStatic(); }
+protected:
+    void process(DeviceSession& s, const DeviceFeatures& f, int metric) override;
+    int m_maxK;
+};
+
 struct CodebookData {          // host copy of what Codebook::iSaveData persists (flattened CodewordDistributions)
     int dim = 0;
     std::vector<float> words, word_weight;
@@ -272,10 +341,10 @@ public:
     Codebook();
     ~Codebook();
     std::string getType() const override { return "Codebook"; }
-    // training: Codebook::activate (codebook.cpp:64-368) for Clustering "None": one codeword per feature
+    // training: Codebook::activate (codebook.cpp:64-368); the codewords are the clustering's centres (one per feature for "None")
     void activate(DeviceSession& s, const DeviceFeatures& f, const std::vector<unsigned>& feat_class, const std::vector<unsigned>& feat_instance,
                   const std::vector<unsigned>& feat_model, const std::vector<std::array<float, 3>>& feat_center,
-                  const std::vector<std::array<float, 3>>& feat_bbox_size, int metric, int n_classes);
+                  const std::vector<std::array<float, 3>>& feat_bbox_size, int metric, int n_classes, const Clustering& clustering);
     // detection: Codebook::castVotes (codebook.cpp:403-555): activate every feature, emit the votes into the voting space
     void castVotes(DeviceSession& s, const DeviceFeatures& f, int metric, Voting& voting) const;
     bool isEmpty() const { return m_data.numWords() == 0; }
@@ -430,7 +499,8 @@ private:
     std::unique_ptr<Keypoints> m_keypoints_detector;
     std::unique_ptr<Features> m_feature_descriptor;
     std::unique_ptr<Voting> m_voting;
-    Json m_clustering_cfg, m_feature_ranking_cfg, m_global_features_cfg;
+    std::unique_ptr<Clustering> m_clustering;
+    Json m_feature_ranking_cfg, m_global_features_cfg;
     std::map<unsigned, std::vector<std::shared_ptr<PointCloud>>> m_training_clouds;     // class -> models
     std::map<unsigned, std::vector<unsigned>> m_training_instances;
     std::map<unsigned, std::string> m_class_labels, m_instance_labels;

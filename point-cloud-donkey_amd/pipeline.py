@@ -46,6 +46,12 @@ class IsmConfig:
     hough_bin_size: float = 0.2
     hough_use_interpolation: bool = True
     hough_rel_threshold: float = 0.8
+    clustering: str = "None"         # Clustering.Type: "None" | "KMeansCount" | "KMeansFactor" | "KMeansThumbRule"
+    cluster_count: int = 10          # Clustering.ClusterCount (KMeansCount)
+    cluster_factor: float = 0.2      # Clustering.ClusterFactor (KMeansFactor)
+    kmeans_iterations: int = 1000    # Clustering.Iterations
+    kmeans_centers_init: str = "FLANN_CENTERS_KMEANSPP"
+    kmeans_seed: int = 0             # this build's draws (the reference draws from rand())
     n_classes: int = 10
     use_random_codebook: bool = False
     random_codebook_size: int = 0    # fixed-size seeded subset (reference: UseRandomCodebook/RandomCodebookFactor, codebook.cpp:821-829)
@@ -197,9 +203,17 @@ class Recognizer:
         assert (np.diff(cls.astype(np.int64)) >= 0).all(), "training objects must be ordered class-major"
         knn_rule = getattr(c, "activation", "KNN") == "KNNRule"
         k_act = 1 if knn_rule else c.k                       # KNNRule trains with plain 1-NN and keeps multi-vote codewords
+        # clustering (implicit_shape_model.cpp:445-475): k-means centres become the codewords; "None" = every feature its own codeword
+        centres = None
+        kind = getattr(c, "clustering", "None")
+        if kind != "None":
+            count = {"KMeansCount": lambda: c.cluster_count, "KMeansFactor": lambda: int(round(n * min(c.cluster_factor, 1.0))),
+                     "KMeansThumbRule": lambda: int(round(float(np.sqrt(np.float32(n / 2.0)))))}[kind]()
+            centres, self.cluster_indices, _, self.kmeans_iterations = capi.kmeans(ctx, c.metric, desc, max(1, count), c.kmeans_iterations,
+                                                                                   c.kmeans_centers_init, c.kmeans_seed)
         act = capi.train_activate(ctx, c.metric, desc, lrf, kp[:, 0].contiguous(), kp[:, 1].contiguous(), kp[:, 2].contiguous(), cls, model,
-                                  center.cpu().numpy(), k=k_act, clean_up=(not knn_rule and c.k == 1), n_classes=c.n_classes)
-        words_h = desc.cpu().numpy()
+                                  center.cpu().numpy(), k=k_act, clean_up=(not knn_rule and c.k == 1), n_classes=c.n_classes, codewords=centres)
+        words_h = (desc if centres is None else centres).cpu().numpy()
         keep_words, vote_off, src = act["word_src"].astype(np.int64), act["vote_offsets"], act["vote_feature"].astype(np.int64)
         vote_xyz, vote_w, vote_cw = act["vote_xyz"], act["vote_weight"], act["vote_class_weight"]
         if c.use_random_codebook and 0 < c.random_codebook_size < len(keep_words):

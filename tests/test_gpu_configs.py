@@ -137,6 +137,41 @@ def test_cfg1_knn_rule_activation_end_to_end(pkg, gpu, ora):
     assert (got["cls"][:, 0].cpu().numpy() == nb["labels"]).all()
 
 
+def test_kmeans_codebook_with_vote_fan_out_end_to_end(pkg, gpu, ora):
+    """Clustering KMeansCount + KNN activation with K = 2 (the reference's clustered setting, implicit_shape_model.cpp:445-490): the
+    training features are clustered on the device, every feature votes through its 2 nearest centres, detection activates 2 centres
+    per feature and casts all their votes. Checked stage by stage: centres and distributions against the oracle's k-means /
+    activate on the same features, detection against the oracle's kNN + castVotes on the trained codebook; the objects are classified."""
+    cfg = pkg.pipeline.IsmConfig(feature="SHOT", n_classes=3, k=2, clustering="KMeansCount", cluster_count=300, kmeans_iterations=25, kmeans_seed=4,
+                                 use_vote_weight=True, use_matching_weight=True, max_maxima=8)   # (the class weights' class-keyed term3 misleads 150-word codebooks)
+    syn = pkg.synthetic
+    train = syn.Dataset(3, 6, split=0, n_points=8192, n_keypoints=384)
+    test = syn.Dataset(3, 3, split=1, n_points=8192, n_keypoints=384)
+    ctx, dev = gpu
+    rec = pkg.pipeline.Recognizer(ctx, cfg)
+    order = sorted(range(6), key=lambda i: (train.label(i), i))
+    tb = pkg.pipeline.DeviceBatch(train.batch(order), dev)
+    cb = rec.train([tb])
+    assert len(cb["words"]) == 300 and rec.kmeans_iterations >= 2
+    sizes = np.diff(cb["vote_offsets"].astype(np.int64))
+    assert sizes.sum() == 2 * len(rec.cluster_indices) and sizes.max() > 3          # fan-out: every feature left 2 votes
+    # the training features again, through the oracle's clustering and activation
+    f = rec.compute_features(tb)
+    desc = f["desc"].cpu().numpy()
+    wcen, wassign, _, wit = ora.kmeans(cfg.metric, desc, 300, max_iterations=25, centers_init=2, seed=4)
+    assert np.array_equal(wcen, cb["words"]) and np.array_equal(wassign, rec.cluster_indices.cpu().numpy()) and wit == rec.kmeans_iterations
+    # detection on the clustered codebook
+    nb = test.batch(range(3))
+    got = rec.detect(pkg.pipeline.DeviceBatch(nb, dev), keep_intermediates=True)
+    fd = got["features"]
+    wi, wd = ora.knn(cfg.metric, cb["words"], fd["desc"].cpu().numpy(), 2)
+    assert np.array_equal(got["idx"].cpu().numpy().reshape(-1, 2), wi)
+    votes = ora.cast_votes(cb, cfg.weight_flags, fd["lrf"].cpu().numpy(), fd["kx"].cpu().numpy(), fd["ky"].cpu().numpy(), fd["kz"].cpu().numpy(), wi, wd)
+    assert np.array_equal(got["votes"]["cls"].cpu().numpy(), votes["cls"])
+    np.testing.assert_allclose(got["votes"]["weight"].cpu().numpy(), votes["weight"], rtol=1e-5, atol=1e-9)
+    assert (got["cls"][:, 0].cpu().numpy() == nb["labels"]).all()
+
+
 def test_knn_rule_matches_oracle(pkg, gpu, ora):
     import torch
     ctx, dev = gpu

@@ -893,6 +893,98 @@ def test_train_activate_matches_oracle(pkg, gpu, ora, metric, k, clean_up):
         assert len(want["word_src"]) < n - 30                                  # the duplicated rows were cleaned away
 
 
+def _training_set(rng, n, D, n_proto=60, n_classes=4):
+    proto = rng.random((n_proto, D)).astype(np.float32)
+    feats = (proto[rng.integers(0, n_proto, n)] + 0.05 * rng.random((n, D))).astype(np.float32)
+    cls = np.sort(rng.integers(0, n_classes, n)).astype(np.uint32)
+    model = np.zeros(n, np.uint32)
+    for c in range(n_classes):
+        ids = np.nonzero(cls == c)[0]
+        model[ids] = c * 10 + (np.arange(len(ids)) * 3 // max(1, len(ids)))
+    A = rng.normal(size=(n, 3, 3)); Q, _ = np.linalg.qr(A); Q[np.linalg.det(Q) < 0, 2] *= -1
+    lrf = Q.reshape(n, 9).astype(np.float32); kp = rng.normal(size=(n, 3)).astype(np.float32)
+    centre = rng.normal(size=(10 * n_classes, 3)).astype(np.float32)[model]
+    return feats, cls, model, lrf, kp, centre
+
+
+@pytest.mark.parametrize("init", ["FLANN_CENTERS_RANDOM", "FLANN_CENTERS_GONZALES", "FLANN_CENTERS_KMEANSPP"])
+@pytest.mark.parametrize("metric,shape,k", [(0, (3000, 48), 40), (1, (1200, 33), 25), (0, (5000, 352), 300), (0, (400, 16), 400)])
+def test_kmeans_matches_oracle(pkg, gpu, ora, init, metric, shape, k):
+    """ClusteringKMeans::cluster (clustering_kmeans.h:53-131) on the device against the oracle's sequential restatement of the same
+    build-defined k-means (seeded draws, integer potentials and means): centres, assignment, distances and the iteration count are
+    bit-identical. FLANN itself is random and approximate here -- parity with the reference is unpinned (DESIGN)."""
+    ctx, dev = gpu
+    n, D = shape
+    rng = np.random.default_rng(n + D + k)
+    feats = _training_set(rng, n, D, n_proto=max(5, k // 2))[0]
+    feats = (feats + 0.2 * rng.normal(size=feats.shape)).astype(np.float32)     # overlapping clusters: Lloyd needs several rounds
+    if metric == 1:
+        feats = np.abs(feats)
+    feats[7] = feats[3]; feats[n - 1] = feats[3]                  # coinciding points: never two centres on them
+    cen, assign, dist, it = pkg.capi.kmeans(ctx, metric, T(feats, dev), k, max_iterations=30, centers_init=init, seed=11)
+    wcen, wassign, wdist, wit = ora.kmeans(metric, feats, k, max_iterations=30, centers_init=pkg.capi.CENTERS_INIT[init], seed=11)
+    print(f"kmeans {init} metric {metric} {shape} k={k}: {len(wcen)} centres, {wit} iterations, sizes {np.bincount(wassign, minlength=len(wcen)).min()}..{np.bincount(wassign).max()}")
+    assert it == wit and tuple(cen.shape) == wcen.shape
+    assert np.array_equal(cen.cpu().numpy(), wcen)
+    assert np.array_equal(assign.cpu().numpy(), wassign)
+    assert np.array_equal(dist.cpu().numpy(), wdist)
+    if k < n:                                                      # a k-means result: every feature sits with its nearest centre, no centre is idle
+        assert np.bincount(wassign, minlength=len(wcen)).min() >= 1 or wit == 30
+    else:
+        assert len(wcen) <= n - 2                                  # the coinciding points cannot all become centres
+
+
+def test_kmeans_on_separated_blobs_finds_them(pkg, gpu):
+    """property: well separated blobs, k = number of blobs, k-means++ -> one centre per blob (its mean), every member assigned to it"""
+    ctx, dev = gpu
+    rng = np.random.default_rng(8)
+    mu = rng.normal(size=(12, 64)).astype(np.float32) * 4
+    lab = rng.integers(0, 12, 6000)
+    x = (mu[lab] + 0.1 * rng.normal(size=(6000, 64))).astype(np.float32)
+    cen, assign, dist, it = pkg.capi.kmeans(ctx, 0, T(x, dev), 12, seed=1)
+    a = assign.cpu().numpy(); c = cen.cpu().numpy()
+    assert len(c) == 12 and it <= 10
+    for b in range(12):
+        ids = np.nonzero(lab == b)[0]
+        assert len(set(a[ids])) == 1
+        np.testing.assert_allclose(c[a[ids[0]]], x[ids].mean(0), atol=1e-5)
+
+
+@pytest.mark.parametrize("metric,k,clean_up", [(0, 2, False), (0, 3, False), (1, 2, False), (0, 1, True), (0, 6, False)])
+def test_train_activate_with_cluster_centres_matches_oracle(pkg, gpu, ora, metric, k, clean_up):
+    """Codebook::activate with a clustered codebook (implicit_shape_model.cpp:445-490): the codewords are k-means centres, every
+    feature activates its K nearest of them (vote fan-out), distributions hold tens to hundreds of votes -- one of them more than
+    2048, which takes the workgroup-per-vote median kernel -- and sigma^2 samples feature x centre distances."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(70 + 10 * metric + k)
+    n, D = 6000, 32
+    feats, cls, model, lrf, kp, centre = _training_set(rng, n, D, n_proto=30)
+    feats[2000:4600] = feats[2000] + 1e-3 * rng.random((2600, D)).astype(np.float32)    # 2600 features around one point: one crowded codeword
+    cen, assign, _, _ = pkg.capi.kmeans(ctx, metric, T(feats, dev), 45, max_iterations=20, seed=5)
+    cen_h = cen.cpu().numpy()
+    got = pkg.capi.train_activate(ctx, metric, T(feats, dev), T(lrf, dev), T(kp[:, 0], dev), T(kp[:, 1], dev), T(kp[:, 2], dev), cls, model, centre,
+                                  k=k, clean_up=clean_up, n_classes=4, codewords=cen)
+    want = ora.activate(metric, feats, lrf, kp, cls, model, centre, k=k, clean_up=clean_up, n_classes=4, codewords=cen_h)
+    for key in ("word_src", "vote_offsets", "vote_feature"):
+        assert np.array_equal(got[key], want[key]), key
+    np.testing.assert_allclose(got["vote_xyz"], want["vote_xyz"], atol=2e-6)
+    np.testing.assert_allclose(got["vote_weight"], want["vote_weight"], atol=2e-6)
+    np.testing.assert_allclose(got["vote_class_weight"], want["vote_class_weight"], rtol=1e-6, atol=1e-12)
+    assert np.array_equal(got["class_sigma"], want["class_sigma"])
+    sizes = np.diff(want["vote_offsets"].astype(np.int64))
+    if not clean_up:
+        assert len(want["word_src"]) == 45 and sizes.sum() == n * k and sizes.max() > 2048
+    else:
+        assert len(want["word_src"]) < 45                          # K = 1 clean-up keeps only single-vote codewords (codebook.cpp:201-224)
+    if k == 3:                                                     # fewer codewords than K: every feature activates all of them
+        two = cen[:2].contiguous()
+        got = pkg.capi.train_activate(ctx, metric, T(feats[:500], dev), T(lrf[:500], dev), T(kp[:500, 0], dev), T(kp[:500, 1], dev), T(kp[:500, 2], dev),
+                                      cls[:500], model[:500], centre[:500], k=3, clean_up=False, n_classes=4, codewords=two)
+        want = ora.activate(metric, feats[:500], lrf[:500], kp[:500], cls[:500], model[:500], centre[:500], k=3, clean_up=False, n_classes=4, codewords=cen_h[:2])
+        assert np.array_equal(got["vote_offsets"], want["vote_offsets"]) and list(want["vote_offsets"]) == [0, 500, 1000]
+        assert np.array_equal(got["vote_feature"], want["vote_feature"]) and np.array_equal(got["class_sigma"][:1], want["class_sigma"][:1])
+
+
 # ------------------------------------------------------------------------------------------------ round-2 known-answer vectors
 # the same closed-form vectors the oracle is held to (tests/kat_checks.py), here through the C ABI on the GPU
 def test_kat_shot_off_centre_interpolation(pkg, gpu):

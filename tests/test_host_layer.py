@@ -54,11 +54,14 @@ def test_config_errors_match_reference_behaviour():
     for edits, needle in [({"Children/Features/Type": "PFH"}, "outside the MI355X hot path"),
                           ({"Children/Voting/Type": "Hough4D"}, "not built"),
                           ({"Children/Codebook/Children/ActivationStrategy/Type": "INN"}, "not built"),
-                          ({"Children/Clustering/Type": "KMeans"}, "out of scope"),
+                          ({"Children/Clustering/Type": "Agglomerative"}, "not built"),
+                          ({"Children/Clustering": {"Type": "KMeansCount", "Parameters": {"CentersInit": "FLANN_CENTERS_BEST"}}}, None),
                           ({"Parameters/DistanceType": "Manhattan"}, "invalid distance type"),
                           ({"Children/Voting/Parameters/MaxIter": "many"}, "invalid type for parameter"),
                           ({"Parameters/UseSmoothing": True}, "not built")]:
         m = hb.Model()
+        if needle is None:                                        # the value is checked when the clustering runs, as in the reference's trait
+            m.config_from_json(_cfg(**edits)); continue
         with pytest.raises(hb.HostError) as e:
             m.config_from_json(_cfg(**edits))
         assert needle in str(e.value), (edits, str(e.value))
@@ -369,6 +372,61 @@ def test_host_partial_shot_and_bandwidth_types(pkg, gpu, tmp_path):
     nb = test.batch(range(6))
     got = m2.detect_batch(nb["pt_off"], nb["xyz"], nb["normals"], max_maxima=4)
     assert (got["cls"][:, 0] == nb["labels"]).all()
+
+
+@pytest.mark.gpu
+def test_host_kmeans_clustering_matches_python_harness(pkg, gpu, tmp_path):
+    """Clustering KMeansCount / KMeansFactor / KMeansThumbRule / KMeansHartigan through the C++ host (clustering/*.cpp): codewords are
+    the device k-means' centres, KNN activation with K = 2 fans every feature's vote out; the codebook equals the Python harness's on
+    the same data (both drive ismhip_kmeans + ismhip_train_activate), survives the .ismd round trip and classifies the test objects."""
+    import torch
+    ctx, dev = gpu
+    train, test = _dataset(pkg, 3, 9, 6)
+    order = sorted(range(9), key=lambda i: (train.label(i), i))
+    edits = {"Children/Clustering": {"Type": "KMeansCount", "Parameters": {"ClusterCount": 300, "Iterations": 25, "Seed": 4}},
+             "Children/Codebook/Children/ActivationStrategy/Parameters/K": 2,
+             "Children/Codebook/Parameters/UseVoteWeight": True, "Children/Codebook/Parameters/UseMatchingWeight": True}
+    m = hb.Model()
+    m.config_from_json(_cfg(**edits))
+    assert json.loads(m.config_to_json())["Children"]["Clustering"]["Parameters"]["CentersInit"] == "FLANN_CENTERS_KMEANSPP"
+    for i in order:
+        o = train.get(i)
+        m.add_training(o["xyz"], o["normals"], o["label"], i)
+    m.train()
+    cfg = pkg.pipeline.IsmConfig(n_classes=3, k=2, clustering="KMeansCount", cluster_count=300, kmeans_iterations=25, kmeans_seed=4,
+                                 use_vote_weight=True, use_matching_weight=True)
+    rec = pkg.pipeline.Recognizer(ctx, cfg)
+    cb = rec.train([pkg.pipeline.DeviceBatch(train.batch(order), dev)], instance_ids=order)
+    got = m.codebook_all()
+    assert got["words"].shape == cb["words"].shape == (300, 352)
+    # (1-ulp keypoint differences between the two hosts' voxel grids move descriptor entries by a few 1e-6, see the test above)
+    np.testing.assert_allclose(got["words"], cb["words"], atol=2e-5)
+    assert np.array_equal(got["vote_offsets"], cb["vote_offsets"]) and np.array_equal(got["vote_class"], cb["vote_class"])
+    np.testing.assert_allclose(got["vote_xyz"], cb["vote_xyz"], atol=1e-4)
+    np.testing.assert_allclose(got["vote_weight"], cb["vote_weight"], atol=1e-4)
+    assert got["vote_offsets"][-1] == 2 * len(rec.cluster_indices)
+    path = str(tmp_path / "km.ism")
+    m.write(path)
+    m2 = hb.Model()
+    m2.read(path)
+    nb = test.batch(range(6))
+    out = m2.detect_batch(nb["pt_off"], nb["xyz"], nb["normals"], max_maxima=4)
+    assert (out["cls"][:, 0] == nb["labels"]).all()
+    # the other cluster-count rules: count from the feature total
+    n_feat = len(rec.cluster_indices)
+    for kind, params, want in [("KMeansFactor", {"ClusterFactor": 0.1, "Iterations": 3}, int(round(n_feat * np.float32(0.1)))),
+                               ("KMeansThumbRule", {"Iterations": 3}, int(round(float(np.sqrt(np.float32(n_feat / 2.0)))))),
+                               ("KMeansHartigan", {"MaxK": 4, "Iterations": 5}, None)]:
+        mk = hb.Model()
+        mk.config_from_json(_cfg(**{"Children/Clustering": {"Type": kind, "Parameters": params}, "Children/Codebook/Children/ActivationStrategy/Parameters/K": 2}))
+        for i in order:
+            o = train.get(i)
+            mk.add_training(o["xyz"], o["normals"], o["label"], i)
+        mk.train()
+        if want is not None:
+            assert mk.codebook_size() == want, (kind, mk.codebook_size(), want)
+        else:
+            assert 1 <= mk.codebook_size() <= 4
 
 
 @pytest.mark.gpu
