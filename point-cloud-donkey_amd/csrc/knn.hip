@@ -38,6 +38,20 @@ struct TopT {
 #pragma unroll
         for (int t = 0; t < T; ++t) { v[t] = __builtin_inff(); i[t] = -1; }
     }
+    // the same insertion without a branch (k_knn_l2_ring16's epilogue: a wave enters it when ANY lane has a score to insert, and
+    // nested exec-mask branches cost more than thirteen predicated instructions); x = +inf leaves the list as it is
+    __device__ __forceinline__ void push_flat(float x, int idx) {
+        bool c[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) c[t] = x < v[t];
+#pragma unroll
+        for (int t = T - 1; t > 0; --t) {
+            v[t] = c[t - 1] ? v[t - 1] : (c[t] ? x : v[t]);
+            i[t] = c[t - 1] ? i[t - 1] : (c[t] ? idx : i[t]);
+        }
+        v[0] = c[0] ? x : v[0];
+        i[0] = c[0] ? idx : i[0];
+    }
     // insert keeping ascending order; strict < keeps the earlier (lower row) on ties
     __device__ __forceinline__ void push(float x, int idx) {
         if (!(x < v[T - 1])) return;
@@ -723,6 +737,11 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
 //   C tile: lane l holds rows 4 (l >> 4) + j, j = 0..3, of column (l & 15): a lane now serves FOUR query columns (one per n-tile)
 //     with four codeword rows per tile each, so a query column is scanned by 8 lane slots per workgroup (4 row groups x 2 wave
 //     rows) and the kernel leaves 8 slots per codebook split (the host limits it to two splits: 64 candidates per query)
+#ifdef ISM_KNN_DBG_VARIANTS
+// DBG & 256: [0] wave-tiles, [1] with a hit, [2] flagged columns, [3] flagged groups, [4] flagged scores, [5] inserting lanes;
+// [8 + t] flagged scores of tile index t (t < 248) summed over waves
+__device__ unsigned long long g_knn_dbg[256];
+#endif
 template <int T, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict__ wh, const float* __restrict__ word_norm, int n_tiles_m, int ld, int k_steps,
                                                           const u16* __restrict__ qh, int nq, const float* __restrict__ out_scale,
@@ -776,6 +795,9 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
 #pragma unroll
     for (int n = 0; n < NT; ++n) { top[n].init(); thr[n] = -__builtin_inff(); }
     f32x4 acc[MT][NT];
+#ifdef ISM_KNN_DBG_VARIANTS
+    unsigned dbg_c[6] = {0, 0, 0, 0, 0, 0};
+#endif
     const int pw = (1 - wr) * WC + wc;
 #pragma unroll
     for (int n = 0; n < NT; ++n) sThr[(wv * NT + n) * 64 + lane] = -__builtin_inff();
@@ -790,8 +812,10 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
     for (int g = 0; g < G; ++g) {
         const u16* st = ring + (g & (RG_STAGES - 1)) * RG_STAGE_HALVES;
         const u16* sn = ring + ((g + 1) & (RG_STAGES - 1)) * RG_STAGE_HALVES;
+        if (!(DBG & 16) || g == 0) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) bq[n] = *(const f16x8*)(st + fragB + n * 16 * KB);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
         // first slice of a tile: the accumulators START from the tile's pre-scaled |c|^2 row (rows 16 mt + 4 fq + j), passed as
@@ -804,56 +828,129 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
                 for (int mt = 0; mt < 4; ++mt) {
                     const f32x4 c0 = *(const f32x4*)(cnp + (mb + mt) * 16);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mb + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bq[nt], c0, 0, 0, 0);
-                    nxt[mt] = *(const f16x8*)(nsrc + mt * 16 * KB);
+                    for (int nt = 0; nt < NT; ++nt) { if (!(DBG & 2)) acc[mb + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bq[nt], c0, 0, 0, 0); else acc[mb + mt][nt] = c0; }
+                    if (!(DBG & 16) || g == 0) nxt[mt] = *(const f16x8*)(nsrc + mt * 16 * KB);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mb + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bq[nt], acc[mb + mt][nt], 0, 0, 0);
-                    nxt[mt] = *(const f16x8*)(nsrc + mt * 16 * KB);
+                    for (int nt = 0; nt < NT; ++nt) if (!(DBG & 2)) acc[mb + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bq[nt], acc[mb + mt][nt], 0, 0, 0);
+                    if (!(DBG & 16) || g == 0) nxt[mt] = *(const f16x8*)(nsrc + mt * 16 * KB);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         };
         mma4(0, xa, ya, st + fragA + 4 * 16 * KB);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        issue();
+        if (!(DBG & 32)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!(DBG & 4) || g < 4) issue();
         __builtin_amdgcn_sched_barrier(0);
         mma4(4, ya, xa, sn + fragA);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (++kc == nk) {
             const int row0 = (mt0 + t) * BM + wr * (MT * 16) + 4 * fq;
+            if (DBG & 1) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int nt = 0; nt < NT; ++nt) top[nt].v[0] += acc[mt][nt][0];
+            } else {
+                // Epilogue. A scalar branch right behind the vector compare it depends on stalls ~19 cycles, and 128 of those pairs
+                // per tile were a good part of the kernel. So: the largest of a column's 32 scores by 16 v_max3_f32, ONE compare
+                // per column into its own SGPR pair, one branch per tile (measured: the test itself is free, 13.0 ms with and
+                // without it); only a column that does hold a score above its threshold is walked.
+                float mx[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float m;
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[0][nt][0]), "v"(acc[0][nt][1]), "v"(acc[0][nt][2]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(acc[0][nt][3]));
+#pragma unroll
+                    for (int mt = 1; mt < MT; ++mt) {
+                        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[mt][nt][0]), "v"(acc[mt][nt][1]));
+                        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[mt][nt][2]), "v"(acc[mt][nt][3]));
+                    }
+                    mx[nt] = m;
+                }
+                unsigned long long hit[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) hit[nt] = __ballot(mx[nt] > thr[nt]);
+#ifdef ISM_KNN_DBG_VARIANTS
+                if (DBG & 256) { ++dbg_c[0]; if ((hit[0] | hit[1] | hit[2] | hit[3]) != 0ull) ++dbg_c[1]; }
+#endif
+                if (DBG & 64) { if ((hit[0] | hit[1] | hit[2] | hit[3]) != 0ull) top[0].i[0] += 1; }
+                else if (__builtin_expect((hit[0] | hit[1] | hit[2] | hit[3]) != 0ull, 0)) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const float a = acc[mt][nt][j];
-                        if (DBG & 1) { if (j == 0) top[nt].v[0] += a; }
-                        else if (__builtin_expect(__any(a > thr[nt]), 0)) {
-                            if (a > thr[nt]) top[nt].push(-a, row0 + mt * 16 + j);
-                            thr[nt] = fmaxf(thr[nt], -top[nt].v[T]);
+                        if (hit[nt] == 0ull) continue;
+#ifdef ISM_KNN_DBG_VARIANTS
+                        if (DBG & 256) ++dbg_c[2];
+#endif
+                        // Every step ends in a workgroup barrier, so a tile's epilogue costs what it costs the SLOWEST of the eight
+                        // waves: keep the walk of a flagged column short. The largest of each 4-row group (two instructions per
+                        // group), eight compares into eight SGPR pairs, eight scalar tests; only a group that holds a score above
+                        // the threshold has its four scores compared and inserted (the empty asm keeps the compiler from sinking
+                        // every compare next to its branch again). A score is re-tested against the threshold as it stands when
+                        // its turn comes; the insertion itself is branch-free.
+                        float gm[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(gm[mt]) : "v"(acc[mt][nt][0]), "v"(acc[mt][nt][1]), "v"(acc[mt][nt][2]));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(gm[mt]) : "v"(gm[mt]), "v"(acc[mt][nt][3]));
+                        }
+                        unsigned long long gk[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) gk[mt] = __ballot(gm[mt] > thr[nt]);
+                        asm volatile("" :: "s"(gk[0]), "s"(gk[1]), "s"(gk[2]), "s"(gk[3]), "s"(gk[4]), "s"(gk[5]), "s"(gk[6]), "s"(gk[7]));
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if (gk[mt] == 0ull) continue;
+#ifdef ISM_KNN_DBG_VARIANTS
+                            if (DBG & 256) ++dbg_c[3];
+#endif
+                            unsigned long long mk[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) mk[j] = __ballot(acc[mt][nt][j] > thr[nt]);
+                            asm volatile("" :: "s"(mk[0]), "s"(mk[1]), "s"(mk[2]), "s"(mk[3]));
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (mk[j] == 0ull) continue;
+#ifdef ISM_KNN_DBG_VARIANTS
+                                if (DBG & 256) { ++dbg_c[4]; dbg_c[5] += __popcll(mk[j]); if (lane == 0 && t < 248) atomicAdd(&g_knn_dbg[8 + t], 1ull); }
+#endif
+                                const float a = acc[mt][nt][j];
+                                top[nt].push_flat(a > thr[nt] ? -a : __builtin_inff(), row0 + mt * 16 + j);
+                                asm("v_max_f32_e64 %0, %1, -%2" : "=v"(thr[nt]) : "v"(thr[nt]), "v"(top[nt].v[T]));
+                            }
                         }
                     }
+                }
+            }
             // thresholds shared by the 8 lane slots of a query column: the four row groups of this wave (lanes fr, fr+16, fr+32,
-            // fr+48), then the partner wave row through LDS (see k_knn_l2_ring)
+            // fr+48) by two register swaps (v_permlane32_swap / v_permlane16_swap: no LDS round trip), then the partner wave row
+            // through LDS (see k_knn_l2_ring)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float sh = fmaxf(thr[nt], __shfl_xor(thr[nt], 16, 64));
-                sh = fmaxf(sh, __shfl_xor(sh, 32, 64));
+                if (DBG & 64) asm volatile("" : "+v"(thr[nt]));
+                const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(thr[nt]), __float_as_uint(thr[nt]), false, false);
+                float sh;
+                asm("v_max_f32 %0, %1, %2" : "=v"(sh) : "v"(__uint_as_float(h[0])), "v"(__uint_as_float(h[1])));
+                const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(sh), __float_as_uint(sh), false, false);
+                asm("v_max_f32 %0, %1, %2" : "=v"(sh) : "v"(__uint_as_float(q[0])), "v"(__uint_as_float(q[1])));
                 sThr[(wv * NT + nt) * 64 + lane] = sh;
-                thr[nt] = fmaxf(sh, sThr[(pw * NT + nt) * 64 + lane]);
+                const float other = sThr[(pw * NT + nt) * 64 + lane];
+                asm("v_max_f32 %0, %1, %2" : "=v"(thr[nt]) : "v"(sh), "v"(other));
             }
             kc = 0; ++t;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ISM_KNN_DBG_VARIANTS
+    if ((DBG & 256) && lane == 0) for (int c = 0; c < 6; ++c) atomicAdd(&g_knn_dbg[c], (unsigned long long)dbg_c[c]);
+#endif
     // candidates: slot = split*(8*T) + (wr*4 + fq)*T + t; bound slot = split*8 + wr*4 + fq
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1438,6 +1535,13 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 wh = cb->words_f16t;
                 const void* rk = ring16 ? (const void*)k_knn_l2_ring16<T, 0> : (const void*)k_knn_l2_ring<T, 0>;
 #ifdef ISM_KNN_DBG_VARIANTS
+                if (ring16) switch (ctx->knn_dbg) {       // 1 no epilogue, 2 no MFMA, 4 no DMA, 16 no fragment reads, 32 no barrier, 64 pre-test only, 256 counters
+                    case 1: rk = (const void*)k_knn_l2_ring16<T, 1>; break;  case 2: rk = (const void*)k_knn_l2_ring16<T, 2>; break;
+                    case 5: rk = (const void*)k_knn_l2_ring16<T, 5>; break;  case 21: rk = (const void*)k_knn_l2_ring16<T, 21>; break;
+                    case 53: rk = (const void*)k_knn_l2_ring16<T, 53>; break; case 64: rk = (const void*)k_knn_l2_ring16<T, 64>; break;
+                    case 256: rk = (const void*)k_knn_l2_ring16<T, 256>; break;
+                    default: break;
+                } else
                 switch (ctx->knn_dbg) {
                     case 1: rk = (const void*)k_knn_l2_ring<T, 1>; break;  case 3: rk = (const void*)k_knn_l2_ring<T, 3>; break;
                     case 5: rk = (const void*)k_knn_l2_ring<T, 5>; break;  case 7: rk = (const void*)k_knn_l2_ring<T, 7>; break;
@@ -1600,6 +1704,13 @@ int ism_codebook_split_bf16(ismhip_ctx* ctx, ismhip_codebook* cb, uint32_t absma
     return ISMHIP_OK;
 }
 
+#ifdef ISM_KNN_DBG_VARIANTS
+extern "C" int ismhip_debug_knn_counters(unsigned long long* out256, int reset) {
+    if (out256 && hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_knn_dbg), 2048) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[256]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg), z, 2048) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 extern "C" {
 
 int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q, int k,

@@ -53,6 +53,16 @@ for v in args.variants:
     print(f"[{v or 'default'}] wall {wall:.2f} ms/{args.objects} obj | " + " ".join(f"{n} {tm[n][0] / max(1, tm[n][1]):.3f}" for n in names) +
           f" | stage-2 queries {int(ctx.timer('knn_stage2_queries')[0])} fallback queries {fb} | same result {same}", flush=True)
     ctx.timers_enable(False)
+    L = capi.lib()
+    if hasattr(L, "ismhip_debug_knn_counters"):                  # library built with -DISM_KNN_DBG_VARIANTS
+        import ctypes
+        c = (ctypes.c_ulonglong * 256)()
+        L.ismhip_debug_knn_counters(c, 1)
+        if c[0]:
+            h = [c[8 + t] for t in range(248)]
+            tot = max(1, sum(h))
+            print("    flagged scores by tile index (share of all): " + " ".join(f"{t}:{sum(h[t:t2]) / tot:.3f}" for t, t2 in [(0, 1), (1, 2), (2, 4), (4, 8), (8, 16), (16, 32), (32, 64), (64, 128), (128, 248)]), flush=True)
+            print(f"    per wave-tile: any-hit {c[1] / c[0]:.3f}, flagged columns {c[2] / c[0]:.3f}, flagged groups {c[3] / c[0]:.3f}, flagged scores {c[4] / c[0]:.3f}, inserting lanes {c[5] / c[0]:.3f} (wave-tiles {c[0]})", flush=True)
     rec.codebook.close(); ctx.close()
     for k in keys:
         del os.environ[k]
