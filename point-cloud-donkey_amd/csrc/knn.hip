@@ -781,7 +781,10 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
         if (wv == 0 && pkc == 0) lds_dma16(word_norm + (size_t)(mt0 + pt) * BM + lane * 4, sCn + (pt & 3) * BM);
         const char* sp = dbase + pt * tile_stride + (size_t)pkc * (BM * KB * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_dma16(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);
+        for (int j = 0; j < 4; ++j) {
+            if (((DBG & 128) && dma_a) || ((DBG & 1024) && !dma_a)) lds_dma16_nt(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);   // timing / traffic experiments
+            else lds_dma16(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);
+        }
         ++pg;
         if (pt * nk + pkc + 1 < G) { if (++pkc == nk) { pkc = 0; ++pt; } }
     };
@@ -1540,6 +1543,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     case 5: rk = (const void*)k_knn_l2_ring16<T, 5>; break;  case 21: rk = (const void*)k_knn_l2_ring16<T, 21>; break;
                     case 53: rk = (const void*)k_knn_l2_ring16<T, 53>; break; case 64: rk = (const void*)k_knn_l2_ring16<T, 64>; break;
                     case 256: rk = (const void*)k_knn_l2_ring16<T, 256>; break;
+                    case 128: rk = (const void*)k_knn_l2_ring16<T, 128>; break; case 1024: rk = (const void*)k_knn_l2_ring16<T, 1024>; break;
                     default: break;
                 } else
                 switch (ctx->knn_dbg) {
