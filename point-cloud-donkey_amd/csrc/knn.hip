@@ -742,17 +742,22 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring(const u16* __restrict__ 
 // [8 + t] flagged scores of tile index t (t < 248) summed over waves
 __device__ unsigned long long g_knn_dbg[256];
 #endif
-template <int T, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict__ wh, const float* __restrict__ word_norm, int n_tiles_m, int ld, int k_steps,
+// WR = 2: the 256 x 256 tile, 8 waves (2 x 4), one workgroup per CU, four ring stages (three slices in flight).
+// WR = 1 (ISMHIP_KNN_HALF=1): a 128 x 256 tile, 4 waves, 76 KB of LDS: TWO independent workgroups per CU, three stages (two in
+// flight). The eight waves of the big workgroup meet at a barrier every slice, so their DMA issue and their epilogues coincide
+// and the matrix pipes idle meanwhile; two small workgroups drift apart and fill each other's gaps, at 1.5x the DMA per flop.
+template <int T, int WR = 2, int DBG = 0>
+__global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __restrict__ wh, const float* __restrict__ word_norm, int n_tiles_m, int ld, int k_steps,
                                                           const u16* __restrict__ qh, int nq, const float* __restrict__ out_scale,
                                                           int tiles_per_split, int n_splits,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
                                                           float* __restrict__ cand_bound, int bound_stride) {
-    constexpr int WC = 4, MT = 8, NT = 4, KB = RG_KB, BM = RG_BM, BN = RG_BN;
+    constexpr int WC = 4, MT = 8, NT = 4, KB = RG_KB, BM = WR * 128, BN = RG_BN;
+    constexpr int STAGES = WR == 2 ? 4 : 3, STAGE_HALVES = (BM + BN) * KB, CNS = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
-    u16* ring = (u16*)knn_smem;                                        // [RG_STAGES][512 rows][32 halves]
-    float* sCn = (float*)(ring + RG_STAGES * RG_STAGE_HALVES);        // [4][BM]
-    float* sThr = sCn + 4 * BM;                                        // [8 waves][NT][64]
+    u16* ring = (u16*)knn_smem;                                        // [STAGES][BM + BN rows][32 halves]
+    float* sCn = (float*)(ring + STAGES * STAGE_HALVES);              // [4][CNS]: |c|^2 of four tiles (a DMA always delivers 256 floats)
+    float* sThr = sCn + 4 * CNS;                                       // [8 waves][NT][64] (WR = 2 only)
     const float oscale = out_scale[0];
 
     const int tid = threadIdx.x;
@@ -769,26 +774,40 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
     const int nk = (k_steps + 1) / 2;
     const int G = n_t * nk;
 
-    const bool dma_a = wv < 4;
+    // DMA shares per slice (pieces of 16 rows x 64 B = 1 KB per wave instruction). WR = 2: waves 0-3 bring 64 codeword rows each,
+    // waves 4-7 64 query rows each; WR = 1: every wave brings 32 codeword rows and 64 query rows. Both images are stored in
+    // 256-row tiles [tile][slice][row][64 B]; a 128-row codeword tile is one half of such a block.
+    constexpr int NA = WR == 2 ? 4 : 2, NB = 4;
+    const bool dma_a = WR == 1 || wv < 4, dma_b = WR == 1 || wv >= 4;
     const unsigned lane_off = (unsigned)(lane * 16);
-    const char* dbase = (dma_a ? (const char*)(wh + (size_t)mt0 * nk * (BM * KB)) : (const char*)(qh + (size_t)qtile * nk * (BN * KB)))
-                        + (wv & 3) * (64 * KB * 2);
-    const int ddst = (dma_a ? 0 : BM * KB) + (wv & 3) * 64 * KB;
-    const size_t tile_stride = dma_a ? (size_t)nk * (BM * KB * 2) : 0;
-    int pt = 0, pkc = 0, pg = 0;
+    const int row_a = WR == 2 ? (wv & 3) * 64 : wv * 32, row_b = (wv & 3) * 64;
+    const char* qbase = (const char*)(qh + (size_t)qtile * nk * (BN * KB)) + row_b * (KB * 2);
+    int pt = 0, pkc = 0, ps = 0;
     auto issue = [&]() {
-        u16* st = ring + (pg & (RG_STAGES - 1)) * RG_STAGE_HALVES + ddst;
-        if (wv == 0 && pkc == 0) lds_dma16(word_norm + (size_t)(mt0 + pt) * BM + lane * 4, sCn + (pt & 3) * BM);
-        const char* sp = dbase + pt * tile_stride + (size_t)pkc * (BM * KB * 2);
+        u16* st = ring + ps * STAGE_HALVES;
+        if (wv == 0 && pkc == 0) lds_dma16(word_norm + (size_t)(mt0 + pt) * BM + lane * 4, sCn + (pt & 3) * CNS);
+        if (dma_a) {
+            const int tt = mt0 + pt;
+            const char* sp = (const char*)wh + ((size_t)(WR == 2 ? tt : (tt >> 1)) * nk + pkc) * (256 * KB * 2) + ((WR == 2 ? 0 : (tt & 1) * 128) + row_a) * (KB * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (((DBG & 128) && dma_a) || ((DBG & 1024) && !dma_a)) lds_dma16_nt(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);   // timing / traffic experiments
-            else lds_dma16(sp + j * (16 * KB * 2) + lane_off, st + j * 16 * KB);
+            for (int j = 0; j < NA; ++j) {
+                if (DBG & 128) lds_dma16_nt(sp + j * (16 * KB * 2) + lane_off, st + (row_a + j * 16) * KB);   // timing / traffic experiments
+                else lds_dma16(sp + j * (16 * KB * 2) + lane_off, st + (row_a + j * 16) * KB);
+            }
         }
-        ++pg;
+        if (dma_b) {
+            const char* sp = qbase + (size_t)pkc * (BN * KB * 2);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (DBG & 1024) lds_dma16_nt(sp + j * (16 * KB * 2) + lane_off, st + BM * KB + (row_b + j * 16) * KB);
+                else lds_dma16(sp + j * (16 * KB * 2) + lane_off, st + BM * KB + (row_b + j * 16) * KB);
+            }
+        }
+        if (++ps == STAGES) ps = 0;
         if (pt * nk + pkc + 1 < G) { if (++pkc == nk) { pkc = 0; ++pt; } }
     };
-    issue(); issue(); issue(); issue();
+#pragma unroll
+    for (int i = 0; i < STAGES; ++i) issue();
 
     // fragment address of this lane inside a 16-row tile: row fr, physical segment fq ^ F[(fr >> 2) & 3]
     const int fso = (fr * KB) + ((fq ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 3);
@@ -802,8 +821,10 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
     unsigned dbg_c[6] = {0, 0, 0, 0, 0, 0};
 #endif
     const int pw = (1 - wr) * WC + wc;
+    if (WR == 2) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) sThr[(wv * NT + n) * 64 + lane] = -__builtin_inff();
+        for (int n = 0; n < NT; ++n) sThr[(wv * NT + n) * 64 + lane] = -__builtin_inff();
+    }
 
     // pipeline as in k_knn_l2_ring, with the fragments split by codeword rows instead of k-steps: X = tiles 0-3 (read during the
     // previous step), Y = tiles 4-7 and the four query fragments (read at the top of the step)
@@ -811,10 +832,12 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
     asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int m = 0; m < 4; ++m) xa[m] = *(const f16x8*)(ring + fragA + m * 16 * KB);
-    int t = 0, kc = 0;
+    int t = 0, kc = 0, gs = 0;
     for (int g = 0; g < G; ++g) {
-        const u16* st = ring + (g & (RG_STAGES - 1)) * RG_STAGE_HALVES;
-        const u16* sn = ring + ((g + 1) & (RG_STAGES - 1)) * RG_STAGE_HALVES;
+        const int gn = gs + 1 == STAGES ? 0 : gs + 1;
+        const u16* st = ring + gs * STAGE_HALVES;
+        const u16* sn = ring + gn * STAGE_HALVES;
+        gs = gn;
         if (!(DBG & 16) || g == 0) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) bq[n] = *(const f16x8*)(st + fragB + n * 16 * KB);
@@ -824,7 +847,7 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
         // first slice of a tile: the accumulators START from the tile's pre-scaled |c|^2 row (rows 16 mt + 4 fq + j), passed as
         // the C operand of the tile's first MFMAs. The fragment reads of the other half-step are issued one per four MFMAs, so
         // the first MFMAs wait only for the query fragments and the reads ride inside the MFMA stream.
-        const float* cnp = sCn + (t & 3) * BM + wr * (MT * 16) + 4 * fq;
+        const float* cnp = sCn + (t & 3) * CNS + wr * (MT * 16) + 4 * fq;
         auto mma4 = [&](int mb, const f16x8* af, f16x8* nxt, const u16* nsrc) {
             if (kc == 0) {
 #pragma unroll
@@ -847,7 +870,7 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
         };
         mma4(0, xa, ya, st + fragA + 4 * 16 * KB);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(DBG & 32)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!(DBG & 32)) { if (WR == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
         if (!(DBG & 4) || g < 4) issue();
         __builtin_amdgcn_sched_barrier(0);
         mma4(4, ya, xa, sn + fragA);
@@ -943,9 +966,11 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
                 asm("v_max_f32 %0, %1, %2" : "=v"(sh) : "v"(__uint_as_float(h[0])), "v"(__uint_as_float(h[1])));
                 const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(sh), __float_as_uint(sh), false, false);
                 asm("v_max_f32 %0, %1, %2" : "=v"(sh) : "v"(__uint_as_float(q[0])), "v"(__uint_as_float(q[1])));
-                sThr[(wv * NT + nt) * 64 + lane] = sh;
-                const float other = sThr[(pw * NT + nt) * 64 + lane];
-                asm("v_max_f32 %0, %1, %2" : "=v"(thr[nt]) : "v"(sh), "v"(other));
+                if (WR == 2) {
+                    sThr[(wv * NT + nt) * 64 + lane] = sh;
+                    const float other = sThr[(pw * NT + nt) * 64 + lane];
+                    asm("v_max_f32 %0, %1, %2" : "=v"(thr[nt]) : "v"(sh), "v"(other));
+                } else thr[nt] = sh;
             }
             kc = 0; ++t;
         }
@@ -954,17 +979,17 @@ __global__ __launch_bounds__(512, 2) void k_knn_l2_ring16(const u16* __restrict_
 #ifdef ISM_KNN_DBG_VARIANTS
     if ((DBG & 256) && lane == 0) for (int c = 0; c < 6; ++c) atomicAdd(&g_knn_dbg[c], (unsigned long long)dbg_c[c]);
 #endif
-    // candidates: slot = split*(8*T) + (wr*4 + fq)*T + t; bound slot = split*8 + wr*4 + fq
+    // candidates: slot = split*(WR*4*T) + (wr*4 + fq)*T + t; bound slot = split*WR*4 + wr*4 + fq
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int qi = qtile * BN + wc * (NT * 16) + nt * 16 + fr;
         if (qi < nq) {
 #pragma unroll
             for (int tt = 0; tt < T; ++tt) {
-                const size_t o = (size_t)qi * cand_stride + split * (8 * T) + (wr * 4 + fq) * T + tt;
+                const size_t o = (size_t)qi * cand_stride + split * (WR * 4 * T) + (wr * 4 + fq) * T + tt;
                 cand_val[o] = -oscale * top[nt].v[tt]; cand_idx[o] = top[nt].i[tt];
             }
-            cand_bound[(size_t)qi * bound_stride + split * 8 + (wr * 4 + fq)] = oscale * thr[nt];
+            cand_bound[(size_t)qi * bound_stride + split * (WR * 4) + (wr * 4 + fq)] = oscale * thr[nt];
         }
     }
 }
@@ -1280,7 +1305,8 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
     const bool l2 = metric != ISMHIP_METRIC_CHI2;
     const bool lay_all = l2 && wr_rows == -2;                     // merged splits (k_knn_merge_splits): the one slot owns every row
     const bool lay16 = l2 && wr_rows == -1;                       // k_knn_l2_ring16: slot b = split*8 + wr*4 + fq owns rows wr*128 + 16 m + 4 fq + j
-    const int rows_per_tile = lay_all ? tile_rows : (lay16 ? 32 : (l2 ? wr_rows / 2 : tile_rows));   // else a lane slot sees half of its wave-row block (bit 2 of the row == h)
+    const bool lay16h = l2 && wr_rows == -3;                      // k_knn_l2_ring16<T, 1>: 128-row tiles, slot b = split*4 + fq owns rows 16 m + 4 fq + j
+    const int rows_per_tile = lay_all ? tile_rows : ((lay16 || lay16h) ? 32 : (l2 ? wr_rows / 2 : tile_rows));   // else a lane slot sees half of its wave-row block (bit 2 of the row == h)
     const int nj = dim_pad / 16;
     const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     // With few items a wave per item would leave the chip idle behind a handful of long scans: every item is cut into P row
@@ -1292,7 +1318,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
         const int qi = (int)items[2 * (size_t)it], b = (int)items[2 * (size_t)it + 1];
         const float* qp = q + (size_t)qi * ldq;
         const int split = lay_all ? 0 : (lay16 ? (b >> 3) : (l2 ? (b >> 2) : b));
-        const int wr = lay16 ? (b >> 2) & 1 : (b >> 1) & 1, h = b & 1, fq = b & 3;
+        const int wr = lay16h ? 0 : (lay16 ? (b >> 2) & 1 : (b >> 1) & 1), h = b & 1, fq = b & 3;
         const int mt0 = split * tiles_per_split, mt1 = min(n_tiles, mt0 + tiles_per_split);
         const int total = (mt1 - mt0) * rows_per_tile;
         unsigned long long best[KM];
@@ -1310,7 +1336,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const float* __restrict__ 
             int r = n_words;                                  // out of range = idle group
             if (e < e_end) {
                 const int tile = mt0 + e / rows_per_tile, y = e % rows_per_tile;
-                const int x = lay_all ? y : (lay16 ? (wr * 128 + ((y >> 2) << 4) + (fq << 2) + (y & 3)) : (l2 ? (wr * wr_rows + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y));
+                const int x = lay_all ? y : ((lay16 || lay16h) ? (wr * 128 + ((y >> 2) << 4) + (fq << 2) + (y & 3)) : (l2 ? (wr * wr_rows + (((y >> 2) << 3) | (h << 2) | (y & 3))) : y));
                 r = tile * tile_rows + x;
             }
             float part = 0.f;
@@ -1452,12 +1478,14 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     const int mode = metric != ISMHIP_METRIC_L2SQ ? -1 : (short_dim ? 2 : (ctx->knn_mode == 0 && cb->words_f16 ? 0 : (ctx->knn_mode <= 1 && cb->words_bf16_hi ? 1 : 2)));
     const bool use_lp = mode == 0 || mode == 1;
     const bool big_tile = use_lp && nq >= 4096 && cb->n_words_pad >= 4096 && !ctx->knn_small_tile;      // 256x256 tile, 8 waves
-    const int BM = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BM) : CHI_B;
+    const int BM0 = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BM) : CHI_B;
     const int BNq = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BN) : CHI_B;
     const int wr_rows = big_tile ? 128 : 64;
     const bool use_ring = big_tile && mode == 0 && !ctx->knn_no_ring && cb->words_f16t;
     const bool ring16 = use_ring && !ctx->knn_ring32;                  // 16x16x32 MFMA shape: 8 lane slots per query and split instead of 4
-    const int slots = ring16 ? 8 : 4;
+    const bool half = ring16 && ctx->knn_half;                         // 128 x 256 tile, two workgroups per CU (k_knn_l2_ring16<T, 1>)
+    const int BM = half ? 128 : BM0;
+    const int slots = ring16 && !half ? 8 : 4;
     const int ring_nk = ((cb->dim + 15) / 16 + 1) / 2;                 // 32-k slices per row in the tiled images
     const bool merged = many_splits && metric == ISMHIP_METRIC_L2SQ && use_lp && !big_tile;
     if (metric == ISMHIP_METRIC_L2SQ) {
@@ -1536,14 +1564,14 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
             }
             if (use_ring) {
                 wh = cb->words_f16t;
-                const void* rk = ring16 ? (const void*)k_knn_l2_ring16<T, 0> : (const void*)k_knn_l2_ring<T, 0>;
+                const void* rk = ring16 ? (half ? (const void*)k_knn_l2_ring16<T, 1, 0> : (const void*)k_knn_l2_ring16<T, 2, 0>) : (const void*)k_knn_l2_ring<T, 0>;
 #ifdef ISM_KNN_DBG_VARIANTS
                 if (ring16) switch (ctx->knn_dbg) {       // 1 no epilogue, 2 no MFMA, 4 no DMA, 16 no fragment reads, 32 no barrier, 64 pre-test only, 256 counters
-                    case 1: rk = (const void*)k_knn_l2_ring16<T, 1>; break;  case 2: rk = (const void*)k_knn_l2_ring16<T, 2>; break;
-                    case 5: rk = (const void*)k_knn_l2_ring16<T, 5>; break;  case 21: rk = (const void*)k_knn_l2_ring16<T, 21>; break;
-                    case 53: rk = (const void*)k_knn_l2_ring16<T, 53>; break; case 64: rk = (const void*)k_knn_l2_ring16<T, 64>; break;
-                    case 256: rk = (const void*)k_knn_l2_ring16<T, 256>; break;
-                    case 128: rk = (const void*)k_knn_l2_ring16<T, 128>; break; case 1024: rk = (const void*)k_knn_l2_ring16<T, 1024>; break;
+                    case 1: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 1> : (const void*)k_knn_l2_ring16<T, 2, 1>; break;  case 2: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 2> : (const void*)k_knn_l2_ring16<T, 2, 2>; break;
+                    case 5: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 5> : (const void*)k_knn_l2_ring16<T, 2, 5>; break;  case 21: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 21> : (const void*)k_knn_l2_ring16<T, 2, 21>; break;
+                    case 53: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 53> : (const void*)k_knn_l2_ring16<T, 2, 53>; break; case 64: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 64> : (const void*)k_knn_l2_ring16<T, 2, 64>; break;
+                    case 256: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 256> : (const void*)k_knn_l2_ring16<T, 2, 256>; break;
+                    case 128: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 128> : (const void*)k_knn_l2_ring16<T, 2, 128>; break; case 1024: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 1024> : (const void*)k_knn_l2_ring16<T, 2, 1024>; break;
                     default: break;
                 } else
                 switch (ctx->knn_dbg) {
@@ -1555,13 +1583,14 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     default: break;
                 }
 #endif
-                const size_t rlds = (size_t)RG_STAGES * RG_STAGE_HALVES * sizeof(u16) + 4 * RG_BM * sizeof(float) + 8 * 4 * 64 * sizeof(float);
+                const size_t rlds = half ? (size_t)3 * (128 + 256) * RG_KB * sizeof(u16) + 4 * 256 * sizeof(float)
+                                         : (size_t)RG_STAGES * RG_STAGE_HALVES * sizeof(u16) + 4 * RG_BM * sizeof(float) + 8 * 4 * 64 * sizeof(float);
                 if (ctx->knn_dbg || !ctx->attr_done.count(rk)) {          // per device, so remembered per ctx
                     ISM_HIP(ctx, hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
                     ctx->attr_done.insert(rk);
                 }
                 const float* osc = (const float*)(qsc + 1);
-                float* cn_scaled = (float*)ism_scratch(ctx, SCR_QNORM2, (size_t)cb->n_words_pad * sizeof(float));
+                float* cn_scaled = (float*)ism_scratch(ctx, SCR_QNORM2, ((size_t)cb->n_words_pad + 256) * sizeof(float));   // the |c|^2 DMA of a 128-row tile reads 256 floats
                 if (!cn_scaled) return ISMHIP_ERR_NOMEM;
                 hipLaunchKernelGGL(k_scale_norms, dim3((cb->n_words_pad + 255) / 256), dim3(256), 0, ctx->stream, cb->word_norm, cb->n_words_pad, osc, cn_scaled);
                 ISM_CHECK_LAUNCH(ctx, "k_scale_norms");
@@ -1569,7 +1598,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
                 const u16* qh_ = q_hi;
                 void* rargs[] = {&wh, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb};
-                ISM_HIP(ctx, hipLaunchKernel(rk, grid, dim3(512), rargs, rlds, ctx->stream));
+                ISM_HIP(ctx, hipLaunchKernel(rk, grid, dim3(half ? 256 : 512), rargs, rlds, ctx->stream));
                 ISM_CHECK_LAUNCH(ctx, "k_knn_l2_ring");
             } else {
             (void)ai;
@@ -1617,7 +1646,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     if (stage1) { stage1->flag_count = flag_count; stage1->qrec = qrec; return ISMHIP_OK; }
     {
         TimerScope ts(ctx, "knn_fallback");
-        const int fb_tps = merged ? cb->n_words_pad / BM : tiles_per_split, fb_lay = merged ? -2 : (ring16 ? -1 : wr_rows);
+        const int fb_tps = merged ? cb->n_words_pad / BM : tiles_per_split, fb_lay = merged ? -2 : (half ? -3 : (ring16 ? -1 : wr_rows));
         if (k <= 4) hipLaunchKernelGGL(k_knn_fallback<4>, dim3(1024), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words, qq, ldq, metric, k,
                                        fb_tps, cb->n_words_pad / BM, BM, fb_lay, flag_count, items, idx_out, dist_out, item_out, q_items);
         else hipLaunchKernelGGL(k_knn_fallback<KNN_MAX_K>, dim3(1024), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words, qq, ldq, metric, k,
