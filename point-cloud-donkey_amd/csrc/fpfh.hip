@@ -83,6 +83,7 @@ __device__ __forceinline__ int clamp_bin(int h) { return h < 0 ? 0 : (h > 10 ? 1
 
 __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
     __shared__ unsigned int s_hist[4][36];
+    __shared__ WaveRows s_rows[4];
     const int o = blockIdx.y;
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const uint32_t base = a.pt_off[o];
@@ -101,29 +102,26 @@ __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
     const uint32_t* cs = a.cell_start + (size_t)o * ISM_GRID_STRIDE;
     const float d_pi = 1.0f / (2.0f * 3.14159265358979323846f);
     uint32_t total = 0;
-    for (int gz = cr.lo[2]; gz <= cr.hi[2]; ++gz)
-        for (int gy = cr.lo[1]; gy <= cr.hi[1]; ++gy) {
-            int xl, xh;
-            if (!row_cells(m, cr, gy, gz, px, py, pz, a.radius, xl, xh)) continue;
-            const int rb = (gz * m.dim[1] + gy) * m.dim[0];
-            const uint32_t s = cs[rb + xl], e = cs[rb + xh + 1];
-            for (uint32_t t = s + lane; t < e; t += 64) {
-                const float4 qq = a.sp4[base + t];
-                const float qx = qq.x, qy = qq.y, qz = qq.z;
-                const float d2 = sqdist3(qx, qy, qz, px, py, pz);
-                if (!(d2 < a.r2)) continue;
-                total++;
-                if (t == p) continue;
-                float f1, f2, f3;
-                const float4 qn = a.sn4[base + t];
-                if (!pair_features(px, py, pz, pnx, pny, pnz, qx, qy, qz, qn.x, qn.y, qn.z, f1, f2, f3)) continue;
-                // the three bin formulas are evaluated in double as in PCL (float operands, double constants)
-                const int h1 = clamp_bin((int)floor(11 * (((double)f1 + 3.14159265358979323846) * (double)d_pi)));
-                const int h2 = clamp_bin((int)floor(11 * (((double)f2 + 1.0) * 0.5)));
-                const int h3 = clamp_bin((int)floor(11 * (((double)f3 + 1.0) * 0.5)));
-                atomicAdd(&hist[h1], 1u); atomicAdd(&hist[11 + h2], 1u); atomicAdd(&hist[22 + h3], 1u);
-            }
-        }
+    // flattened ball traversal (common.h): the candidate rows laid end to end, every lane busy; the pair features are ~170
+    // instructions per neighbour, so a half-empty wave per cell row was most of this kernel's time
+    ball_for_each(m, cs, cr, px, py, pz, a.radius, lane, s_rows[wv],
+                  [&](uint32_t t, bool v) { return v ? a.sp4[base + t] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                  [&](const float4& qq, uint32_t t, bool v) {
+        if (!v) return;
+        const float qx = qq.x, qy = qq.y, qz = qq.z;
+        const float d2 = sqdist3(qx, qy, qz, px, py, pz);
+        if (!(d2 < a.r2)) return;
+        total++;
+        if (t == p) return;
+        float f1, f2, f3;
+        const float4 qn = a.sn4[base + t];
+        if (!pair_features(px, py, pz, pnx, pny, pnz, qx, qy, qz, qn.x, qn.y, qn.z, f1, f2, f3)) return;
+        // the three bin formulas are evaluated in double as in PCL (float operands, double constants)
+        const int h1 = clamp_bin((int)floor(11 * (((double)f1 + 3.14159265358979323846) * (double)d_pi)));
+        const int h2 = clamp_bin((int)floor(11 * (((double)f2 + 1.0) * 0.5)));
+        const int h3 = clamp_bin((int)floor(11 * (((double)f3 + 1.0) * 0.5)));
+        atomicAdd(&hist[h1], 1u); atomicAdd(&hist[11 + h2], 1u); atomicAdd(&hist[22 + h3], 1u);
+    });
     total = (uint32_t)wave_sum_i((int)total);
     const float hist_incr = 100.0f / (float)(total - 1u);
     // a bin that received nothing stays 0 even when hist_incr = 100/0 (point alone in its ball), as in the reference's += loop
