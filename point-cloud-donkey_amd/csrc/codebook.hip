@@ -152,7 +152,13 @@ int ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* w
     }
     {
         uint32_t amax = 0u;                                       // largest |element| as float bits (NaN/inf sort last)
-        for (size_t i = 0; i < (size_t)n_words * dim; ++i) { uint32_t b; memcpy(&b, &words_h[i], 4); b &= 0x7fffffffu; amax = b > amax ? b : amax; }
+        bool nonneg = true;                                       // histograms: every element >= 0 (NaN counts as not)
+        for (size_t i = 0; i < (size_t)n_words * dim; ++i) {
+            uint32_t b; memcpy(&b, &words_h[i], 4);
+            if (!(words_h[i] >= 0.f)) nonneg = false;
+            b &= 0x7fffffffu; amax = b > amax ? b : amax;
+        }
+        cb->words_nonneg = nonneg;
         int rc = ism_codebook_split_bf16(ctx, cb, amax);
         if (rc != ISMHIP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(rc != ISMHIP_OK ? rc : ISMHIP_ERR_HIP, "codebook_create: bf16 split");
     }

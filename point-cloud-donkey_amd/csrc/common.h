@@ -63,6 +63,7 @@ struct ismhip_codebook {
     unsigned short* words_f16t = nullptr;      // the f16 image in k_knn_l2_ring's streaming layout (k_to_f16_tiled), own allocation
     int ld16 = 0;                    // row stride (halves) of the 16-bit images: dim rounded up to 64, zero padded
     float f16_scale = 1.f;           // power of two: largest |element| * f16_scale in [2^13, 2^14)
+    bool words_nonneg = false;       // no negative (or NaN) element: k_knn_chi2 may drop the functor's "sum > 0" test (see there)
     float max_norm2 = 0.f;           // max squared norm over the real rows (bounds the fp32 contraction error of kNN)
     float* word_weight = nullptr;    // [n_words]
     uint32_t* vote_off = nullptr;    // [n_words+1]

@@ -302,6 +302,34 @@ def test_knn_more_than_four_neighbours(pkg, gpu, ora, metric, shape, k):
         assert (widx[:, n_words:] == -1).all()
 
 
+@pytest.mark.parametrize("case", ["histograms", "negative_words", "negative_queries", "nan_query"])
+def test_knn_chi2_sum_test_paths(pkg, gpu, ora, case):
+    """The chi-square functor skips terms whose sum is not positive (utils/distance.h:65, FLANN ChiSquareDistance). The candidate
+    kernel drops that test -- and uses the packed FP32 instructions -- only when neither the codebook nor the query batch holds a
+    negative or NaN element; sparse histograms (many 0 + 0 terms) take that path, any negative element the exact one. Both must
+    return the oracle's neighbours bit for bit, cancelling terms (c = -q) included."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(17)
+    words = rng.random((700, 96)).astype(np.float32)
+    words[rng.random(words.shape) < 0.6] = 0.0                       # sparse histograms: most sums are 0 + 0
+    q = (words[rng.integers(0, 700, 300)] + 0.05 * rng.random((300, 96)) * (rng.random((300, 96)) < 0.3)).astype(np.float32)
+    if case == "negative_words":
+        words[5, :10] = -words[5, :10] - 0.25
+        q[0, :10] = -words[5, :10]                                   # sums of exactly 0 with a non-zero difference: skipped by the functor
+    elif case == "negative_queries":
+        q[3, 7] = -0.5; q[4, :] = -q[4, :]
+    elif case == "nan_query":
+        q[9, 2] = np.nan
+    host, cb = _cb(pkg, gpu, words)
+    for k in (1, 3):
+        idx, dist = pkg.capi.knn(ctx, cb, 1, T(q, dev), k)
+        widx, wdist = ora.knn(1, words, q, k)
+        ok = ~np.isnan(wdist).any(1)                                 # a NaN query has no defined order
+        assert np.array_equal(idx.cpu().numpy()[ok], widx[ok])
+        assert np.array_equal(dist.cpu().numpy()[ok], wdist[ok])
+    assert ok.sum() >= 299
+
+
 def _knn_flagged(ctx):
     return int(ctx.timer("knn_flagged_queries")[0]), int(ctx.timer("knn_flagged_items")[0])
 
