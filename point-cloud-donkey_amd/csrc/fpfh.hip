@@ -167,8 +167,18 @@ __global__ __launch_bounds__(256) void k_fpfh_sum(FpfhArgs a) {
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int cnt = __popcll(umask);
-                if (lane < 33)
-                    for (int j = 0; j < cnt; ++j) acc += a.spfh[(size_t)s_qi[wv][j] * 33 + lane] * s_qw[wv][j];
+                if (lane < 33) {
+                    // eight independent 132-byte row gathers in flight, then the additions in the neighbours' order (unchanged sum)
+                    int j = 0;
+                    for (; j + 8 <= cnt; j += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = a.spfh[(size_t)s_qi[wv][j + u] * 33 + lane];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc += v[u] * s_qw[wv][j + u];
+                    }
+                    for (; j < cnt; ++j) acc += a.spfh[(size_t)s_qi[wv][j] * 33 + lane] * s_qw[wv][j];
+                }
                 __builtin_amdgcn_wave_barrier();
             }
         }

@@ -1804,7 +1804,8 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
     TimerScope ts(ctx, "knn");
     // T = candidates kept per slot. The bf16x3 candidate scores carry a larger error bound, so more are kept (T = 4): the proof
     // then compares against the 5th best of every slot and almost never fails.
-    const bool wide = k > 2 || (metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi && ctx->knn_mode <= 1);
+    // (short descriptors take the exact-f32 contraction, whose scores are as good as exact: two candidates per slot are plenty)
+    const bool wide = k > 2 || (metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi && ctx->knn_mode <= 1 && !(cb->dim <= 64 && ctx->knn_mode == 0));
     // default for big squared-L2 launches with k <= 2 (every shipped configuration): the two-stage search (see run_knn_two_stage)
     if (metric == ISMHIP_METRIC_L2SQ && k <= 2 && ctx->knn_t == 0 && ctx->knn_mode == 0 && ctx->knn_two_stage && cb->words_f16t && nq >= 4096 &&
         cb->n_words_pad >= 4096 && !ctx->knn_small_tile && !ctx->knn_no_ring && cb->dim > 64)
