@@ -105,6 +105,7 @@ struct ismhip_ctx {
     uint32_t knn_stage2_queries = 0;  // last two-stage ismhip_knn: queries the T = 2 stage could not prove (searched again with T = 4)
     bool knn_two_stage = true;   // env ISMHIP_KNN_TWOSTAGE=0: single-stage T = 4 search (A/B runs)
     bool knn_small_tile = false; // env ISMHIP_KNN_TILE128=1: keep the bf16x3 kernel on its 128x128 tile (A/B runs)
+    bool knn_qpanel = false;     // env ISMHIP_KNN_QPANEL=1: the ring kernel on 256 x 128 tiles with the query panel resident in LDS (A/B runs)
     bool knn_half = false;       // env ISMHIP_KNN_HALF=1: the ring kernel on 128 x 256 tiles, two workgroups per CU (A/B runs)
     bool knn_ring32 = false;     // env ISMHIP_KNN_RING32=1: the ring kernel on the 32x32x16 MFMA shape instead of 16x16x32 (A/B runs)
     int knn_splits = 0;          // env ISMHIP_KNN_SPLITS: force the number of codebook splits of the squared-L2 candidate kernels (A/B runs)

@@ -746,18 +746,22 @@ __device__ unsigned long long g_knn_dbg[256];
 // WR = 1 (ISMHIP_KNN_HALF=1): a 128 x 256 tile, 4 waves, 76 KB of LDS: TWO independent workgroups per CU, three stages (two in
 // flight). The eight waves of the big workgroup meet at a barrier every slice, so their DMA issue and their epilogues coincide
 // and the matrix pipes idle meanwhile; two small workgroups drift apart and fill each other's gaps, at 1.5x the DMA per flop.
-template <int T, int WR = 2, int DBG = 0>
+// QP = 1 (ISMHIP_KNN_QPANEL=1, WR = 2, descriptors of at most 352 elements): a 256 x 128 tile whose QUERY panel (128 queries x all
+// slices, 88 KB) is loaded into LDS once per workgroup; only the codeword tiles stream through the ring. The 256 x 256 kernel
+// re-reads its 180 KB query tile for every codeword tile, and that is what falls out of the XCD L2s.
+template <int T, int WR = 2, int DBG = 0, int QP = 0>
 __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __restrict__ wh, const float* __restrict__ word_norm, int n_tiles_m, int ld, int k_steps,
                                                           const u16* __restrict__ qh, int nq, const float* __restrict__ out_scale,
                                                           int tiles_per_split, int n_splits,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
                                                           float* __restrict__ cand_bound, int bound_stride) {
-    constexpr int WC = 4, MT = 8, NT = 4, KB = RG_KB, BM = WR * 128, BN = RG_BN;
-    constexpr int STAGES = WR == 2 ? 4 : 3, STAGE_HALVES = (BM + BN) * KB, CNS = 256;
+    constexpr int WC = 4, MT = 8, NT = QP ? 2 : 4, KB = RG_KB, BM = WR * 128, BN = QP ? 128 : RG_BN;
+    constexpr int STAGES = WR == 2 ? 4 : 3, STAGE_HALVES = (QP ? BM : BM + BN) * KB, CNS = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
-    u16* ring = (u16*)knn_smem;                                        // [STAGES][BM + BN rows][32 halves]
+    u16* ring = (u16*)knn_smem;                                        // [STAGES][BM + BN rows][32 halves] (QP: codeword rows only)
     float* sCn = (float*)(ring + STAGES * STAGE_HALVES);              // [4][CNS]: |c|^2 of four tiles (a DMA always delivers 256 floats)
     float* sThr = sCn + 4 * CNS;                                       // [8 waves][NT][64] (WR = 2 only)
+    u16* panel = (u16*)(sThr + 8 * NT * 64);                           // QP: [slices][128 queries][32 halves]
     const float oscale = out_scale[0];
 
     const int tid = threadIdx.x;
@@ -777,11 +781,15 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
     // DMA shares per slice (pieces of 16 rows x 64 B = 1 KB per wave instruction). WR = 2: waves 0-3 bring 64 codeword rows each,
     // waves 4-7 64 query rows each; WR = 1: every wave brings 32 codeword rows and 64 query rows. Both images are stored in
     // 256-row tiles [tile][slice][row][64 B]; a 128-row codeword tile is one half of such a block.
-    constexpr int NA = WR == 2 ? 4 : 2, NB = 4;
-    const bool dma_a = WR == 1 || wv < 4, dma_b = WR == 1 || wv >= 4;
+    constexpr int NA = QP ? 2 : (WR == 2 ? 4 : 2), NB = 4;
+    const bool dma_a = QP || WR == 1 || wv < 4, dma_b = !QP && (WR == 1 || wv >= 4);
     const unsigned lane_off = (unsigned)(lane * 16);
-    const int row_a = WR == 2 ? (wv & 3) * 64 : wv * 32, row_b = (wv & 3) * 64;
-    const char* qbase = (const char*)(qh + (size_t)qtile * nk * (BN * KB)) + row_b * (KB * 2);
+    const int row_a = QP ? wv * 32 : (WR == 2 ? (wv & 3) * 64 : wv * 32), row_b = (wv & 3) * 64;
+    const char* qbase = QP ? (const char*)(qh + (size_t)(qtile >> 1) * nk * (256 * KB)) + ((qtile & 1) * 128 + wv * 16) * (KB * 2)
+                           : (const char*)(qh + (size_t)qtile * nk * (BN * KB)) + row_b * (KB * 2);
+    if (QP) {            // the query panel: wave w brings rows 16 w .. 16 w + 15 of every slice
+        for (int s_ = 0; s_ < nk; ++s_) lds_dma16(qbase + (size_t)s_ * (256 * KB * 2) + lane_off, panel + (s_ * 128 + wv * 16) * KB);
+    }
     int pt = 0, pkc = 0, ps = 0;
     auto issue = [&]() {
         u16* st = ring + ps * STAGE_HALVES;
@@ -811,7 +819,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
 
     // fragment address of this lane inside a 16-row tile: row fr, physical segment fq ^ F[(fr >> 2) & 3]
     const int fso = (fr * KB) + ((fq ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) << 3);
-    const int fragA = wr * (MT * 16) * KB + fso, fragB = BM * KB + wc * (NT * 16) * KB + fso;
+    const int fragA = wr * (MT * 16) * KB + fso, fragB = (QP ? 0 : BM * KB) + wc * (NT * 16) * KB + fso;
     TopT<T + 1> top[NT];
     float thr[NT];
 #pragma unroll
@@ -829,7 +837,8 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
     // pipeline as in k_knn_l2_ring, with the fragments split by codeword rows instead of k-steps: X = tiles 0-3 (read during the
     // previous step), Y = tiles 4-7 and the four query fragments (read at the top of the step)
     f16x8 xa[4], ya[4], bq[NT];
-    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    if (QP) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");        // panel + slice 0 landed (2 pieces per wave and slice)
+    else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int m = 0; m < 4; ++m) xa[m] = *(const f16x8*)(ring + fragA + m * 16 * KB);
     int t = 0, kc = 0, gs = 0;
@@ -840,7 +849,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
         gs = gn;
         if (!(DBG & 16) || g == 0) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bq[n] = *(const f16x8*)(st + fragB + n * 16 * KB);
+        for (int n = 0; n < NT; ++n) bq[n] = *(const f16x8*)((QP ? panel + kc * (128 * KB) : st) + fragB + n * 16 * KB);
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
@@ -870,7 +879,11 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
         };
         mma4(0, xa, ya, st + fragA + 4 * 16 * KB);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(DBG & 32)) { if (WR == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+        if (!(DBG & 32)) {
+            if (QP) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (WR == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         if (!(DBG & 4) || g < 4) issue();
         __builtin_amdgcn_sched_barrier(0);
         mma4(4, ya, xa, sn + fragA);
@@ -904,11 +917,14 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
                 unsigned long long hit[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) hit[nt] = __ballot(mx[nt] > thr[nt]);
+                unsigned long long any_hit = 0ull;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) any_hit |= hit[nt];
 #ifdef ISM_KNN_DBG_VARIANTS
-                if (DBG & 256) { ++dbg_c[0]; if ((hit[0] | hit[1] | hit[2] | hit[3]) != 0ull) ++dbg_c[1]; }
+                if (DBG & 256) { ++dbg_c[0]; if (any_hit != 0ull) ++dbg_c[1]; }
 #endif
-                if (DBG & 64) { if ((hit[0] | hit[1] | hit[2] | hit[3]) != 0ull) top[0].i[0] += 1; }
-                else if (__builtin_expect((hit[0] | hit[1] | hit[2] | hit[3]) != 0ull, 0)) {
+                if (DBG & 64) { if (any_hit != 0ull) top[0].i[0] += 1; }
+                else if (__builtin_expect(any_hit != 0ull, 0)) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         if (hit[nt] == 0ull) continue;
@@ -1520,11 +1536,13 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     const bool use_lp = mode == 0 || mode == 1;
     const bool big_tile = use_lp && nq >= 4096 && cb->n_words_pad >= 4096 && !ctx->knn_small_tile;      // 256x256 tile, 8 waves
     const int BM0 = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BM) : CHI_B;
-    const int BNq = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BN) : CHI_B;
+    int BNq = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BN) : CHI_B;
     const int wr_rows = big_tile ? 128 : 64;
     const bool use_ring = big_tile && mode == 0 && !ctx->knn_no_ring && cb->words_f16t;
     const bool ring16 = use_ring && !ctx->knn_ring32;                  // 16x16x32 MFMA shape: 8 lane slots per query and split instead of 4
     const bool half = ring16 && ctx->knn_half;                         // 128 x 256 tile, two workgroups per CU (k_knn_l2_ring16<T, 1>)
+    const bool qpanel = ring16 && !half && ctx->knn_qpanel && ((cb->dim + 15) / 16 + 1) / 2 <= 11;   // 256 x 128 tile, query panel resident in LDS
+    if (qpanel) BNq = 128;
     const int BM = half ? 128 : BM0;
     const int slots = ring16 && !half ? 8 : 4;
     const int ring_nk = ((cb->dim + 15) / 16 + 1) / 2;                 // 32-k slices per row in the tiled images
@@ -1566,7 +1584,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     uint32_t* qsc = flag_count + 4;      // f16 mode: [0] absmax bits of the query batch, [1] -2/(s_q s_c), [2] 2^-14/s_q
     u16 *q_hi = nullptr, *q_lo = nullptr;
     if (use_lp) {
-        const int nq_pad = (nq + BNq - 1) / BNq * BNq;
+        const int nq_pad = use_ring ? (nq + 255) / 256 * 256 : (nq + BNq - 1) / BNq * BNq;
         const size_t tot = use_ring ? (size_t)(nq_pad / 256) * ring_nk * 8192 : (size_t)nq_pad * cb->ld16;
         q_hi = (u16*)ism_scratch(ctx, SCR_KNN_QSPLIT, tot * 2 * sizeof(u16));
         if (!q_hi) return ISMHIP_ERR_NOMEM;
@@ -1605,7 +1623,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
             }
             if (use_ring) {
                 wh = cb->words_f16t;
-                const void* rk = ring16 ? (half ? (const void*)k_knn_l2_ring16<T, 1, 0> : (const void*)k_knn_l2_ring16<T, 2, 0>) : (const void*)k_knn_l2_ring<T, 0>;
+                const void* rk = ring16 ? (qpanel ? (const void*)k_knn_l2_ring16<T, 2, 0, 1> : half ? (const void*)k_knn_l2_ring16<T, 1, 0> : (const void*)k_knn_l2_ring16<T, 2, 0>) : (const void*)k_knn_l2_ring<T, 0>;
 #ifdef ISM_KNN_DBG_VARIANTS
                 if (ring16) switch (ctx->knn_dbg) {       // 1 no epilogue, 2 no MFMA, 4 no DMA, 16 no fragment reads, 32 no barrier, 64 pre-test only, 256 counters
                     case 1: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 1> : (const void*)k_knn_l2_ring16<T, 2, 1>; break;  case 2: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 2> : (const void*)k_knn_l2_ring16<T, 2, 2>; break;
@@ -1624,7 +1642,8 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     default: break;
                 }
 #endif
-                const size_t rlds = half ? (size_t)3 * (128 + 256) * RG_KB * sizeof(u16) + 4 * 256 * sizeof(float)
+                const size_t rlds = qpanel ? (size_t)4 * 256 * RG_KB * sizeof(u16) + 4 * 256 * sizeof(float) + 8 * 2 * 64 * sizeof(float) + (size_t)ring_nk * 128 * RG_KB * sizeof(u16)
+                                  : half ? (size_t)3 * (128 + 256) * RG_KB * sizeof(u16) + 4 * 256 * sizeof(float)
                                          : (size_t)RG_STAGES * RG_STAGE_HALVES * sizeof(u16) + 4 * RG_BM * sizeof(float) + 8 * 4 * 64 * sizeof(float);
                 if (ctx->knn_dbg || !ctx->attr_done.count(rk)) {          // per device, so remembered per ctx
                     ISM_HIP(ctx, hipFuncSetAttribute(rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
