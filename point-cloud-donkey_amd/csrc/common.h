@@ -105,6 +105,7 @@ struct ismhip_ctx {
     uint32_t knn_stage2_queries = 0;  // last two-stage ismhip_knn: queries the T = 2 stage could not prove (searched again with T = 4)
     bool knn_two_stage = true;   // env ISMHIP_KNN_TWOSTAGE=0: single-stage T = 4 search (A/B runs)
     bool knn_small_tile = false; // env ISMHIP_KNN_TILE128=1: keep the bf16x3 kernel on its 128x128 tile (A/B runs)
+    bool knn_join = true;        // env ISMHIP_KNN_JOIN=0: every workgroup of the ring kernel sweeps its split from the first tile (A/B runs); default: joined streams
     bool knn_qpanel = false;     // env ISMHIP_KNN_QPANEL=1: the ring kernel on 256 x 128 tiles with the query panel resident in LDS (A/B runs)
     bool knn_half = false;       // env ISMHIP_KNN_HALF=1: the ring kernel on 128 x 256 tiles, two workgroups per CU (A/B runs)
     bool knn_ring32 = false;     // env ISMHIP_KNN_RING32=1: the ring kernel on the 32x32x16 MFMA shape instead of 16x16x32 (A/B runs)
@@ -122,7 +123,7 @@ struct ismhip_ctx {
 enum ScratchSlot {
     SCR_KP_OFF = 1, SCR_TIE_LIST, SCR_TIE_REC, SCR_TIE_KEYS, SCR_COUNTERS, SCR_KNN_CAND_IDX, SCR_KNN_CAND_VAL,
     SCR_QNORM, SCR_FPFH_FLAG, SCR_FPFH_LIST, SCR_FPFH_SPFH, SCR_FPFH_LOOKUP, SCR_SLOT_OFF, SCR_CLASS_BW,
-    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK, SCR_KMEANS
+    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK, SCR_KMEANS, SCR_KNN_CLOCK
 };
 
 int  ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg);

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
                                                           const u16* __restrict__ qh, int nq, const float* __restrict__ out_scale,
                                                           int tiles_per_split, int n_splits,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
-                                                          float* __restrict__ cand_bound, int bound_stride) {
+                                                          float* __restrict__ cand_bound, int bound_stride, unsigned int* __restrict__ stream_clock) {
     constexpr int WC = 4, MT = 8, NT = QP ? 2 : 4, KB = RG_KB, BM = WR * 128, BN = QP ? 128 : RG_BN;
     constexpr int STAGES = WR == 2 ? 4 : 3, STAGE_HALVES = (QP ? BM : BM + BN) * KB, CNS = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
@@ -777,6 +777,23 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
     if (n_t <= 0) return;
     const int nk = (k_steps + 1) / 2;
     const int G = n_t * nk;
+    // Joined codeword streams. The workgroups of an XCD that work on the same codebook split read the same codeword tiles, but a
+    // workgroup that starts later (second and later rounds of the grid) would begin at the split's first tile while the others are
+    // somewhere in the middle: no two of them would ever touch a tile at the same time and every tile would come from beyond
+    // the L2 once per workgroup. The order of the tiles does not matter for the result, so a workgroup begins where the stream
+    // of its (XCD, split) currently is -- a clock in global memory that every workgroup advances as it finishes tiles -- and wraps
+    // around. Nobody waits for anybody.
+    int toff = 0; unsigned c0 = 0u;
+    if (stream_clock) {
+        unsigned int* clk = stream_clock + xcd * n_splits + split;
+        if (tid == 0) *(volatile unsigned*)ring = __hip_atomic_load(clk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        c0 = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)ring);
+        __syncthreads();                                              // the ring is free for the first DMA
+        toff = (int)(c0 % (unsigned)n_t);
+        stream_clock = clk;
+    }
+    auto tile_of = [&](int i) { const int x = i + toff; return mt0 + (x >= n_t ? x - n_t : x); };   // i-th tile of this workgroup's sweep
 
     // DMA shares per slice (pieces of 16 rows x 64 B = 1 KB per wave instruction). WR = 2: waves 0-3 bring 64 codeword rows each,
     // waves 4-7 64 query rows each; WR = 1: every wave brings 32 codeword rows and 64 query rows. Both images are stored in
@@ -793,9 +810,9 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
     int pt = 0, pkc = 0, ps = 0;
     auto issue = [&]() {
         u16* st = ring + ps * STAGE_HALVES;
-        if (wv == 0 && pkc == 0) lds_dma16(word_norm + (size_t)(mt0 + pt) * BM + lane * 4, sCn + (pt & 3) * CNS);
+        const int tt = tile_of(pt);
+        if (wv == 0 && pkc == 0) lds_dma16(word_norm + (size_t)tt * BM + lane * 4, sCn + (pt & 3) * CNS);
         if (dma_a) {
-            const int tt = mt0 + pt;
             const char* sp = (const char*)wh + ((size_t)(WR == 2 ? tt : (tt >> 1)) * nk + pkc) * (256 * KB * 2) + ((WR == 2 ? 0 : (tt & 1) * 128) + row_a) * (KB * 2);
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
@@ -890,7 +907,8 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (++kc == nk) {
-            const int row0 = (mt0 + t) * BM + wr * (MT * 16) + 4 * fq;
+            const int row0 = tile_of(t) * BM + wr * (MT * 16) + 4 * fq;
+            if (stream_clock && tid == 0) atomicMax(stream_clock, c0 + (unsigned)t + 1u);
             if (DBG & 1) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -1657,7 +1675,13 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 const float* word_norm = cn_scaled;
                 int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
                 const u16* qh_ = q_hi;
-                void* rargs[] = {&wh, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb};
+                unsigned int* clock = nullptr;                                   // joined codeword streams (k_knn_l2_ring16), one clock per (XCD, split)
+                if (ring16 && ctx->knn_join) {
+                    clock = (unsigned int*)ism_scratch(ctx, SCR_KNN_CLOCK, 8 * 64 * sizeof(unsigned int));
+                    if (!clock) return ISMHIP_ERR_NOMEM;
+                    ISM_HIP(ctx, hipMemsetAsync(clock, 0, 8 * 64 * sizeof(unsigned int), ctx->stream));
+                }
+                void* rargs[] = {&wh, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb, &clock};
                 ISM_HIP(ctx, hipLaunchKernel(rk, grid, dim3(half ? 256 : 512), rargs, rlds, ctx->stream));
                 ISM_CHECK_LAUNCH(ctx, "k_knn_l2_ring");
             } else {
