@@ -849,7 +849,8 @@ def test_shot_is_invariant_under_rigid_motion_full_size(pkg, gpu):
 def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
     """BASELINE configs[1] scale without an oracle: 102 400 codewords x 352, 32 768 queries of clustered, descriptor-like unit
     vectors (plus exact duplicates of codewords and duplicated codewords). The default path (f16 MFMA candidates -> exact re-rank ->
-    proof -> exact scan of unproven slots; both MFMA shapes of the ring kernel) and the exact-f32 MFMA candidate path are independent routes to the same contract, so
+    proof -> exact scan of unproven slots; both MFMA shapes of the ring kernel, its tile variants, joined and separate codeword streams) and the exact-f32 MFMA
+    candidate path are independent routes to the same contract, so
     indices and distances must agree bit for bit; duplicates must resolve to the lowest row at distance 0."""
     import torch
     _, dev = gpu
@@ -867,9 +868,12 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
     wn = words.numpy()
     off = np.arange(n_words + 1, dtype=np.uint32)
     res = {}
-    for mode in ("f16", "f16-ring32", "f32"):
+    for mode in ("f16", "f16-ring32", "f16-nojoin", "f16-half", "f16-qpanel", "f32"):
         monkeypatch.setenv("ISMHIP_KNN_MODE", mode.split("-")[0])
         monkeypatch.setenv("ISMHIP_KNN_RING32", "1" if mode.endswith("ring32") else "0")     # the 32x32x16 variant of the ring kernel
+        monkeypatch.setenv("ISMHIP_KNN_JOIN", "0" if mode.endswith("nojoin") else "1")       # every workgroup sweeps its split from tile 0
+        monkeypatch.setenv("ISMHIP_KNN_HALF", "1" if mode.endswith("half") else "0")         # 128 x 256 tiles, two workgroups per CU
+        monkeypatch.setenv("ISMHIP_KNN_QPANEL", "1" if mode.endswith("qpanel") else "0")     # 256 x 128 tiles, query panel resident in LDS
         ctx = pkg.capi.Ctx(0)
         cb = pkg.capi.Codebook(ctx, wn, off, np.zeros((n_words, 3), np.float32), np.zeros(n_words, np.uint32), np.zeros(n_words, np.uint32), 1,
                                np.ones(1, np.float32))
@@ -877,7 +881,7 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
         idx, dist = pkg.capi.knn(ctx, cb, 0, q.to(dev), 2)
         res[mode] = (idx.cpu().numpy(), dist.cpu().numpy(), _knn_flagged(ctx))
         cb.close()
-    for m in ("f16", "f16-ring32"):
+    for m in ("f16", "f16-ring32", "f16-nojoin", "f16-half", "f16-qpanel"):
         assert np.array_equal(res[m][0], res["f32"][0]), m
         assert np.array_equal(res[m][1], res["f32"][1]), m
     i16, d16, flagged = res["f16"]
