@@ -1568,9 +1568,11 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     if (metric == ISMHIP_METRIC_L2SQ) {
         const int n_qt = (nq + BNq - 1) / BNq, n_mt = cb->n_words_pad / BM;
         const int max_s = 64 / (slots * T);
-        // at least two codebook splits: with one, the 32 workgroups of an XCD hold 32 different query tiles (6 MB of f16 queries
-        // re-read per codeword tile) and fall out of its 4 MB L2; two splits halve that working set (measured 21.0 -> 19.9 ms at 262144 queries)
-        n_splits = std::max(1, std::min(std::min(max_s, n_mt), std::max(2, (1024 + n_qt - 1) / n_qt)));
+        // at least three codebook splits (two when the candidate slots allow no more): with one, the 32 workgroups of an XCD hold 32
+        // different query tiles (6 MB of f16 queries re-read per codeword tile) and fall out of its 4 MB L2; two splits halve that
+        // working set (measured 21.0 -> 19.9 ms at 262144 queries), three cost the same time as two and fetch a fifth less from
+        // beyond the L2 (joined streams); four are 1.5 % slower
+        n_splits = std::max(1, std::min(std::min(max_s, n_mt), std::max(3, (1024 + n_qt - 1) / n_qt)));
         if (ctx->knn_splits > 0) n_splits = std::max(1, std::min(std::min(max_s, n_mt), ctx->knn_splits));
         // few queries (stage 2 of the two-stage search): cut the codebook into as many splits as it takes to fill the chip; the
         // candidates of all splits are then folded into one slot of KNN_MERGE_KEEP by k_knn_merge_splits
