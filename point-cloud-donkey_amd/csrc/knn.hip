@@ -1573,6 +1573,9 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         // working set (measured 21.0 -> 19.9 ms at 262144 queries), three cost the same time as two and fetch a fifth less from
         // beyond the L2 (joined streams); four are 1.5 % slower
         n_splits = std::max(1, std::min(std::min(max_s, n_mt), std::max(3, (1024 + n_qt - 1) / n_qt)));
+        // ... as long as a workgroup still has a few dozen tiles to amortise its prologue over (10 k-word codebook, 40 tiles: 1 / 2 / 3
+        // splits = 3.81 / 4.18 / 4.51 ms) and the launch fills the chip without them
+        if (big_tile && n_qt >= 512) n_splits = std::min(n_splits, std::max(1, n_mt / 32));
         if (ctx->knn_splits > 0) n_splits = std::max(1, std::min(std::min(max_s, n_mt), ctx->knn_splits));
         // few queries (stage 2 of the two-stage search): cut the codebook into as many splits as it takes to fill the chip; the
         // candidates of all splits are then folded into one slot of KNN_MERGE_KEEP by k_knn_merge_splits
