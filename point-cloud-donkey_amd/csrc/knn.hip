@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
                                                         const float* __restrict__ q, int nq, int ldq,
                                                         int tiles_per_split, int n_splits,
                                                         float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
-                                                        float* __restrict__ cand_bound, int bound_stride) {
+                                                        float* __restrict__ cand_bound, int bound_stride, int last_steps) {
     __shared__ __attribute__((aligned(16))) float sA[2][KNN_BM * KNN_LDK];
     __shared__ __attribute__((aligned(16))) float sB[2][KNN_BN * KNN_LDK];
     __shared__ float sCn[KNN_BM];
@@ -157,15 +157,20 @@ __global__ __launch_bounds__(256, 2) void k_knn_l2_mfma(const float* __restrict_
 #pragma unroll
                 for (int v = 0; v < 4; ++v) fb[ni][v] = *(const f32x4*)(p + v * 4);
             }
+            // the last slice holds dim - 32 (nk - 1) real columns, the rest is zero padding: MFMA step s covers columns s and 16 + s,
+            // so only the first last_steps steps carry anything (FPFH-33: 1 of 16 -- the padded steps were 47 % of this kernel's MFMAs)
+            const int steps = kc + 1 < nk ? 16 : last_steps;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * v + e >= steps) continue;                 // uniform
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < 2; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][v][e], fb[ni][v][e], acc[mi][ni], 0, 0, 0);
+                }
             if (kc + 1 < nk) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1703,7 +1708,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
             const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
             hipLaunchKernelGGL(k_knn_l2_mfma<T>, dim3(8 * ((n_qt + 7) / 8) * n_splits), dim3(256), 0, ctx->stream, cb->words, cb->word_norm,
                                cb->n_words_pad / KNN_BM, cb->dim_pad, qq, nq, ldq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand,
-                               cand_bound, n_bound);
+                               cand_bound, n_bound, std::min(16, cb->dim - (cb->dim_pad / KNN_BK - 1) * KNN_BK));
             ISM_CHECK_LAUNCH(ctx, "k_knn_l2_mfma");
         } else {
             const int n_qt = (nq + CHI_B - 1) / CHI_B;
