@@ -73,6 +73,9 @@ int  ismhip_ctx_create(int device, void* stream, ismhip_ctx** out);
  * that already owns a stream (e.g. torch.cuda.current_stream()) orders its own work with the library's. */
 int  ismhip_ctx_create_on_stream(int device, void* stream, ismhip_ctx** out);
 int  ismhip_ctx_destroy(ismhip_ctx* ctx);
+/* waits for the context's stream. Also the place where asynchronous caps surface: if find_maxima / hough3d_maxima had to drop
+ * maxima since the last call (more than 128 per object and class, or 1024 per object), it returns ISMHIP_ERR_UNSUPPORTED once
+ * (message in ismhip_last_error) and clears the condition -- the reference has no such caps, so this is never silent. */
 int  ismhip_sync(ismhip_ctx* ctx);
 const char* ismhip_last_error(const ismhip_ctx* ctx);
 /* per-kernel device timers (hipEvent on the ctx stream). Enable, run, sync, then read.

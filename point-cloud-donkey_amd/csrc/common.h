@@ -100,6 +100,7 @@ struct ismhip_ctx {
     float* lut_sxyz = nullptr;   // [4000]
     // destroyed clouds keep their device allocations here for the next ismhip_cloud_create (no hipMalloc/hipFree per batch)
     std::vector<ismhip_cloud*> cloud_pool;
+    uint32_t* truncated_d = nullptr;  // device counter: maxima dropped by the per-class / per-object caps of find_maxima / hough3d_maxima (ismhip_sync reports and clears it)
     uint32_t knn_stats[2] = {0, 0};   // last ismhip_knn: {queries, (query,slot) items} sent to the exact fallback (valid with timers on, after a sync)
     std::set<const void*> attr_done;  // kernels whose MaxDynamicSharedMemorySize attribute has been raised on THIS ctx's device
     uint32_t knn_stage2_queries = 0;  // last two-stage ismhip_knn: queries the T = 2 stage could not prove (searched again with T = 4)

@@ -96,6 +96,8 @@ static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out)
     }
     (void)hipMemcpy(ctx->lut_srgb, srgb.data(), 256 * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(ctx->lut_sxyz, sxyz.data(), 4000 * 4, hipMemcpyHostToDevice);
+    if (hipMalloc((void**)&ctx->truncated_d, 4) != hipSuccess) { delete ctx; return ISMHIP_ERR_NOMEM; }
+    (void)hipMemset(ctx->truncated_d, 0, 4);
     *out = ctx;
     return ISMHIP_OK;
 }
@@ -110,6 +112,7 @@ int ismhip_ctx_destroy(ismhip_ctx* ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->lut_srgb) (void)hipFree(ctx->lut_srgb);
     if (ctx->lut_sxyz) (void)hipFree(ctx->lut_sxyz);
+    if (ctx->truncated_d) (void)hipFree(ctx->truncated_d);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return ISMHIP_OK;
@@ -118,6 +121,15 @@ int ismhip_ctx_destroy(ismhip_ctx* ctx) {
 int ismhip_sync(ismhip_ctx* ctx) {
     if (!ctx) return ISMHIP_ERR_INVALID;
     ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->truncated_d) {                // caps of the maxima kernels (128 per object and class, 1024 per object): never silent
+        uint32_t n = 0;
+        ISM_HIP(ctx, hipMemcpy(&n, ctx->truncated_d, 4, hipMemcpyDeviceToHost));
+        if (n) {
+            ISM_HIP(ctx, hipMemset(ctx->truncated_d, 0, 4));
+            return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "find_maxima / hough3d_maxima: " + std::to_string(n) +
+                               " (object, class) lists exceeded 128 maxima per class or 1024 per object since the last sync; the results of those objects are truncated");
+        }
+    }
     return ISMHIP_OK;
 }
 

@@ -27,6 +27,7 @@ struct MaxArgs {
     int32_t* n_max; float* mpos; float* mw; int32_t* mcls; int32_t* minst; float* miw; float* mbs; int32_t* mnv; float* class_score;
     float* rec; int32_t* rec_count;      // per (object, class): up to MX_MAXM_C records of MX_REC floats
     unsigned char* work; const uint32_t* work_off; const uint32_t* class_count;   // big objects: per-(object, class) vote arrays in HBM
+    uint32_t* truncated;                 // ctx counter: maxima dropped by a cap (MX_MAXM_C per class, MX_MAXM per object); ismhip_sync reports it
 };
 #define MX_LDS_SLOTS 2048  // vote slots per object that fit the LDS-resident kernels
 #define MX_WORK_STRIDE 72  // bytes of workspace per vote slot (65 used by k_find_maxima, 37 by k_hough3d)
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
                     r[4] = __int_as_float(bestS > 0.f ? bestI : -1); r[5] = bestS > 0.f ? bestS : 0.f;
                     r[6] = b0 / sw; r[7] = b1 / sw; r[8] = b2 / sw; r[9] = __int_as_float(cnt);
                     s_nmax = m + 1;
-                }
+                } else atomicAdd(a.truncated, 1u);
             }
             __syncthreads();
         }
@@ -376,12 +377,18 @@ __global__ __launch_bounds__(64) void k_finalize_maxima(MaxArgs a) {
     const int C = a.n_classes;
     if (threadIdx.x != 0) return;
     int nm = 0;
+    {
+        int total = 0;
+        for (int c = 0; c < C; ++c) total += a.rec_count[(size_t)o * C + c];
+        if (total > MX_MAXM && a.truncated) atomicAdd(a.truncated, 1u);          // the object keeps its first MX_MAXM maxima: reported by ismhip_sync
+    }
     for (int c = 0; c < C; ++c) {
         const int cnt = a.rec_count[(size_t)o * C + c];
         for (int m = 0; m < cnt && nm < MX_MAXM; ++m) {
             const float* r = a.rec + (((size_t)o * C + c) * MX_MAXM_C + m) * MX_REC;
             s_w[nm] = r[3]; s_iw[nm] = r[5]; s_src[nm] = c * MX_MAXM_C + m; s_cls[nm] = c; s_order[nm] = nm; ++nm;
         }
+
     }
     if (a.max_filter == ISMHIP_MAXFILTER_SIMPLE && nm > 1) {
         // MaximaHandler::filterMaxima "Simple" -> suppressNeighborMaxima2 (maxima_handler.cpp:227-268): greedy non-maximum suppression
@@ -458,6 +465,7 @@ struct HoughArgs {
     int n_classes; const float* class_bin; float bin; float minc[3], maxc[3]; int use_int; float rel; int min_votes, cap, tile_edge;
     float* rec; int32_t* rec_count; int32_t* overflow;
     unsigned char* work; const uint32_t* work_off; const uint32_t* class_count;
+    uint32_t* truncated;
 };
 struct HgBin { int c[3]; int dir[3]; float wc[3]; bool in; };
 __device__ __forceinline__ HgBin hg_bin(const HoughArgs& a, double bin, const int cnt[3], float px, float py, float pz) {
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(256) void k_hough3d(HoughArgs a) {
         }
     }
     int nm = s_nm;
-    if (nm > MX_MAXM_C) { if (tid == 0) atomicAdd(a.overflow, 1); nm = MX_MAXM_C; }
+    if (nm > MX_MAXM_C) { if (tid == 0) { atomicAdd(a.overflow, 1); atomicAdd(a.truncated, 1u); } nm = MX_MAXM_C; }
     if (tid == 0)                                               // ascending bin index = the order findMaxima reports them in
         for (int i = 1; i < nm; ++i) { const long long v = s_mbin[i]; int j = i - 1; while (j >= 0 && s_mbin[j] > v) { s_mbin[j + 1] = s_mbin[j]; --j; } s_mbin[j + 1] = v; }
     __syncthreads();
@@ -691,7 +699,7 @@ __global__ __launch_bounds__(256) void k_hough3d(HoughArgs a) {
                 r[4] = __int_as_float(bestS > 0.f ? bestI : -1); r[5] = bestS > 0.f ? bestS : 0.f;
                 r[6] = b0 / sw; r[7] = b1 / sw; r[8] = b2 / sw; r[9] = __int_as_float(vcnt);
                 s_nmax = m + 1;
-            }
+            } else atomicAdd(a.truncated, 1u);
         }
         __syncthreads();
     }
@@ -763,6 +771,7 @@ extern "C" int ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* sl
         ISM_HIP(ctx, hipFuncSetAttribute((const void*)k_find_maxima<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
         ctx->attr_done.insert((const void*)k_find_maxima<false>);
     }
+    a.truncated = ctx->truncated_d;
     a.work = nullptr; a.work_off = nullptr; a.class_count = nullptr;
     if (big) { int rc = big_object_workspace(ctx, n_obj, P->n_classes, slot_offsets_h, so, vote_class, &a.work, &a.work_off, &a.class_count); if (rc != ISMHIP_OK) return rc; }
     const size_t n_oc = (size_t)n_obj * P->n_classes;
@@ -835,7 +844,7 @@ extern "C" int ismhip_hough3d_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t*
         ISM_HIP(ctx, hipFuncSetAttribute(hk, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         ctx->attr_done.insert(hk);
     }
-    h.work = nullptr; h.work_off = nullptr; h.class_count = nullptr;
+    h.work = nullptr; h.work_off = nullptr; h.class_count = nullptr; h.truncated = ctx->truncated_d; a.truncated = ctx->truncated_d;
     if (big) { int rc = big_object_workspace(ctx, n_obj, P->n_classes, slot_offsets_h, so, vote_class, &h.work, &h.work_off, &h.class_count); if (rc != ISMHIP_OK) return rc; }
     TimerScope ts(ctx, "hough3d");
     ISM_HIP(ctx, hipMemsetAsync(h.overflow, 0, 4, ctx->stream));

@@ -745,6 +745,23 @@ def test_maxima_of_objects_with_more_slots_than_fit_lds(pkg, gpu, ora):
     assert want["n"][0] >= 1
 
 
+def test_maxima_caps_are_reported_by_sync(pkg, gpu):
+    """More than 128 maxima of one class in one object (200 far-apart single-vote blobs): the kernels keep the first 128 and
+    ismhip_sync returns ISMHIP_ERR_UNSUPPORTED once -- the reference has no cap, so a truncation must not pass silently."""
+    ctx, dev = gpu
+    n = 200
+    pos = np.stack([np.arange(n) * 5.0, np.zeros(n), np.zeros(n)], 1).astype(np.float32)
+    v = dict(pos=T(pos, dev), weight=T(np.ones(n, np.float32), dev), cls=T(np.zeros(n, np.int32), dev), inst=T(np.zeros(n, np.int32), dev))
+    out = pkg.capi.find_maxima(ctx, [0, n], v, n_classes=2, bandwidth=0.5, max_maxima=256)
+    with pytest.raises(pkg.capi.IsmHipError, match="128 maxima per class"):
+        ctx.sync()
+    ctx.sync()                                                     # reported once, then cleared
+    assert int(out["n"][0]) == 128
+    out = pkg.capi.find_maxima(ctx, [0, 100], {k: a[:100] for k, a in v.items()}, n_classes=2, bandwidth=0.5, max_maxima=256)
+    ctx.sync()
+    assert int(out["n"][0]) == 100
+
+
 def test_find_maxima_two_blobs_property(pkg, gpu):
     ctx, dev = gpu
     rng = np.random.default_rng(40)
