@@ -55,7 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE.json configs[i]")
     ap.add_argument("--objects", type=int, default=0, help="objects of the test split classified per step by ALL ranks together (0 = the config's default; 908 for config 1)")
-    ap.add_argument("--batch", type=int, default=512, help="largest launch: a rank's shard is processed in chunks of at most this many objects")
+    ap.add_argument("--batch", type=int, default=1024, help="largest launch: a rank's shard is processed in chunks of at most this many objects (the 908-object split is one launch)")
     ap.add_argument("--train-per-class", type=int, default=0, help="training objects per class (0 = the config's default)")
     ap.add_argument("--cpu-objects", type=int, default=24, help="objects of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--points", type=int, default=0)
