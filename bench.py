@@ -288,7 +288,7 @@ def main():
         # beyond-L2 bytes per launch come from the committed PMC passes of this very command (separate FETCH_SIZE / WRITE_SIZE
         # runs, gfx950 correction applied); they are NOT measured in the run that prints this line, and are null for other shapes
         tf, tj = latest_traffic_json()
-        if tj and args.config == 1 and world == 1 and tj.get("objects") == G and tj.get("batch") == args.batch and not args.points and not args.keypoints:
+        if tj and args.config == 1 and world == 1 and tj.get("objects") == G and tj.get("launches_per_step") == len(chunks) and not args.points and not args.keypoints:
             for key in ("roofline", "roofline_shot"):
                 r = rooflines.get(key)
                 if r and r["kernel"] in tj:
@@ -298,13 +298,24 @@ def main():
     # ---- PCIe-inclusive leg (rank-local, N = 1): pinned host inputs -> H2D on a copy stream, double-buffered; scores D2H
     e2e = None
     if world == 1 and not args.no_e2e:
-        stager = pipeline.HostStager(chunks_h, dev)
+        # the uploads only hide behind compute when there is more than one launch per step: this leg cuts the shard into launches
+        # of at most 512 objects (two of 454 for the default split) whatever --batch says
+        e_bounds = plan_shard(G, rank, world, min(args.batch, 512))[3]
+        if len(e_bounds) - 1 == len(chunks_h):
+            e_chunks_h, e_ids = chunks_h, chunk_ids
+        else:
+            e_chunks_h, e_ids = [], []
+            for j in range(len(e_bounds) - 1):
+                ids = list(range(e_bounds[j], e_bounds[j + 1]))
+                if ids:
+                    e_chunks_h.append(test.batch(ids)); e_ids.append(torch.as_tensor(ids, device=dev))
+        stager = pipeline.HostStager(e_chunks_h, dev)
         score_h = torch.empty((G, C), dtype=torch.float32).pin_memory()
 
         def step_e2e():
             n = 0
             stager.begin()
-            for j, ids in enumerate(chunk_ids):
+            for j, ids in enumerate(e_ids):
                 b = stager.get(j)                      # waits (on the compute stream) for chunk j's upload, starts chunk j+1's
                 score, outs = classify(b)
                 score_h[n:n + len(ids)].copy_(score, non_blocking=True)
@@ -318,7 +329,7 @@ def main():
             step_e2e()
         dte = time.perf_counter() - t0
         e2e = {"value": round(G * n_e2e / dte, 3), "unit": "objects/s", "ms_per_step": round(dte / n_e2e * 1e3, 3), "steps": n_e2e,
-               "h2d_bytes_per_step": stager.bytes_per_pass, "note": "first H2D -> last class-score D2H (SURVEY §8d); uploads double-buffered on a copy stream"}
+               "h2d_bytes_per_step": stager.bytes_per_pass, "launches_per_step": len(e_ids), "note": "first H2D -> last class-score D2H (SURVEY §8d); uploads double-buffered on a copy stream"}
 
     # ---- CPU baseline: the oracle on a bounded sample (rank 0, N = 1, headline config only)
     cpu = None

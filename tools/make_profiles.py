@@ -66,7 +66,7 @@ def publish(tag, root="gpurun_out", dst="profiles"):
     out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --cpu-objects 0 --no-e2e --steps 2 --warmup 1",
            "note": "FETCH_SIZE/WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request and is doubled (MI355X_MICROARCH.md, HBM); "
                    "Infinity-Cache hits are included, so this is traffic beyond the XCD L2s, not DRAM alone",
-           "objects": line["config"]["objects_per_step_all_gpus"], "batch": 512}
+           "objects": line["config"]["objects_per_step_all_gpus"], "launches_per_step": line["config"]["launches_per_step_per_gpu"]}
     for k in ("k_shot<false>", "k_knn_l2_ring16", "k_lrf_cov", "k_lrf_sign"):
         f = [float(r["value_per_dispatch"]) for r in rows if r["kernel"] == k and r["counter"] == "FETCH_SIZE"]
         w = [float(r["value_per_dispatch"]) for r in rows if r["kernel"] == k and r["counter"] == "WRITE_SIZE"]
