@@ -240,9 +240,10 @@ def main():
     correct, total = int((best == labels).sum().item()), int(len(oi))
 
     # ---- per-kernel device time (HIP events on the ctx stream, timed region only; this rank)
-    names = ["grid", "lrf", "shot352", "cshot1344", "fpfh33", "knn", "knn_l2_mfma", "knn_chi2", "knn_fallback", "cast_votes", "maxima"]
+    names = ["grid", "lrf", "shot352", "cshot1344", "fpfh33", "knn", "knn_rotate", "knn_l2_mfma", "knn_chi2", "knn_rerank", "knn_stage2", "knn_fallback", "cast_votes", "maxima"]
     tm = {n: ctx.timer(n) for n in names}
-    knn_fb = {"queries": int(ctx.timer("knn_flagged_queries")[0]), "slot_items": int(ctx.timer("knn_flagged_items")[0])}
+    knn_fb = {"queries": int(ctx.timer("knn_flagged_queries")[0]), "slot_items": int(ctx.timer("knn_flagged_items")[0]),
+              "stage2_queries": int(ctx.timer("knn_stage2_queries")[0])}
     ctx.timers_enable(False)
     rooflines = {}
     if rank == 0:

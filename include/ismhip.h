@@ -180,6 +180,10 @@ int  ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* 
 int  ismhip_codebook_set_word_class(ismhip_ctx* ctx, ismhip_codebook* cb, const uint32_t* word_class_h);
 int  ismhip_codebook_destroy(ismhip_ctx* ctx, ismhip_codebook* cb);
 int  ismhip_codebook_max_votes_per_word(const ismhip_codebook* cb);
+/* Diagnostic: leading rotated coordinates of the codebook's stage-1 search image (0 = none: the squared-L2 candidate stage runs on
+ * all dimensions). Speed only -- every ismhip_knn answer is the exact functor minimum either way. energy_out (may be NULL): share
+ * of the codebook's second moment those coordinates hold. */
+int  ismhip_codebook_stage1_dims(const ismhip_codebook* cb, float* energy_out);
 
 /* ---- activation: ActivationStrategyKNN::activateKNN (activation_strategy/activation_strategy_knn.h:41-126)
  *      with FLANNExactMatch semantics (SearchParams(-1)): exact k nearest codewords, ascending distance,

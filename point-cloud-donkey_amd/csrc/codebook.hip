@@ -12,6 +12,8 @@
 #include <limits>
 
 int ism_codebook_split_bf16(ismhip_ctx* ctx, ismhip_codebook* cb, uint32_t absmax_bits);
+int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb);       // pca.hip: rotated, truncated stage-1 image
+void ism_codebook_free_pca(ismhip_codebook* cb);
 
 namespace {
 
@@ -161,6 +163,8 @@ int ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* w
         cb->words_nonneg = nonneg;
         int rc = ism_codebook_split_bf16(ctx, cb, amax);
         if (rc != ISMHIP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(rc != ISMHIP_OK ? rc : ISMHIP_ERR_HIP, "codebook_create: bf16 split");
+        rc = ism_codebook_build_pca(ctx, cb);
+        if (rc != ISMHIP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(rc != ISMHIP_OK ? rc : ISMHIP_ERR_HIP, "codebook_create: rotated image");
     }
     *out = cb;
     return ISMHIP_OK;
@@ -172,6 +176,7 @@ int ismhip_codebook_destroy(ismhip_ctx* ctx, ismhip_codebook* cb) {
     void* ptrs[] = {cb->words, cb->word_norm, cb->word_weight, cb->vote_off, cb->vote_xyz, cb->vote_weight, cb->vote_class_weight,
                     cb->vote_class, cb->vote_instance, cb->vote_bbox_quat, cb->vote_bbox_size, cb->class_sigma, cb->word_class, cb->words_bf16_hi, cb->words_f16t};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    ism_codebook_free_pca(cb);
     delete cb;
     return ISMHIP_OK;
 }
@@ -183,6 +188,11 @@ int ismhip_codebook_set_word_class(ismhip_ctx* ctx, ismhip_codebook* cb, const u
 }
 
 int ismhip_codebook_max_votes_per_word(const ismhip_codebook* cb) { return cb ? cb->max_votes : ISMHIP_ERR_INVALID; }
+int ismhip_codebook_stage1_dims(const ismhip_codebook* cb, float* energy_out) {
+    if (!cb) return ISMHIP_ERR_INVALID;
+    if (energy_out) *energy_out = cb->pca_m > 0 ? cb->pca_energy : 1.0f;
+    return cb->pca_m;
+}
 
 int ismhip_cast_votes(ismhip_ctx* ctx, const ismhip_codebook* cb, uint32_t weight_flags,
                       int nq, const float* lrf9, const float* kpx, const float* kpy, const float* kpz,

@@ -76,6 +76,20 @@ struct ismhip_codebook {
     float* vote_bbox_size = nullptr; // [n_votes*3]
     float* class_sigma = nullptr;    // [n_classes]
     uint32_t* word_class = nullptr;  // [n_words] Codeword::getClassId
+    // ---- rotated, truncated stage-1 image of the squared-L2 search (pca.hip; pca_m == 0: not built) ----------------------------
+    // rows of R = the pca_m leading eigenvectors of the codebook's second-moment matrix (orthonormal up to pca_orth_err), so
+    // |R (q - c)|^2 <= sigma_max(R)^2 |q - c|^2: a score over the leading pca_m rotated coordinates is a LOWER bound of the functor value
+    int pca_m = 0;                   // leading rotated coordinates kept (multiple of 32)
+    float* pca_R = nullptr;          // [pca_m x dim_pad] fp32, row j = j-th basis vector (zero in the padding columns)
+    unsigned short* pca_f16t = nullptr;   // f16 image of R c (scale pca_sc) in the ring kernel's streaming layout [tile][pca_m/32][256][32]
+    float* pca_cn_scaled = nullptr;  // [n_words_pad + 256] |c^|^2 / out_scale of that image (-inf for padding rows): the ring kernel's C operand
+    float* pca_osc = nullptr;        // device scalars: [0] out_scale = -2 / (pca_sq pca_sc)
+    float pca_sq = 1.f, pca_sc = 1.f;     // power-of-two f16 scales of the query / codebook images (the query scale is FIXED per codebook)
+    float pca_cmax2 = 0.f;           // max |c^|^2 over the real rows (c^ = image / pca_sc)
+    float pca_inv_sig2 = 1.f;        // 1 / (upper bound of sigma_max(R)^2), rounded down
+    float pca_d_rel = 0.f;           // |x^ - R x|_2 <= pca_d_rel |x|_2 + pca_dq_abs (queries) / pca_dc_abs (codewords): rotation + f16 rounding
+    float pca_dq_abs = 0.f, pca_dc_abs = 0.f;
+    float pca_energy = 0.f;          // share of the codebook's second moment in the leading pca_m coordinates (diagnostic)
 };
 
 struct TimerAcc {
@@ -118,13 +132,15 @@ struct ismhip_ctx {
     bool xcd_map = true;         // env ISMHIP_XCD_MAP=0: per-object kernels on the plain object-major block order instead of the XCD-local map (A/B runs)
     float grid_xfrac = 0.f;      // env ISMHIP_GRID_XFRAC: x cells this many times finer than y/z cells (default ISM_GRID_XFRAC; A/B runs)
     int shot_var = 0;            // env ISMHIP_SHOT_VAR=2: k_shot on the contiguous candidate sweep instead of 16 interleaved segments (A/B runs; same histogram)
+    int knn_pca_m = -1;          // env ISMHIP_KNN_PCA_M: leading rotated coordinates of the stage-1 image (0 = no rotated image, -1 = chosen from the spectrum)
+    uint32_t knn_pca_launches = 0;    // squared-L2 searches whose stage 1 ran on the rotated image (tests / bench)
     int knn_mode = 0;            // env ISMHIP_KNN_MODE = f16 (0, default) | bf16x3 (1) | f32 (2): squared-L2 candidate kernel (A/B runs, tests)
 };
 
 enum ScratchSlot {
     SCR_KP_OFF = 1, SCR_TIE_LIST, SCR_TIE_REC, SCR_TIE_KEYS, SCR_COUNTERS, SCR_KNN_CAND_IDX, SCR_KNN_CAND_VAL,
     SCR_QNORM, SCR_FPFH_FLAG, SCR_FPFH_LIST, SCR_FPFH_SPFH, SCR_FPFH_LOOKUP, SCR_SLOT_OFF, SCR_CLASS_BW,
-    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK, SCR_KMEANS, SCR_KNN_CLOCK
+    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK, SCR_KMEANS, SCR_KNN_CLOCK, SCR_PCA
 };
 
 int  ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg);

@@ -75,6 +75,7 @@ static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out)
     { const char* e = getenv("ISMHIP_KNN_DBG"); ctx->knn_dbg = e ? atoi(e) : 0; }
     { const char* e = getenv("ISMHIP_KNN_NORING"); ctx->knn_no_ring = e && e[0] == '1'; }
     { const char* e = getenv("ISMHIP_KNN_KB32"); ctx->knn_kb32 = e && e[0] == '1'; }
+    { const char* e = getenv("ISMHIP_KNN_PCA_M"); ctx->knn_pca_m = e ? atoi(e) : -1; }
     { const char* e = getenv("ISMHIP_KNN_TILE128"); ctx->knn_small_tile = e && e[0] == '1'; }
     if (!own) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else {
@@ -163,6 +164,7 @@ int ismhip_timers_reset(ismhip_ctx* ctx) {
 int ismhip_timer_get(ismhip_ctx* ctx, const char* name, double* ms_out, int64_t* launches_out) {
     if (!ctx || !name) return ISMHIP_ERR_INVALID;
     resolve_timers(ctx);
+    if (std::strcmp(name, "knn_pca_launches") == 0) { if (ms_out) *ms_out = (double)ctx->knn_pca_launches; if (launches_out) *launches_out = 1; return ISMHIP_OK; }
     if (std::strcmp(name, "knn_stage2_queries") == 0) { if (ms_out) *ms_out = (double)ctx->knn_stage2_queries; if (launches_out) *launches_out = 1; return ISMHIP_OK; }
     if (std::strcmp(name, "knn_flagged_queries") == 0 || std::strcmp(name, "knn_flagged_items") == 0) {     // counters, not times
         if (ms_out) *ms_out = (double)ctx->knn_stats[name[12] == 'q' ? 0 : 1];

@@ -21,6 +21,8 @@
 //     adversarial inputs (un-normalised magnitudes, hundreds of near-duplicates): it keeps the answer exact in every case.
 #include "common.h"
 
+int ism_pca_rotate_queries(ismhip_ctx* ctx, const ismhip_codebook* cb, const float* q, int nq, int ldq, unsigned short* dst);   // pca.hip
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1357,6 +1359,120 @@ __global__ __launch_bounds__(256) void k_knn_rerank(const float* __restrict__ wo
     }
 }
 
+// ---- re-rank + proof for a stage 1 that ran on the ROTATED, TRUNCATED image (pca.hip) --------------------------------------------
+// The candidate scores are now |c^|^2 - 2 c^.q^ over the m leading rotated coordinates (x^ = the f16 image of fl(R x) / scale): up
+// to accumulation error a LOWER bound piece of the functor value, not an approximation of it. With
+//   L(s)  = |q^|^2 (1 - 16u) + s - eps_acc                  <= |q^ - c^|^2     (eps_acc as in k_knn_rerank, accumulation terms only)
+//   LB(s) = ((sqrt(L) - delta_q - delta_c)+ )^2 / sigma_max(R)^2                <= |q - c|^2   (pca.hip header)
+// a row whose score is s has functor value >= LB(s) (1 - ku). Consequences:
+//   * candidates are evaluated with the exact functor in ascending order of their score until the next one's LB exceeds the k-th
+//     exact value found so far (the others cannot be among the k best, nor tie with them);
+//   * a slot whose dropped-score bound b has LB(b) (1 - ku) above the k-th exact value cannot hide a better row: proven.
+struct PcaVerify {
+    const u16* qimg; int nk;          // rotated f16 query image (tiled), slices per row
+    float inv_sq2;                    // 1 / scale^2 of that image
+    float inv_sig2, d_rel, dq_abs, dc;   // 1 / sigma_max^2 (rounded down); |x^ - R x| <= d_rel |x| + abs; dc = the codeword side for |c| = |c|max
+    float eps_c2, dot2, cmax2;        // eps_acc = eps_c2 + dot2 |q^||c^|max;  cmax2 = max |c^|^2
+    float ku;
+};
+__device__ __forceinline__ void knn_queue_unproven(bool viol, int qi, int lane, uint32_t* __restrict__ flag_count, uint32_t* __restrict__ qrec, uint32_t* __restrict__ items) {
+    // queue: one record per unproven query {query, first item, #items} and one work item {query, slot} per failing slot
+    const unsigned long long vmask = __ballot(viol);
+    if (vmask != 0ull) {
+        const int nv = __popcll(vmask);
+        uint32_t ibase = 0;
+        if (lane == 0) {
+            const uint32_t qs = atomicAdd(&flag_count[0], 1u);
+            ibase = atomicAdd(&flag_count[1], (uint32_t)nv);
+            qrec[3 * (size_t)qs] = (uint32_t)qi; qrec[3 * (size_t)qs + 1] = ibase; qrec[3 * (size_t)qs + 2] = (uint32_t)nv;
+        }
+        ibase = __shfl(ibase, 0, 64);
+        if (viol) {
+            const uint32_t it = ibase + __popcll(vmask & ((1ull << lane) - 1ull));
+            items[2 * (size_t)it] = (uint32_t)qi; items[2 * (size_t)it + 1] = (uint32_t)lane;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_knn_rerank_pca(const float* __restrict__ words, int dim, int dim_pad, int n_words,
+                                                        const float* __restrict__ q, int nq, int ldq,
+                                                        const int* __restrict__ cand_idx, const float* __restrict__ cand_val, int cand_stride, int n_cand,
+                                                        const float* __restrict__ cand_bound, int n_bound, PcaVerify pv,
+                                                        int k, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
+                                                        uint32_t* __restrict__ flag_count, uint32_t* __restrict__ qrec, uint32_t* __restrict__ items) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const int lane = lane_id();
+    const float* qp = q + (size_t)qi * ldq;
+    float qn2 = 0.f;
+    for (int i = lane; i < dim; i += 64) { const float v = qp[i]; qn2 += v * v; }
+    qn2 = wave_sum_f(qn2);
+    float qn2h = 0.f;                                                  // |q^|^2 from the image itself (any element order)
+    {
+        const size_t tile = (size_t)(qi >> 8); const int r = qi & 255;
+        for (int i = lane; i < pv.nk * 32; i += 64) {
+            const float v = (float)__builtin_bit_cast(_Float16, pv.qimg[((tile * pv.nk + (i >> 5)) * 256 + r) * 32 + (i & 31)]);
+            qn2h += v * v;
+        }
+        qn2h = wave_sum_f(qn2h) * pv.inv_sq2;
+    }
+    const float dlt = pv.d_rel * (sqrtf(qn2) * 1.00001f) + pv.dq_abs + pv.dc;
+    const float eps_s = (pv.eps_c2 + pv.dot2 * sqrtf(qn2h * pv.cmax2)) * 1.00001f;
+    auto lb_of = [&](float s) -> float {
+        float L = qn2h * (1.f - 16.f * KNN_U) + s - eps_s;
+        L -= 4.f * KNN_U * (qn2h + fabsf(s));                          // rounding of the two additions above
+        if (!(L > 0.f)) return 0.f;                                    // also NaN
+        const float t = sqrtf(L) * (1.f - 4.f * KNN_U) - dlt;
+        if (!(t > 0.f)) return 0.f;
+        return t * t * pv.inv_sig2 * (1.f - 8.f * KNN_U);
+    };
+    int id = -1; float av = __builtin_inff();
+    if (lane < n_cand) { id = cand_idx[(size_t)qi * cand_stride + lane]; av = cand_val[(size_t)qi * cand_stride + lane]; }
+    if (!(id >= 0 && id < n_words)) { id = -1; av = __builtin_inff(); }
+    const float lb = id >= 0 ? lb_of(av) : __builtin_inff();
+    bool done = id < 0;
+    unsigned long long key = ~0ull;
+    {
+        __shared__ __attribute__((aligned(16))) float s_terms[4][1344];
+        float* sT = s_terms[threadIdx.x >> 6];
+        float kth = __builtin_inff(); int n_eval = 0;
+        for (;;) {
+            const float cur = done ? __builtin_inff() : lb;
+            const float mn = wave_min_f(cur);
+            if (!(mn < __builtin_inff())) break;
+            if (n_eval >= k && mn * (1.f - pv.ku) > kth) break;        // every remaining candidate is strictly worse than the k-th exact value
+            const unsigned long long eq = __ballot(!done && cur == mn);
+            const int src = __ffsll((long long)eq) - 1;
+            const int cid = __shfl(id, src, 64);
+            const float d = wave_functor(ISMHIP_METRIC_L2SQ, qp, words + (size_t)cid * dim_pad, dim, lane, sT);
+            if (lane == src) { key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id; done = true; }
+            if (++n_eval >= k) {
+                unsigned long long kk = key, m_ = ~0ull;
+                for (int j = 0; j < k; ++j) { m_ = wave_min_u64(kk); if (kk == m_) kk = ~0ull; }
+                kth = __uint_as_float((unsigned)(m_ >> 32));
+            }
+        }
+    }
+    float bnd = __builtin_inff();
+    if (lane < n_bound) bnd = cand_bound[(size_t)qi * n_bound + lane];
+    float dk = 0.f; bool have_k = true;
+    for (int j = 0; j < k; ++j) {
+        const unsigned long long mn = wave_min_u64(key);
+        if (lane == 0) {
+            if (mn == ~0ull) { idx_out[(size_t)qi * k + j] = -1; dist_out[(size_t)qi * k + j] = __builtin_nanf(""); }
+            else { idx_out[(size_t)qi * k + j] = (int)(mn & 0xffffffffull); dist_out[(size_t)qi * k + j] = __uint_as_float((unsigned)(mn >> 32)); }
+        }
+        if (mn == ~0ull) have_k = false; else dk = __uint_as_float((unsigned)(mn >> 32));
+        if (key == mn) key = ~0ull;
+    }
+    // a slot whose bound is still +inf dropped nothing -- unless scores overflowed, which needs a non-finite |q^|^2 or bound term
+    bool viol = false;
+    if (lane < n_bound && (bnd != __builtin_inff() || !(eps_s + qn2h + dlt < __builtin_inff()))) {
+        if (!have_k) viol = true;
+        else viol = !(dk < lb_of(bnd) * (1.f - pv.ku) - 1e-37f);
+    }
+    knn_queue_unproven(viol, qi, lane, flag_count, qrec, items);
+}
+
 // Exact scan for the slots that could not be proven. One WAVE per (query, slot) work item; the wave handles 4 codeword rows
 // per step (16 lanes each, 64-byte coalesced segments) with the query held in registers; direct (a-b)^2 [/(a+b)] sums pick
 // the rows that can still matter, the FLANN functor order ranks them. Each item leaves its k best (distance,row) keys in
@@ -1537,7 +1653,7 @@ __global__ void k_rule(int nq, float thr, const int32_t* __restrict__ idx3, cons
 struct KnnStage1 { uint32_t* flag_count; uint32_t* qrec; };
 template <int T>
 int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q, int k,
-            int32_t* idx_out, float* dist_out, KnnStage1* stage1 = nullptr, const char* tname = nullptr, bool many_splits = false) {
+            int32_t* idx_out, float* dist_out, KnnStage1* stage1 = nullptr, const char* tname = nullptr, bool many_splits = false, bool use_pca = false) {
     if (cb->dim_pad / 16 > KNN_FB_MAXJ) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: descriptor longer than 1344 not built");
     const float* qq = q; int ldq = cb->dim;
     if (cb->dim_pad != cb->dim) {
@@ -1561,14 +1677,17 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     const int BM0 = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BM) : CHI_B;
     int BNq = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BN) : CHI_B;
     const int wr_rows = big_tile ? 128 : 64;
-    const bool use_ring = big_tile && mode == 0 && !ctx->knn_no_ring && cb->words_f16t;
+    // (the ring kernels prefetch four slices ahead and keep the |c|^2 rows of four tiles: a tile must have at least two slices)
+    const bool use_ring = big_tile && mode == 0 && !ctx->knn_no_ring && cb->words_f16t && (cb->dim + 15) / 16 > 2;
     const bool ring16 = use_ring && !ctx->knn_ring32;                  // 16x16x32 MFMA shape: 8 lane slots per query and split instead of 4
     const bool half = ring16 && ctx->knn_half;                         // 128 x 256 tile, two workgroups per CU (k_knn_l2_ring16<T, 1>)
     const bool qpanel = ring16 && !half && ctx->knn_qpanel && ((cb->dim + 15) / 16 + 1) / 2 <= 11;   // 256 x 128 tile, query panel resident in LDS
     if (qpanel) BNq = 128;
     const int BM = half ? 128 : BM0;
     const int slots = ring16 && !half ? 8 : 4;
-    const int ring_nk = ((cb->dim + 15) / 16 + 1) / 2;                 // 32-k slices per row in the tiled images
+    // stage 1 of the two-stage search on the rotated, truncated image (pca.hip): same kernel, pca_m / 32 slices instead of dim / 32
+    const bool pca = use_pca && use_ring && cb->pca_m > 0;
+    const int ring_nk = pca ? cb->pca_m / 32 : ((cb->dim + 15) / 16 + 1) / 2;   // 32-k slices per row in the tiled images
     const bool merged = many_splits && metric == ISMHIP_METRIC_L2SQ && use_lp && !big_tile;
     if (metric == ISMHIP_METRIC_L2SQ) {
         const int n_qt = (nq + BNq - 1) / BNq, n_mt = cb->n_words_pad / BM;
@@ -1617,7 +1736,12 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         q_hi = (u16*)ism_scratch(ctx, SCR_KNN_QSPLIT, tot * 2 * sizeof(u16));
         if (!q_hi) return ISMHIP_ERR_NOMEM;
         q_lo = q_hi + tot;
-        if (mode == 0) {
+        if (pca) {
+            TimerScope tr(ctx, "knn_rotate");
+            const int rc = ism_pca_rotate_queries(ctx, cb, qq, nq, ldq, q_hi);
+            if (rc != ISMHIP_OK) return rc;
+            ++ctx->knn_pca_launches;
+        } else if (mode == 0) {
             hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, qsc);
             ISM_CHECK_LAUNCH(ctx, "k_absmax");
             if (use_ring) hipLaunchKernelGGL(k_to_f16_tiled, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad / 256, ring_nk, qsc, cb->f16_scale, q_hi);
@@ -1678,12 +1802,16 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     ctx->attr_done.insert(rk);
                 }
                 const float* osc = (const float*)(qsc + 1);
-                float* cn_scaled = (float*)ism_scratch(ctx, SCR_QNORM2, ((size_t)cb->n_words_pad + 256) * sizeof(float));   // the |c|^2 DMA of a 128-row tile reads 256 floats
-                if (!cn_scaled) return ISMHIP_ERR_NOMEM;
-                hipLaunchKernelGGL(k_scale_norms, dim3((cb->n_words_pad + 255) / 256), dim3(256), 0, ctx->stream, cb->word_norm, cb->n_words_pad, osc, cn_scaled);
-                ISM_CHECK_LAUNCH(ctx, "k_scale_norms");
-                const float* word_norm = cn_scaled;
-                int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
+                const float* word_norm;
+                if (pca) { wh = cb->pca_f16t; osc = cb->pca_osc; word_norm = cb->pca_cn_scaled; }      // scales fixed per codebook: the C operand is precomputed
+                else {
+                    float* cn_scaled = (float*)ism_scratch(ctx, SCR_QNORM2, ((size_t)cb->n_words_pad + 256) * sizeof(float));   // the |c|^2 DMA of a 128-row tile reads 256 floats
+                    if (!cn_scaled) return ISMHIP_ERR_NOMEM;
+                    hipLaunchKernelGGL(k_scale_norms, dim3((cb->n_words_pad + 255) / 256), dim3(256), 0, ctx->stream, cb->word_norm, cb->n_words_pad, osc, cn_scaled);
+                    ISM_CHECK_LAUNCH(ctx, "k_scale_norms");
+                    word_norm = cn_scaled;
+                }
+                int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = pca ? cb->pca_m / 16 : (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
                 const u16* qh_ = q_hi;
                 unsigned int* clock = nullptr;                                   // joined codeword streams (k_knn_l2_ring16), one clock per (XCD, split)
                 if (ring16 && ctx->knn_join) {
@@ -1739,9 +1867,27 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     vp.dabs_q = mode == 0 ? (const float*)(qsc + 2) : nullptr;
     vp.sqrt_dim = sqrtf((float)cb->dim_pad);
     vp.cn_acc = mode == 0 ? 1.01f * (float)(cb->dim_pad + 1) * 1.1920929e-07f : 0.f;
+    {
+    TimerScope trr(ctx, "knn_rerank");
+    if (pca) {
+        PcaVerify pv;
+        const float acc_rel = 1.01f * (float)cb->pca_m * 1.1920929e-07f;            // accumulation only: products of f16 values are exact in fp32
+        pv.qimg = q_hi; pv.nk = ring_nk; pv.inv_sq2 = 1.0f / (cb->pca_sq * cb->pca_sq);
+        pv.inv_sig2 = cb->pca_inv_sig2; pv.d_rel = cb->pca_d_rel; pv.dq_abs = cb->pca_dq_abs;
+        pv.dc = (cb->pca_d_rel * sqrtf(cb->max_norm2) + cb->pca_dc_abs) * 1.00001f;
+        pv.cmax2 = cb->pca_cmax2;
+        // subnormal f16 operands may be flushed to zero by the matrix cores: |dq_i| <= 2^-14 / sq, |dc_i| <= 2^-14 / sc per element
+        const float fq = 6.103515625e-05f / cb->pca_sq, fc = 6.103515625e-05f / cb->pca_sc, sm = sqrtf((float)cb->pca_m);
+        pv.eps_c2 = (17.f * KNN_U + 1.01f * (float)(cb->pca_m + 1) * 1.1920929e-07f) * cb->pca_cmax2 + 2.02f * (sm * fq * sqrtf(cb->pca_cmax2) + sm * sm * fq * fc);
+        pv.dot2 = 2.f * acc_rel + 2.f * KNN_U + 2.02f * sm * fc / sqrtf(cb->pca_cmax2);
+        pv.ku = vp.ku;
+        hipLaunchKernelGGL(k_knn_rerank_pca, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
+                           qq, nq, ldq, cand_idx, cand_val, n_cand, n_cand, cand_bound, n_bound, pv, k, idx_out, dist_out, flag_count, qrec, items);
+    } else
     hipLaunchKernelGGL(k_knn_rerank, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
                        qq, nq, ldq, metric, cand_idx, cand_val, n_cand, n_cand, cand_bound, n_bound, vp, k, idx_out, dist_out, flag_count, qrec, items);
     ISM_CHECK_LAUNCH(ctx, "k_knn_rerank");
+    }
     if (stage1) { stage1->flag_count = flag_count; stage1->qrec = qrec; return ISMHIP_OK; }
     {
         TimerScope ts(ctx, "knn_fallback");
@@ -1784,7 +1930,7 @@ __global__ void k_knn_scatter_results(const uint32_t* __restrict__ list2, int n2
 
 int run_knn_two_stage(ismhip_ctx* ctx, const ismhip_codebook* cb, int nq, const float* q, int k, int32_t* idx_out, float* dist_out) {
     KnnStage1 s1{nullptr, nullptr};
-    int rc = run_knn<2>(ctx, cb, ISMHIP_METRIC_L2SQ, nq, q, k, idx_out, dist_out, &s1, nullptr);
+    int rc = run_knn<2>(ctx, cb, ISMHIP_METRIC_L2SQ, nq, q, k, idx_out, dist_out, &s1, nullptr, false, true);
     if (rc != ISMHIP_OK) return rc;
     uint32_t n2u = 0;
     ISM_HIP(ctx, hipMemcpyAsync(&n2u, s1.flag_count, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -464,6 +464,78 @@ def test_knn_large_launch_matches_oracle(pkg, gpu, ora, dim):
         assert np.array_equal(dist.cpu().numpy(), wdist)
 
 
+def _steep_spectrum_data(rng, n_words, nq, dim, rank=40, noise=0.02):
+    """descriptor-like vectors: a low-rank part + small isotropic noise, non-negative, unit length"""
+    basis = rng.random((rank, dim)).astype(np.float32)
+    def draw(n):
+        x = rng.random((n, rank)).astype(np.float32) ** 3 @ basis + noise * rng.random((n, dim)).astype(np.float32)
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    return draw(n_words), draw(nq)
+
+
+def _bare_cb(pkg, ctx, words):
+    n = len(words)
+    return pkg.capi.Codebook(ctx, words, np.arange(n + 1, dtype=np.uint32), np.zeros((n, 3), np.float32), np.zeros(n, np.uint32),
+                             np.zeros(n, np.uint32), 1, np.ones(1, np.float32))
+
+
+@pytest.mark.parametrize("forced_m", [None, 96, 256])
+def test_knn_rotated_stage1_matches_oracle(pkg, gpu, ora, forced_m, monkeypatch):
+    """Stage 1 of the two-stage search on the rotated, truncated image (csrc/pca.hip): partial distances over the leading principal
+    coordinates are lower bounds, the re-rank evaluates candidates in bound order and the proof divides by sigma_max(R)^2. Data
+    with a steep spectrum takes the path by itself (forced_m None); 96 and 256 are forced truncations, 256 the rotation kernel's widest tile. Answers: the oracle's, bit for bit."""
+    _, dev = gpu
+    if forced_m is not None:
+        monkeypatch.setenv("ISMHIP_KNN_PCA_M", str(forced_m))
+    ctx = pkg.capi.Ctx(0)
+    rng = np.random.default_rng(99)
+    words, q = _steep_spectrum_data(rng, 8192 + 100, 5000, 352)
+    words[4000:4003] = words[17]                                          # duplicates: ties to the lowest row
+    q[:8] = words[:8]; q[8] = words[17]
+    q[9] *= 40.0                                                          # far beyond the fixed query scale's headroom: f16 image overflows
+    q[10] *= 1e-6
+    cb = _bare_cb(pkg, ctx, words)
+    assert cb.stage1_dims == (forced_m or cb.stage1_dims) and 0 < cb.stage1_dims <= 256 and cb.stage1_dims % 32 == 0, cb.stage1_dims
+    ctx.timers_enable(True)
+    for k in (1, 2):
+        idx, dist = pkg.capi.knn(ctx, cb, 0, T(q, dev), k)
+        gi, gd = idx.cpu().numpy(), dist.cpu().numpy()
+        n2 = int(ctx.timer("knn_stage2_queries")[0])
+        widx, wdist = ora.knn(0, words, q, k)
+        assert np.array_equal(gi, widx) and np.array_equal(gd, wdist)
+        assert n2 >= 1                                                    # at least the overflowing query went to stage 2
+        if forced_m is None:
+            assert n2 < 500, n2                                           # the chosen truncation proves the bulk
+    assert int(ctx.timer("knn_pca_launches")[0]) == 2
+    cb.close()
+
+
+def test_knn_rotated_stage1_on_a_flat_spectrum_falls_back(pkg, gpu, ora, monkeypatch):
+    """Random vectors have no leading directions: by itself the codebook gets no rotated image; FORCED onto 192 of 352 coordinates
+    the partial distances bound almost nothing, nearly every stage-1 proof fails and stage 2 / the exact scan (original coordinates)
+    answer -- slower, never wrong."""
+    _, dev = gpu
+    rng = np.random.default_rng(5)
+    words = rng.normal(size=(6000, 352)).astype(np.float32)
+    q = rng.normal(size=(4500, 352)).astype(np.float32)
+    q[:5] = words[:5]
+    ctx = pkg.capi.Ctx(0)
+    cb = _bare_cb(pkg, ctx, words)
+    assert cb.stage1_dims == 0                                            # spectrum too flat to pay
+    cb.close()
+    monkeypatch.setenv("ISMHIP_KNN_PCA_M", "192")
+    ctx = pkg.capi.Ctx(0)
+    cb = _bare_cb(pkg, ctx, words)
+    assert cb.stage1_dims == 192 and cb.stage1_energy < 0.7
+    ctx.timers_enable(True)
+    idx, dist = pkg.capi.knn(ctx, cb, 0, T(q, dev), 2)
+    n2 = int(ctx.timer("knn_stage2_queries")[0])
+    widx, wdist = ora.knn(0, words, q, 2)
+    assert np.array_equal(idx.cpu().numpy(), widx) and np.array_equal(dist.cpu().numpy(), wdist)
+    assert n2 > 2000, n2                                                  # the forced truncation really was useless, and it showed
+    cb.close()
+
+
 def test_knn_ties_kat_and_ratio(pkg, gpu, ora):
     ctx, dev = gpu
     k = KAT["knn_ties"]
@@ -863,9 +935,9 @@ def test_shot_is_invariant_under_rigid_motion_full_size(pkg, gpu):
     assert (dd < 2e-3).mean() > 0.999 and np.median(dd.max(1)) < 1e-4, ((dd < 2e-3).mean(), np.median(dd.max(1)))
 
 
-def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
-    """BASELINE configs[1] scale without an oracle: 102 400 codewords x 352, 32 768 queries of clustered, descriptor-like unit
-    vectors (plus exact duplicates of codewords and duplicated codewords). The default path (f16 MFMA candidates -> exact re-rank ->
+def test_knn_bench_scale_modes_agree(pkg, gpu, ora, monkeypatch):
+    """BASELINE configs[1] scale: 102 400 codewords x 352, 32 768 queries of clustered, descriptor-like unit
+    vectors (plus exact duplicates of codewords and duplicated codewords); 512 of the queries also go through the oracle. The default path (f16 MFMA candidates -> exact re-rank ->
     proof -> exact scan of unproven slots; both MFMA shapes of the ring kernel, its tile variants, joined and separate codeword streams) and the exact-f32 MFMA
     candidate path are independent routes to the same contract, so
     indices and distances must agree bit for bit; duplicates must resolve to the lowest row at distance 0."""
@@ -885,8 +957,15 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
     wn = words.numpy()
     off = np.arange(n_words + 1, dtype=np.uint32)
     res = {}
-    for mode in ("f16", "f16-ring32", "f16-nojoin", "f16-half", "f16-qpanel", "f32"):
+    modes = ("f16", "f16-nopca", "f16-pca192", "f16-ring32", "f16-nojoin", "f16-half", "f16-qpanel", "f32")
+    for mode in modes:
         monkeypatch.setenv("ISMHIP_KNN_MODE", mode.split("-")[0])
+        if mode.endswith("nopca"):
+            monkeypatch.setenv("ISMHIP_KNN_PCA_M", "0")                                       # stage 1 on all 352 dimensions
+        elif mode.endswith("pca192"):
+            monkeypatch.setenv("ISMHIP_KNN_PCA_M", "192")                                     # stage 1 forced onto 192 rotated coordinates
+        else:
+            monkeypatch.delenv("ISMHIP_KNN_PCA_M", raising=False)
         monkeypatch.setenv("ISMHIP_KNN_RING32", "1" if mode.endswith("ring32") else "0")     # the 32x32x16 variant of the ring kernel
         monkeypatch.setenv("ISMHIP_KNN_JOIN", "0" if mode.endswith("nojoin") else "1")       # every workgroup sweeps its split from tile 0
         monkeypatch.setenv("ISMHIP_KNN_HALF", "1" if mode.endswith("half") else "0")         # 128 x 256 tiles, two workgroups per CU
@@ -896,12 +975,18 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, monkeypatch):
                                np.ones(1, np.float32))
         ctx.timers_enable(True)
         idx, dist = pkg.capi.knn(ctx, cb, 0, q.to(dev), 2)
-        res[mode] = (idx.cpu().numpy(), dist.cpu().numpy(), _knn_flagged(ctx))
+        res[mode] = (idx.cpu().numpy(), dist.cpu().numpy(), _knn_flagged(ctx), cb.stage1_dims)
         cb.close()
-    for m in ("f16", "f16-ring32", "f16-nojoin", "f16-half", "f16-qpanel"):
+    assert res["f16-nopca"][3] == 0 and res["f16-pca192"][3] == 192
+    for m in modes[:-1]:
         assert np.array_equal(res[m][0], res["f32"][0]), m
         assert np.array_equal(res[m][1], res["f32"][1]), m
-    i16, d16, flagged = res["f16"]
+    # the oracle leg: every 64th query against all 102 400 words on the CPU
+    sel = np.arange(0, nq, 64)
+    widx, wdist = ora.knn(0, wn, q.numpy()[sel], 2)
+    for m in ("f16", "f16-pca192", "f32"):
+        assert np.array_equal(res[m][0][sel], widx) and np.array_equal(res[m][1][sel], wdist), m
+    i16, d16, flagged, _ = res["f16"]
     assert np.array_equal(i16[:20, 0], np.arange(20)) and (d16[:20, 0] == 0).all()
     assert np.array_equal(i16[10:20, 1], np.arange(50000, 50010)) and (d16[10:20, 1] == 0).all()    # the duplicate is the second neighbour
     assert (d16[:, 0] <= d16[:, 1]).all()
