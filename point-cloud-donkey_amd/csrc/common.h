@@ -89,6 +89,7 @@ struct ismhip_codebook {
     float pca_inv_sig2 = 1.f;        // 1 / (upper bound of sigma_max(R)^2), rounded down
     float pca_d_rel = 0.f;           // |x^ - R x|_2 <= pca_d_rel |x|_2 + pca_dq_abs (queries) / pca_dc_abs (codewords): rotation + f16 rounding
     float pca_dq_abs = 0.f, pca_dc_abs = 0.f;
+    float pca_resid2 = 0.f;          // mean second moment per codeword OUTSIDE the leading pca_m coordinates (the pre-pass relaxes its start thresholds by it)
     float pca_energy = 0.f;          // share of the codebook's second moment in the leading pca_m coordinates (diagnostic)
 };
 
@@ -132,6 +133,9 @@ struct ismhip_ctx {
     bool xcd_map = true;         // env ISMHIP_XCD_MAP=0: per-object kernels on the plain object-major block order instead of the XCD-local map (A/B runs)
     float grid_xfrac = 0.f;      // env ISMHIP_GRID_XFRAC: x cells this many times finer than y/z cells (default ISM_GRID_XFRAC; A/B runs)
     int shot_var = 0;            // env ISMHIP_SHOT_VAR=2: k_shot on the contiguous candidate sweep instead of 16 interleaved segments (A/B runs; same histogram)
+    int knn_t1 = 2;              // env ISMHIP_KNN_T1 = 1 | 2: candidates kept per lane slot in stage 1 of the two-stage search (A/B runs)
+    float knn_pre_gamma = 1.5f;  // env ISMHIP_KNN_PRE_GAMMA: relaxation of the pre-pass start thresholds in units of the truncated second moment (A/B runs)
+    bool knn_prepass = true;     // env ISMHIP_KNN_PREPASS=0: stage 1 starts every candidate list cold instead of from the sampled pre-pass threshold (A/B runs)
     int knn_pca_m = -1;          // env ISMHIP_KNN_PCA_M: leading rotated coordinates of the stage-1 image (0 = no rotated image, -1 = chosen from the spectrum)
     uint32_t knn_pca_launches = 0;    // squared-L2 searches whose stage 1 ran on the rotated image (tests / bench)
     int knn_mode = 0;            // env ISMHIP_KNN_MODE = f16 (0, default) | bf16x3 (1) | f32 (2): squared-L2 candidate kernel (A/B runs, tests)
@@ -140,7 +144,7 @@ struct ismhip_ctx {
 enum ScratchSlot {
     SCR_KP_OFF = 1, SCR_TIE_LIST, SCR_TIE_REC, SCR_TIE_KEYS, SCR_COUNTERS, SCR_KNN_CAND_IDX, SCR_KNN_CAND_VAL,
     SCR_QNORM, SCR_FPFH_FLAG, SCR_FPFH_LIST, SCR_FPFH_SPFH, SCR_FPFH_LOOKUP, SCR_SLOT_OFF, SCR_CLASS_BW,
-    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK, SCR_KMEANS, SCR_KNN_CLOCK, SCR_PCA
+    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK, SCR_KMEANS, SCR_KNN_CLOCK, SCR_PCA, SCR_KNN_THR0
 };
 
 int  ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg);

@@ -756,12 +756,22 @@ __device__ unsigned long long g_knn_dbg[256];
 // QP = 1 (ISMHIP_KNN_QPANEL=1, WR = 2, descriptors of at most 352 elements): a 256 x 128 tile whose QUERY panel (128 queries x all
 // slices, 88 KB) is loaded into LDS once per workgroup; only the codeword tiles stream through the ring. The 256 x 256 kernel
 // re-reads its 180 KB query tile for every codeword tile, and that is what falls out of the XCD L2s.
-template <int T, int WR = 2, int DBG = 0, int QP = 0>
+// PRE = 1 (WR = 2, QP = 0): the SAMPLING PRE-PASS. The workgroup sweeps every tile_step-th codeword tile (one split) and keeps, per
+// query column, only the best score it meets; thr_out[query] = that score (lowered by a few ulps). The main launch (PRE = 0) then
+// STARTS every lane slot of the query from thr_init[query] instead of -inf. Why this is sound for ANY start value: thresholds only
+// rise, a dropped score is <= the threshold at the time <= the final threshold, which is what the slot reports as its bound -- a
+// start value that is too high only makes proofs fail (stage 2 then answers). Why it pays: the insertion code runs whenever ANY of
+// a wave's 256 (query, slot) lists takes a score, and from a cold start each of the 24 lists of a query (8 slots x 3 splits) fills
+// and refines itself independently (measured: 28 inserting lanes per wave and tile, 27 % of the kernel at 4 slices per tile); the
+// best of a 1/16 sample is about the 16th best score of the query overall, so with it as the start only a few dozen scores per
+// QUERY (not per list) ever reach the insertion code.
+template <int T, int WR = 2, int DBG = 0, int QP = 0, int PRE = 0>
 __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __restrict__ wh, const float* __restrict__ word_norm, int n_tiles_m, int ld, int k_steps,
                                                           const u16* __restrict__ qh, int nq, const float* __restrict__ out_scale,
                                                           int tiles_per_split, int n_splits,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
-                                                          float* __restrict__ cand_bound, int bound_stride, unsigned int* __restrict__ stream_clock) {
+                                                          float* __restrict__ cand_bound, int bound_stride, unsigned int* __restrict__ stream_clock,
+                                                          const float* __restrict__ thr_init, float* __restrict__ thr_out, int tile_step, float thr_relax) {
     constexpr int WC = 4, MT = 8, NT = QP ? 2 : 4, KB = RG_KB, BM = WR * 128, BN = QP ? 128 : RG_BN;
     constexpr int STAGES = WR == 2 ? 4 : 3, STAGE_HALVES = (QP ? BM : BM + BN) * KB, CNS = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
@@ -780,7 +790,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
     const int split = jx % n_splits, qtile = (jx / n_splits) * 8 + xcd;
     if (qtile * BN >= nq) return;
     const int mt0 = split * tiles_per_split;
-    const int n_t = min(n_tiles_m, mt0 + tiles_per_split) - mt0;
+    const int n_t = PRE ? (n_tiles_m + tile_step - 1) / tile_step : min(n_tiles_m, mt0 + tiles_per_split) - mt0;
     if (n_t <= 0) return;
     const int nk = (k_steps + 1) / 2;
     const int G = n_t * nk;
@@ -800,7 +810,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
         toff = (int)(c0 % (unsigned)n_t);
         stream_clock = clk;
     }
-    auto tile_of = [&](int i) { const int x = i + toff; return mt0 + (x >= n_t ? x - n_t : x); };   // i-th tile of this workgroup's sweep
+    auto tile_of = [&](int i) { if (PRE) return i * tile_step; const int x = i + toff; return mt0 + (x >= n_t ? x - n_t : x); };   // i-th tile of this workgroup's sweep
 
     // DMA shares per slice (pieces of 16 rows x 64 B = 1 KB per wave instruction). WR = 2: waves 0-3 bring 64 codeword rows each,
     // waves 4-7 64 query rows each; WR = 1: every wave brings 32 codeword rows and 64 query rows. Both images are stored in
@@ -847,7 +857,10 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
     TopT<T + 1> top[NT];
     float thr[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) { top[n].init(); thr[n] = -__builtin_inff(); }
+    for (int n = 0; n < NT; ++n) {
+        top[n].init(); thr[n] = -__builtin_inff();
+        if (!PRE && thr_init) { const int qi_ = qtile * BN + wc * (NT * 16) + n * 16 + fr; if (qi_ < nq) thr[n] = thr_init[qi_]; }
+    }
     f32x4 acc[MT][NT];
 #ifdef ISM_KNN_DBG_VARIANTS
     unsigned dbg_c[6] = {0, 0, 0, 0, 0, 0};
@@ -885,7 +898,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
             if (kc == 0) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const f32x4 c0 = *(const f32x4*)(cnp + (mb + mt) * 16);
+                    const f32x4 c0 = (DBG & 2048) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(cnp + (mb + mt) * 16);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) { if (!(DBG & 2)) acc[mb + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bq[nt], c0, 0, 0, 0); else acc[mb + mt][nt] = c0; }
                     if (!(DBG & 16) || g == 0) nxt[mt] = *(const f16x8*)(nsrc + mt * 16 * KB);
@@ -916,7 +929,19 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
         if (++kc == nk) {
             const int row0 = tile_of(t) * BM + wr * (MT * 16) + 4 * fq;
             if (stream_clock && tid == 0) atomicMax(stream_clock, c0 + (unsigned)t + 1u);
-            if (DBG & 1) {
+            if (PRE) {
+                // pre-pass: the best score of the column so far, nothing else (16 v_max3 per column and tile)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float m = thr[nt];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[mt][nt][0]), "v"(acc[mt][nt][1]));
+                        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(acc[mt][nt][2]), "v"(acc[mt][nt][3]));
+                    }
+                    thr[nt] = m;
+                }
+            } else if (DBG & 1) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1020,6 +1045,27 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
 #ifdef ISM_KNN_DBG_VARIANTS
     if ((DBG & 256) && lane == 0) for (int c = 0; c < 6; ++c) atomicAdd(&g_knn_dbg[c], (unsigned long long)dbg_c[c]);
 #endif
+    if (PRE) {
+        // thr[] is the best over this wave's four row groups and (through sThr, one tile late) the partner wave row; one more exchange
+        // behind a barrier makes it the best of the whole sample: the nearest SAMPLED row in the stage-1 coordinates. The start value
+        // handed to the main launch is that score RELAXED by thr_relax (< 0 in accumulator units): the proof of a query needs every
+        // row it drops to lie beyond the nearest neighbour's FULL distance, which exceeds its stage-1 distance by the energy the
+        // truncation left out -- a start value right at the sample's best makes the proof fail whenever that best is (close to) the
+        // nearest neighbour itself (measured: 15.7 % instead of 6.7 % of the queries).
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) sThr[(wv * NT + nt) * 64 + lane] = thr[nt];
+        __syncthreads();
+        if (wr == 0 && fq == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int qi = qtile * BN + wc * (NT * 16) + nt * 16 + fr;
+                const float b = fmaxf(thr[nt], sThr[(pw * NT + nt) * 64 + lane]);
+                if (qi < nq) thr_out[qi] = b - fabsf(b) * 3.814697265625e-06f + thr_relax;
+            }
+        }
+        return;
+    }
     // candidates: slot = split*(WR*4*T) + (wr*4 + fq)*T + t; bound slot = split*WR*4 + wr*4 + fq
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1696,7 +1742,9 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         // different query tiles (6 MB of f16 queries re-read per codeword tile) and fall out of its 4 MB L2; two splits halve that
         // working set (measured 21.0 -> 19.9 ms at 262144 queries), three cost the same time as two and fetch a fifth less from
         // beyond the L2 (joined streams); four are 1.5 % slower
-        n_splits = std::max(1, std::min(std::min(max_s, n_mt), std::max(3, (1024 + n_qt - 1) / n_qt)));
+        // (stage 1 on the rotated image: two -- with 4-6 slices per tile the epilogue is a larger share of the kernel, and every split
+        // is another eight candidate lists per query to fill: 29.8 -> 28.1 ms per bench launch)
+        n_splits = std::max(1, std::min(std::min(max_s, n_mt), std::max(pca ? 2 : 3, (1024 + n_qt - 1) / n_qt)));
         // ... as long as a workgroup still has a few dozen tiles to amortise its prologue over (10 k-word codebook, 40 tiles: 1 / 2 / 3
         // splits = 3.81 / 4.18 / 4.51 ms) and the launch fills the chip without them
         if (big_tile && n_qt >= 512) n_splits = std::min(n_splits, std::max(1, n_mt / 32));
@@ -1782,6 +1830,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     case 5: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 5> : (const void*)k_knn_l2_ring16<T, 2, 5>; break;  case 21: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 21> : (const void*)k_knn_l2_ring16<T, 2, 21>; break;
                     case 53: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 53> : (const void*)k_knn_l2_ring16<T, 2, 53>; break; case 64: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 64> : (const void*)k_knn_l2_ring16<T, 2, 64>; break;
                     case 256: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 256> : (const void*)k_knn_l2_ring16<T, 2, 256>; break;
+                    case 2048: rk = (const void*)k_knn_l2_ring16<T, 2, 2048>; break; case 2049: rk = (const void*)k_knn_l2_ring16<T, 2, 2049>; break; case 2069: rk = (const void*)k_knn_l2_ring16<T, 2, 2069>; break;
                     case 128: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 128> : (const void*)k_knn_l2_ring16<T, 2, 128>; break; case 1024: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 1024> : (const void*)k_knn_l2_ring16<T, 2, 1024>; break;
                     default: break;
                 } else
@@ -1819,7 +1868,26 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     if (!clock) return ISMHIP_ERR_NOMEM;
                     ISM_HIP(ctx, hipMemsetAsync(clock, 0, 8 * 64 * sizeof(unsigned int), ctx->stream));
                 }
-                void* rargs[] = {&wh, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb, &clock};
+                // sampling pre-pass (stage 1 of the two-stage search on the 256 x 256 kernel, codebooks of >= 128 tiles): the best score
+                // every query meets in every 16th codeword tile becomes the start threshold of all its lane slots (see the kernel)
+                const float* thr_init = nullptr; float* thr_out = nullptr; int tile_step = 1;
+                if (stage1 && ring16 && !half && !qpanel && ctx->knn_prepass && n_tiles_m >= 128 && ctx->knn_dbg == 0) {
+                    float* thr0 = (float*)ism_scratch(ctx, SCR_KNN_THR0, (size_t)((nq + 255) / 256 * 256) * sizeof(float));
+                    if (!thr0) return ISMHIP_ERR_NOMEM;
+                    const void* pk = (const void*)k_knn_l2_ring16<T, 2, 0, 0, 1>;
+                    if (!ctx->attr_done.count(pk)) { ISM_HIP(ctx, hipFuncSetAttribute(pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds)); ctx->attr_done.insert(pk); }
+                    int one = 1, all = n_tiles_m, step = 16; unsigned int* noclk = nullptr; const float* noinit = nullptr;
+                    // relaxation: gamma x the second moment the truncation leaves out (codeword + query side, taken as equal), in
+                    // accumulator units (score / out_scale); the original image truncates nothing
+                    float relax = 0.f;
+                    if (pca) relax = -ctx->knn_pre_gamma * 2.0f * cb->pca_resid2 * (cb->pca_sq * cb->pca_sc * 0.5f);
+                    void* pargs[] = {&wh, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &nq_, &osc, &all, &one, &cand_val, &cand_idx, &ncand, &cand_bound, &nb, &noclk, &noinit, &thr0, &step, &relax};
+                    ISM_HIP(ctx, hipLaunchKernel(pk, dim3(8 * ((n_qt + 7) / 8)), dim3(512), pargs, rlds, ctx->stream));
+                    ISM_CHECK_LAUNCH(ctx, "k_knn_l2_ring16<pre>");
+                    thr_init = thr0;
+                }
+                float no_relax = 0.f;
+                void* rargs[] = {&wh, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb, &clock, &thr_init, &thr_out, &tile_step, &no_relax};
                 ISM_HIP(ctx, hipLaunchKernel(rk, grid, dim3(half ? 256 : 512), rargs, rlds, ctx->stream));
                 ISM_CHECK_LAUNCH(ctx, "k_knn_l2_ring");
             } else {
@@ -1930,7 +1998,8 @@ __global__ void k_knn_scatter_results(const uint32_t* __restrict__ list2, int n2
 
 int run_knn_two_stage(ismhip_ctx* ctx, const ismhip_codebook* cb, int nq, const float* q, int k, int32_t* idx_out, float* dist_out) {
     KnnStage1 s1{nullptr, nullptr};
-    int rc = run_knn<2>(ctx, cb, ISMHIP_METRIC_L2SQ, nq, q, k, idx_out, dist_out, &s1, nullptr, false, true);
+    int rc = ctx->knn_t1 == 1 && k == 1 ? run_knn<1>(ctx, cb, ISMHIP_METRIC_L2SQ, nq, q, k, idx_out, dist_out, &s1, nullptr, false, true)
+                                        : run_knn<2>(ctx, cb, ISMHIP_METRIC_L2SQ, nq, q, k, idx_out, dist_out, &s1, nullptr, false, true);
     if (rc != ISMHIP_OK) return rc;
     uint32_t n2u = 0;
     ISM_HIP(ctx, hipMemcpyAsync(&n2u, s1.flag_count, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1945,8 +2014,15 @@ int run_knn_two_stage(ismhip_ctx* ctx, const ismhip_codebook* cb, int nq, const 
     float* dist2 = (float*)(idx2 + (size_t)n2 * k);
     hipLaunchKernelGGL(k_knn_gather_flagged, dim3(n2), dim3(256), 0, ctx->stream, s1.qrec, n2, q, cb->dim, q2, list2);
     ISM_CHECK_LAUNCH(ctx, "k_knn_gather_flagged");
-    rc = run_knn<4>(ctx, cb, ISMHIP_METRIC_L2SQ, n2, q2, k, idx2, dist2, nullptr, "knn_stage2", n2 < 4096);
-    if (rc != ISMHIP_OK) return rc;
+    // Stage 2 runs 256-query tiles x 2 codebook splits on 256 CUs: 65 536 queries are two full rounds of workgroups, 66 000 are three
+    // (measured 4.5 vs 6.7 ms). So a large stage 2 is cut into a multiple of 32 768 queries and a remainder, which (below 4096
+    // queries) takes the merged-splits kernel that fills the chip with splits instead of query tiles.
+    for (int o = 0; o < n2;) {
+        const int left = n2 - o, n = left >= 32768 ? left / 32768 * 32768 : left;
+        rc = run_knn<4>(ctx, cb, ISMHIP_METRIC_L2SQ, n, q2 + (size_t)o * cb->dim, k, idx2 + (size_t)o * k, dist2 + (size_t)o * k, nullptr, "knn_stage2", n < 4096);
+        if (rc != ISMHIP_OK) return rc;
+        o += n;
+    }
     hipLaunchKernelGGL(k_knn_scatter_results, dim3((n2 * k + 255) / 256), dim3(256), 0, ctx->stream, list2, n2, k, idx2, dist2, idx_out, dist_out);
     ISM_CHECK_LAUNCH(ctx, "k_knn_scatter_results");
     return ISMHIP_OK;

@@ -242,9 +242,11 @@ int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
     jacobi_eig(dp, S, V, w);
     std::vector<int> order(dp); std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w[a] > w[b]; });
-    // leading coordinates kept: forced (ISMHIP_KNN_PCA_M), else the smallest multiple of 32 that holds 98.5 % of the second moment
-    // (bench data: 192 of 352 -> ~0.1 % of the queries fail the stage-1 proof; 160 -> ~1 %) -- if that leaves less than 64 dimensions
-    // saved, or needs more than the 256 the rotation kernel is built for, the original image stays the stage-1 image
+    // leading coordinates kept: forced (ISMHIP_KNN_PCA_M), else the smallest multiple of 32 that holds 97 % of the second moment. Bench
+    // data (929 792 queries x 102 400 words, measured): 128 of 352 coordinates -> 7.0 % of the queries fail the stage-1 proof and are
+    // searched again in all dimensions, kNN 35.6 ms per launch; 160 -> 3.0 %, 36.4 ms; 192 -> 1.0 %, 42.9 ms; 96 -> 14.5 %, 38.6 ms;
+    // all 352 (no rotated image) -> 0.1 %, 58.7 ms. If the rule leaves less than 64 dimensions saved, or needs more than the 256 the
+    // rotation kernel is built for, the original image stays the stage-1 image.
     const int m_cap = std::min(256, dp);
     int m = 0; double cum = 0, energy = 0;
     if (ctx->knn_pca_m > 0) {
@@ -253,7 +255,7 @@ int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
         energy /= trace;
     } else {
         // (at least 64: the ring kernel prefetches four slices ahead and keeps the |c|^2 rows of four tiles, i.e. it needs >= 2 slices per tile)
-        for (int i = 0; i < dp && !m; ++i) { cum += w[order[i]]; if ((i + 1) % 32 == 0 && i + 1 >= 64 && cum >= 0.985 * trace) { m = i + 1; energy = cum / trace; } }
+        for (int i = 0; i < dp && !m; ++i) { cum += w[order[i]]; if ((i + 1) % 32 == 0 && i + 1 >= 64 && cum >= 0.97 * trace) { m = i + 1; energy = cum / trace; } }
         if (m == 0 || m > m_cap || m + 64 > dp) return ISMHIP_OK;
     }
     std::vector<float> R((size_t)m * dp);
@@ -275,6 +277,7 @@ int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
     cb->pca_dc_abs = (float)(1.001 * std::sqrt((double)m) * 6.103515625e-05 / cb->pca_sc);
     cb->pca_inv_sig2 = (float)((1.0 / sig2) * (1.0 - 1e-6));
     cb->pca_energy = (float)energy;
+    cb->pca_resid2 = (float)((1.0 - energy) * trace / (double)cb->n_words);
     const int nk = m / 32, n_tiles = cb->n_words_pad / 256;
     if (hipMalloc((void**)&cb->pca_R, R.size() * sizeof(float)) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook rotation matrix");
     ISM_HIP(ctx, hipMemcpy(cb->pca_R, R.data(), R.size() * sizeof(float), hipMemcpyHostToDevice));
