@@ -27,6 +27,14 @@ __global__ void k_word_norms(const float* __restrict__ words, int n_words, int n
     if (lane == 0) norm[row] = row < n_words ? s : __builtin_inff();   // padding rows can never win
 }
 
+// shadow row p = sqrt(word perm[p]) (p < n_words), zero rows behind
+__global__ void k_sqrt_permuted(const float* __restrict__ src, const uint32_t* __restrict__ perm, int n_words, int dim_pad, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t row = i / dim_pad; const int col = (int)(i % dim_pad);
+    dst[i] = row < (size_t)n_words ? sqrtf(src[(size_t)perm[row] * dim_pad + col]) : 0.f;
+}
+
 #include "quat.h"
 
 struct VoteArgs {
@@ -165,6 +173,42 @@ int ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* w
         if (rc != ISMHIP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(rc != ISMHIP_OK ? rc : ISMHIP_ERR_HIP, "codebook_create: bf16 split");
         rc = ism_codebook_build_pca(ctx, cb);
         if (rc != ISMHIP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(rc != ISMHIP_OK ? rc : ISMHIP_ERR_HIP, "codebook_create: rotated image");
+        // chi-square candidates on the matrix cores: 16-bit images, norms and scales of sqrt(words) in a shadow codebook (histogram
+        // codebooks of descriptors longer than 64 only: short ones take the exact-f32 contraction for L2 and the VALU kernel for chi-square)
+        if (nonneg && dim > 64 && ctx->knn_hellinger && n_words >= 1024) {
+            ismhip_codebook* sh = new ismhip_codebook();
+            cb->chi_shadow = sh;
+            sh->n_words = n_words; sh->dim = dim; sh->dim_pad = cb->dim_pad; sh->n_words_pad = cb->n_words_pad; sh->n_classes = n_classes;
+            if (hipMalloc((void**)&sh->words, wbytes) != hipSuccess || hipMalloc((void**)&sh->word_norm, (size_t)cb->n_words_pad * 4) != hipSuccess)
+                return fail(ISMHIP_ERR_NOMEM, "codebook_create: sqrt image");
+            // The rows of the shadow are a fixed pseudo-random PERMUTATION of the codebook's. Codebooks are class-major (one class ~ one
+            // 256-row tile at 10 k words / 51 classes), so the dozens of rows a proof must hold as candidates would all sit in the eight
+            // candidate lists of ONE tile's split; shuffled, they spread over all splits and slots (measured, CSHOT-1344: 36 % -> 3 % of
+            // the queries unproven). k_knn_rerank_hell maps candidate rows back through shadow_perm.
+            std::vector<uint32_t> perm(n_words);
+            for (int i = 0; i < n_words; ++i) perm[i] = (uint32_t)i;
+            uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)n_words;
+            for (int i = n_words - 1; i > 0; --i) {
+                st += 0x9E3779B97F4A7C15ull; uint64_t z = st; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+                std::swap(perm[i], perm[(size_t)(z % (uint64_t)(i + 1))]);
+            }
+            if (!upload(&sh->shadow_perm, perm.data(), (size_t)n_words)) return fail(ISMHIP_ERR_NOMEM, "codebook_create: sqrt image permutation");
+            const size_t tot = (size_t)cb->n_words_pad * cb->dim_pad;
+            hipLaunchKernelGGL(k_sqrt_permuted, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, cb->words, sh->shadow_perm, n_words, cb->dim_pad, sh->words, tot);
+            hipLaunchKernelGGL(k_word_norms, dim3((cb->n_words_pad + 3) / 4), dim3(256), 0, ctx->stream, sh->words, n_words, cb->n_words_pad, cb->dim_pad, sh->word_norm);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ISMHIP_ERR_HIP, "codebook_create: sqrt image kernels");
+            std::vector<float> nh(n_words);
+            if (hipMemcpy(nh.data(), sh->word_norm, (size_t)n_words * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(ISMHIP_ERR_HIP, "codebook_create: sqrt norms copy");
+            float mx = 0.f;
+            for (float v : nh) if (v > mx || v != v) mx = v;
+            sh->max_norm2 = mx;
+            float amaxf; memcpy(&amaxf, &amax, 4);
+            const float samax = sqrtf(amaxf);                           // largest sqrt element = sqrt of the largest element
+            uint32_t samax_bits; memcpy(&samax_bits, &samax, 4);
+            rc = ism_codebook_split_bf16(ctx, sh, samax_bits);
+            if (rc != ISMHIP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(rc != ISMHIP_OK ? rc : ISMHIP_ERR_HIP, "codebook_create: sqrt 16-bit images");
+            (void)hipFree(sh->words); sh->words = nullptr;             // only the images are needed
+        }
     }
     *out = cb;
     return ISMHIP_OK;
@@ -177,6 +221,12 @@ int ismhip_codebook_destroy(ismhip_ctx* ctx, ismhip_codebook* cb) {
                     cb->vote_class, cb->vote_instance, cb->vote_bbox_quat, cb->vote_bbox_size, cb->class_sigma, cb->word_class, cb->words_bf16_hi, cb->words_f16t};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     ism_codebook_free_pca(cb);
+    if (cb->chi_shadow) {
+        ismhip_codebook* sh = cb->chi_shadow;
+        void* sp[] = {sh->words, sh->word_norm, sh->words_bf16_hi, sh->words_f16t, sh->shadow_perm};
+        for (void* p : sp) if (p) (void)hipFree(p);
+        delete sh;
+    }
     delete cb;
     return ISMHIP_OK;
 }

@@ -76,6 +76,10 @@ struct ismhip_codebook {
     float* vote_bbox_size = nullptr; // [n_votes*3]
     float* class_sigma = nullptr;    // [n_classes]
     uint32_t* word_class = nullptr;  // [n_words] Codeword::getClassId
+    // chi-square candidates on the matrix cores (Hellinger lower bound, k_knn_rerank_hell): a shadow codebook that owns the 16-bit
+    // images, norms and scales of sqrt(words); its fp32 words are not kept. Only for codebooks without negative / NaN elements.
+    ismhip_codebook* chi_shadow = nullptr;
+    uint32_t* shadow_perm = nullptr; // (in the shadow) [n_words] codebook row of every shadow row
     // ---- rotated, truncated stage-1 image of the squared-L2 search (pca.hip; pca_m == 0: not built) ----------------------------
     // rows of R = the pca_m leading eigenvectors of the codebook's second-moment matrix (orthonormal up to pca_orth_err), so
     // |R (q - c)|^2 <= sigma_max(R)^2 |q - c|^2: a score over the leading pca_m rotated coordinates is a LOWER bound of the functor value
@@ -133,6 +137,7 @@ struct ismhip_ctx {
     bool xcd_map = true;         // env ISMHIP_XCD_MAP=0: per-object kernels on the plain object-major block order instead of the XCD-local map (A/B runs)
     float grid_xfrac = 0.f;      // env ISMHIP_GRID_XFRAC: x cells this many times finer than y/z cells (default ISM_GRID_XFRAC; A/B runs)
     int shot_var = 0;            // env ISMHIP_SHOT_VAR=2: k_shot on the contiguous candidate sweep instead of 16 interleaved segments (A/B runs; same histogram)
+    bool knn_hellinger = true;   // env ISMHIP_KNN_HELLINGER=0: chi-square candidates by the VALU kernel k_knn_chi2 only (A/B runs)
     int knn_t1 = 2;              // env ISMHIP_KNN_T1 = 1 | 2: candidates kept per lane slot in stage 1 of the two-stage search (A/B runs)
     float knn_pre_gamma = 1.5f;  // env ISMHIP_KNN_PRE_GAMMA: relaxation of the pre-pass start thresholds in units of the truncated second moment (A/B runs)
     bool knn_prepass = true;     // env ISMHIP_KNN_PREPASS=0: stage 1 starts every candidate list cold instead of from the sampled pre-pass threshold (A/B runs)
@@ -144,7 +149,7 @@ struct ismhip_ctx {
 enum ScratchSlot {
     SCR_KP_OFF = 1, SCR_TIE_LIST, SCR_TIE_REC, SCR_TIE_KEYS, SCR_COUNTERS, SCR_KNN_CAND_IDX, SCR_KNN_CAND_VAL,
     SCR_QNORM, SCR_FPFH_FLAG, SCR_FPFH_LIST, SCR_FPFH_SPFH, SCR_FPFH_LOOKUP, SCR_SLOT_OFF, SCR_CLASS_BW,
-    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK, SCR_KMEANS, SCR_KNN_CLOCK, SCR_PCA, SCR_KNN_THR0
+    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK, SCR_KMEANS, SCR_KNN_CLOCK, SCR_PCA, SCR_KNN_THR0, SCR_KNN_QSQRT
 };
 
 int  ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg);

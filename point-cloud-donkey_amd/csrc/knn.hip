@@ -1304,6 +1304,7 @@ __device__ __forceinline__ float knn_abs_err(const VerifyParams& vp, float qn2) 
     return 1.01f * (vp.sqrt_dim * (dq * sqrtf(vp.cmax2) + dc * sqrtf(qn2)) + vp.sqrt_dim * vp.sqrt_dim * dq * dc);
 }
 #define KNN_U 5.9604645e-08f
+#define KNN_HELL_CPL 4            // candidates per lane of k_knn_rerank_hell (256 per query)
 
 #include "functor.h"
 
@@ -1519,6 +1520,109 @@ __global__ __launch_bounds__(256) void k_knn_rerank_pca(const float* __restrict_
     knn_queue_unproven(viol, qi, lane, flag_count, qrec, items);
 }
 
+// ---- chi-square with candidates from the squared-L2 kernels on the SQUARE-ROOT images (Hellinger lower bound) --------------------
+// For non-negative a, b: (a - b)^2 / (a + b) = (sqrt a - sqrt b)^2 (sqrt a + sqrt b)^2 / (a + b) >= (sqrt a - sqrt b)^2, because
+// (sqrt a + sqrt b)^2 >= a + b; hence  chi2(q, c) >= H(q, c) = |sqrt q - sqrt c|^2 = |sqrt q|^2 + |sqrt c|^2 - 2 sqrt q . sqrt c:
+// a dense contraction, i.e. matrix-core work, where the functor itself (utils/distance.cpp:33-52, a division per element) is not.
+// The candidate kernels score |sqrt c|^2 - 2 sqrt c . sqrt q with the error eps_s of the f16 path (VerifyParams, on the sqrt
+// vectors), so a row with score s has functor value >= LB(s) (1 - ku), LB(s) = |sqrt q|^2 (1 - 16u) + s - eps_s. As in
+// k_knn_rerank_pca the score is a lower bound, not an approximation: candidates are evaluated with the exact functor in ascending
+// order of LB until the next one cannot beat the k-th exact value; a slot is proven when LB(its bound) clears that value.
+// Only for query batches and codebooks without negative / NaN elements (the caller checks); everything else keeps k_knn_chi2.
+__global__ __launch_bounds__(256) void k_knn_rerank_hell(const float* __restrict__ words, int dim, int dim_pad, int n_words,
+                                                         const float* __restrict__ q, int nq, int ldq, const float* __restrict__ sq /* sqrt(q), ld dim_pad */,
+                                                         const uint32_t* __restrict__ perm /* candidate (shadow) row -> codebook row */,
+                                                         const int* __restrict__ cand_idx, const float* __restrict__ cand_val, int cand_stride, int n_cand,
+                                                         const float* __restrict__ cand_bound, int n_bound, VerifyParams vp,
+                                                         int k, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
+                                                         uint32_t* __restrict__ flag_count, uint32_t* __restrict__ qrec, uint32_t* __restrict__ items) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const int lane = lane_id();
+    const float* qp = q + (size_t)qi * ldq;
+    float qn2 = 0.f;                                                   // |sqrt q|^2
+    for (int i = lane; i < dim; i += 64) { const float v = sq[(size_t)qi * dim_pad + i]; qn2 += v * v; }
+    qn2 = wave_sum_f(qn2);
+    const float eps_s = (17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2) + vp.cn_acc * vp.cmax2) * 1.00001f;
+    auto lb_of = [&](float s) -> float {
+        float L = qn2 * (1.f - 16.f * KNN_U) + s - eps_s;
+        L -= 4.f * KNN_U * (qn2 + fabsf(s));
+        return L > 0.f ? L : 0.f;                                      // also NaN -> 0
+    };
+    // up to 256 candidates (the Hellinger bound is loose by up to a factor of two: dozens to hundreds of rows can lie below the
+    // best chi-square value, so the candidate stage runs eight codebook splits): KNN_HELL_CPL per lane, +inf = empty / evaluated
+    int id[KNN_HELL_CPL]; float lb[KNN_HELL_CPL]; unsigned long long key[KNN_HELL_CPL];
+#pragma unroll
+    for (int c = 0; c < KNN_HELL_CPL; ++c) {
+        const int j = lane + 64 * c;
+        id[c] = -1; lb[c] = __builtin_inff(); key[c] = ~0ull;
+        if (j < n_cand) {
+            const int x = cand_idx[(size_t)qi * cand_stride + j];
+            if (x >= 0 && x < n_words) { id[c] = (int)perm[x]; lb[c] = lb_of(cand_val[(size_t)qi * cand_stride + j]); }
+        }
+    }
+    {
+        __shared__ __attribute__((aligned(16))) float s_terms[4][1344];
+        float* sT = s_terms[threadIdx.x >> 6];
+        float kth = __builtin_inff(); int n_eval = 0;
+        for (;;) {
+            float cur = lb[0];
+#pragma unroll
+            for (int c = 1; c < KNN_HELL_CPL; ++c) cur = fminf(cur, lb[c]);
+            const float mn = wave_min_f(cur);
+            if (!(mn < __builtin_inff())) break;
+            if (n_eval >= k && mn * (1.f - vp.ku) > kth) break;
+            const unsigned long long eq = __ballot(cur == mn);
+            const int src = __ffsll((long long)eq) - 1;
+            int mine = -1, cs = 0;                                     // the owning lane's slot that holds the minimum
+#pragma unroll
+            for (int c = KNN_HELL_CPL - 1; c >= 0; --c) if (lb[c] == mn) { mine = id[c]; cs = c; }
+            const int cid = __shfl(mine, src, 64);
+            const float d = wave_functor(ISMHIP_METRIC_CHI2, qp, words + (size_t)cid * dim_pad, dim, lane, sT);
+            if (lane == src) {
+#pragma unroll
+                for (int c = 0; c < KNN_HELL_CPL; ++c) if (c == cs) { key[c] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id[c]; lb[c] = __builtin_inff(); }
+            }
+            if (++n_eval >= k) {
+                unsigned long long kk[KNN_HELL_CPL], m_ = ~0ull;
+#pragma unroll
+                for (int c = 0; c < KNN_HELL_CPL; ++c) kk[c] = key[c];
+                for (int j = 0; j < k; ++j) {
+                    unsigned long long lm = kk[0];
+#pragma unroll
+                    for (int c = 1; c < KNN_HELL_CPL; ++c) lm = kk[c] < lm ? kk[c] : lm;
+                    m_ = wave_min_u64(lm);
+#pragma unroll
+                    for (int c = 0; c < KNN_HELL_CPL; ++c) if (kk[c] == m_) kk[c] = ~0ull;
+                }
+                kth = __uint_as_float((unsigned)(m_ >> 32));
+            }
+        }
+    }
+    float bnd = __builtin_inff();
+    if (lane < n_bound) bnd = cand_bound[(size_t)qi * n_bound + lane];
+    float dk = 0.f; bool have_k = true;
+    for (int j = 0; j < k; ++j) {
+        unsigned long long lm = key[0];
+#pragma unroll
+        for (int c = 1; c < KNN_HELL_CPL; ++c) lm = key[c] < lm ? key[c] : lm;
+        const unsigned long long mn = wave_min_u64(lm);
+        if (lane == 0) {
+            if (mn == ~0ull) { idx_out[(size_t)qi * k + j] = -1; dist_out[(size_t)qi * k + j] = __builtin_nanf(""); }
+            else { idx_out[(size_t)qi * k + j] = (int)(mn & 0xffffffffull); dist_out[(size_t)qi * k + j] = __uint_as_float((unsigned)(mn >> 32)); }
+        }
+        if (mn == ~0ull) have_k = false; else dk = __uint_as_float((unsigned)(mn >> 32));
+#pragma unroll
+        for (int c = 0; c < KNN_HELL_CPL; ++c) if (key[c] == mn) key[c] = ~0ull;       // rows are unique among candidates
+    }
+    bool viol = false;
+    if (lane < n_bound && (bnd != __builtin_inff() || !(eps_s + qn2 < __builtin_inff()))) {
+        if (!have_k) viol = true;
+        else viol = !(dk < lb_of(bnd) * (1.f - vp.ku) - 1e-37f);
+    }
+    knn_queue_unproven(viol, qi, lane, flag_count, qrec, items);
+}
+
 // Exact scan for the slots that could not be proven. One WAVE per (query, slot) work item; the wave handles 4 codeword rows
 // per step (16 lanes each, 64-byte coalesced segments) with the query held in registers; direct (a-b)^2 [/(a+b)] sums pick
 // the rows that can still matter, the FLANN functor order ranks them. Each item leaves its k best (distance,row) keys in
@@ -1699,7 +1803,12 @@ __global__ void k_rule(int nq, float thr, const int32_t* __restrict__ idx3, cons
 struct KnnStage1 { uint32_t* flag_count; uint32_t* qrec; };
 template <int T>
 int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q, int k,
-            int32_t* idx_out, float* dist_out, KnnStage1* stage1 = nullptr, const char* tname = nullptr, bool many_splits = false, bool use_pca = false) {
+            int32_t* idx_out, float* dist_out, KnnStage1* stage1 = nullptr, const char* tname = nullptr, bool many_splits = false, bool use_pca = false, const float* hell_q = nullptr) {
+    // hell_q != nullptr (chi-square only): candidates come from the squared-L2 kernels run on the SQUARE-ROOT images (Hellinger lower
+    // bound, see k_knn_rerank_lb): xb = the shadow codebook that owns those images, hell_q = sqrt(q) rows of dim_pad floats
+    const bool hell = hell_q != nullptr && metric == ISMHIP_METRIC_CHI2 && cb->chi_shadow;
+    const ismhip_codebook* xb = hell ? cb->chi_shadow : cb;
+    const int cmetric = hell ? ISMHIP_METRIC_L2SQ : metric;
     if (cb->dim_pad / 16 > KNN_FB_MAXJ) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "knn: descriptor longer than 1344 not built");
     const float* qq = q; int ldq = cb->dim;
     if (cb->dim_pad != cb->dim) {
@@ -1717,14 +1826,14 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     // proofs fail and the exact scan takes over (measured: 135 ms of scan per 524288 queries). The exact-f32 MFMA contraction costs
     // 2 Nq Nc D flop at ~125 TFLOP/s, which for D <= 64 is cheaper than the 16-bit kernels' fixed overheads -- and it proves everything.
     const bool short_dim = cb->dim <= 64 && ctx->knn_mode == 0;
-    const int mode = metric != ISMHIP_METRIC_L2SQ ? -1 : (short_dim ? 2 : (ctx->knn_mode == 0 && cb->words_f16 ? 0 : (ctx->knn_mode <= 1 && cb->words_bf16_hi ? 1 : 2)));
+    const int mode = cmetric != ISMHIP_METRIC_L2SQ ? -1 : (hell ? 0 : (short_dim ? 2 : (ctx->knn_mode == 0 && cb->words_f16 ? 0 : (ctx->knn_mode <= 1 && cb->words_bf16_hi ? 1 : 2))));
     const bool use_lp = mode == 0 || mode == 1;
     const bool big_tile = use_lp && nq >= 4096 && cb->n_words_pad >= 4096 && !ctx->knn_small_tile;      // 256x256 tile, 8 waves
-    const int BM0 = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BM) : CHI_B;
-    int BNq = metric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BN) : CHI_B;
+    const int BM0 = cmetric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BM) : CHI_B;
+    int BNq = cmetric == ISMHIP_METRIC_L2SQ ? (big_tile ? 256 : KNN_BN) : CHI_B;
     const int wr_rows = big_tile ? 128 : 64;
     // (the ring kernels prefetch four slices ahead and keep the |c|^2 rows of four tiles: a tile must have at least two slices)
-    const bool use_ring = big_tile && mode == 0 && !ctx->knn_no_ring && cb->words_f16t && (cb->dim + 15) / 16 > 2;
+    const bool use_ring = big_tile && mode == 0 && !ctx->knn_no_ring && xb->words_f16t && (cb->dim + 15) / 16 > 2;
     const bool ring16 = use_ring && !ctx->knn_ring32;                  // 16x16x32 MFMA shape: 8 lane slots per query and split instead of 4
     const bool half = ring16 && ctx->knn_half;                         // 128 x 256 tile, two workgroups per CU (k_knn_l2_ring16<T, 1>)
     const bool qpanel = ring16 && !half && ctx->knn_qpanel && ((cb->dim + 15) / 16 + 1) / 2 <= 11;   // 256 x 128 tile, query panel resident in LDS
@@ -1734,10 +1843,10 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     // stage 1 of the two-stage search on the rotated, truncated image (pca.hip): same kernel, pca_m / 32 slices instead of dim / 32
     const bool pca = use_pca && use_ring && cb->pca_m > 0;
     const int ring_nk = pca ? cb->pca_m / 32 : ((cb->dim + 15) / 16 + 1) / 2;   // 32-k slices per row in the tiled images
-    const bool merged = many_splits && metric == ISMHIP_METRIC_L2SQ && use_lp && !big_tile;
-    if (metric == ISMHIP_METRIC_L2SQ) {
+    const bool merged = many_splits && cmetric == ISMHIP_METRIC_L2SQ && use_lp && !big_tile;
+    if (cmetric == ISMHIP_METRIC_L2SQ) {
         const int n_qt = (nq + BNq - 1) / BNq, n_mt = cb->n_words_pad / BM;
-        const int max_s = 64 / (slots * T);
+        const int max_s = (hell ? 64 * KNN_HELL_CPL : 64) / (slots * T);
         // at least three codebook splits (two when the candidate slots allow no more): with one, the 32 workgroups of an XCD hold 32
         // different query tiles (6 MB of f16 queries re-read per codeword tile) and fall out of its 4 MB L2; two splits halve that
         // working set (measured 21.0 -> 19.9 ms at 262144 queries), three cost the same time as two and fetch a fifth less from
@@ -1748,6 +1857,10 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         // ... as long as a workgroup still has a few dozen tiles to amortise its prologue over (10 k-word codebook, 40 tiles: 1 / 2 / 3
         // splits = 3.81 / 4.18 / 4.51 ms) and the launch fills the chip without them
         if (big_tile && n_qt >= 512) n_splits = std::min(n_splits, std::max(1, n_mt / 32));
+        // Hellinger candidates for chi-square: as many splits as the candidate slots allow (up to eight, at least four tiles each) --
+        // the bound of a proof has to lie beyond EVERY row whose Hellinger distance is below the best chi-square value, and
+        // those are dozens to hundreds (CSHOT-1344, 10 k words, measured: median 28, 90th percentile 131, 99th 352)
+        if (hell) n_splits = std::max(1, std::min(std::min(max_s, 8), n_mt / 4));
         if (ctx->knn_splits > 0) n_splits = std::max(1, std::min(std::min(max_s, n_mt), ctx->knn_splits));
         // few queries (stage 2 of the two-stage search): cut the codebook into as many splits as it takes to fill the chip; the
         // candidates of all splits are then folded into one slot of KNN_MERGE_KEEP by k_knn_merge_splits
@@ -1765,7 +1878,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         cand_per_split = T;
     }
     n_cand = n_splits * cand_per_split;
-    int n_bound = metric == ISMHIP_METRIC_L2SQ ? n_splits * slots : n_splits;
+    int n_bound = cmetric == ISMHIP_METRIC_L2SQ ? n_splits * slots : n_splits;
     float* cand_val = (float*)ism_scratch(ctx, SCR_KNN_CAND_VAL, (size_t)nq * (n_cand + n_bound + (merged ? KNN_MERGE_KEEP + 1 : 0)) * sizeof(float));
     int* cand_idx = (int*)ism_scratch(ctx, SCR_KNN_CAND_IDX, (size_t)nq * (n_cand + (merged ? KNN_MERGE_KEEP : 0)) * sizeof(int));
     // queue of unproven work: 16 counters | query records [nq*3] | items [nq*n_bound*2] | item results [nq*n_bound*4] u64
@@ -1790,10 +1903,11 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
             if (rc != ISMHIP_OK) return rc;
             ++ctx->knn_pca_launches;
         } else if (mode == 0) {
-            hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, qsc);
+            const float* cq = hell ? hell_q : qq; const int cldq = hell ? cb->dim_pad : ldq;     // Hellinger: the images are made from sqrt(q)
+            hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, ctx->stream, cq, nq, cb->dim, cldq, qsc);
             ISM_CHECK_LAUNCH(ctx, "k_absmax");
-            if (use_ring) hipLaunchKernelGGL(k_to_f16_tiled, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad / 256, ring_nk, qsc, cb->f16_scale, q_hi);
-            else hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->ld16, qsc, cb->f16_scale, q_hi);
+            if (use_ring) hipLaunchKernelGGL(k_to_f16_tiled, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, cq, nq, cb->dim, cldq, nq_pad / 256, ring_nk, qsc, xb->f16_scale, q_hi);
+            else hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, cq, nq, cb->dim, cldq, nq_pad, cb->ld16, qsc, xb->f16_scale, q_hi);
             ISM_CHECK_LAUNCH(ctx, "k_to_f16");
         } else {
             hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq, nq, cb->dim, ldq, nq_pad, cb->ld16, q_hi, q_lo);
@@ -1801,12 +1915,12 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         }
     }
     {
-        TimerScope ts(ctx, tname ? tname : (metric == ISMHIP_METRIC_L2SQ ? "knn_l2_mfma" : "knn_chi2"));
+        TimerScope ts(ctx, tname ? tname : (metric == ISMHIP_METRIC_L2SQ ? "knn_l2_mfma" : "knn_chi2"));      // chi-square: whichever kernel makes its candidates
         if (use_lp) {
             const int n_qt = (nq + BNq - 1) / BNq;
             const dim3 grid(8 * ((n_qt + 7) / 8) * n_splits);
-            const u16* wh = mode == 0 ? cb->words_f16 : cb->words_bf16_hi;
-            const u16* wl = mode == 0 ? nullptr : cb->words_bf16_lo;
+            const u16* wh = mode == 0 ? xb->words_f16 : xb->words_bf16_hi;
+            const u16* wl = mode == 0 ? nullptr : xb->words_bf16_lo;
             const int nterm = mode == 0 ? 1 : 3;
             const int kb = (nterm == 1 && !ctx->knn_kb32) ? 64 : 32;       // the two bf16x3 images only fit LDS with 32-deep slices
             const size_t lds = (size_t)2 * (BM + BNq) * kb * sizeof(u16) * (nterm == 3 ? 2 : 1) + BM * sizeof(float);
@@ -1822,7 +1936,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 else { kern = (const void*)k_knn_l2_mfma16<T, 2, 2, 2, 2, 1, 32>; ai = 5; }
             }
             if (use_ring) {
-                wh = cb->words_f16t;
+                wh = xb->words_f16t;
                 const void* rk = ring16 ? (qpanel ? (const void*)k_knn_l2_ring16<T, 2, 0, 1> : half ? (const void*)k_knn_l2_ring16<T, 1, 0> : (const void*)k_knn_l2_ring16<T, 2, 0>) : (const void*)k_knn_l2_ring<T, 0>;
 #ifdef ISM_KNN_DBG_VARIANTS
                 if (ring16) switch (ctx->knn_dbg) {       // 1 no epilogue, 2 no MFMA, 4 no DMA, 16 no fragment reads, 32 no barrier, 64 pre-test only, 256 counters
@@ -1856,7 +1970,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 else {
                     float* cn_scaled = (float*)ism_scratch(ctx, SCR_QNORM2, ((size_t)cb->n_words_pad + 256) * sizeof(float));   // the |c|^2 DMA of a 128-row tile reads 256 floats
                     if (!cn_scaled) return ISMHIP_ERR_NOMEM;
-                    hipLaunchKernelGGL(k_scale_norms, dim3((cb->n_words_pad + 255) / 256), dim3(256), 0, ctx->stream, cb->word_norm, cb->n_words_pad, osc, cn_scaled);
+                    hipLaunchKernelGGL(k_scale_norms, dim3((cb->n_words_pad + 255) / 256), dim3(256), 0, ctx->stream, xb->word_norm, cb->n_words_pad, osc, cn_scaled);
                     ISM_CHECK_LAUNCH(ctx, "k_scale_norms");
                     word_norm = cn_scaled;
                 }
@@ -1893,14 +2007,14 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
             } else {
             (void)ai;
             if (!ctx->attr_done.count(kern)) { ISM_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ctx->attr_done.insert(kern); }
-            const float* word_norm = cb->word_norm; const float* osc = (const float*)(qsc + 1);
+            const float* word_norm = xb->word_norm; const float* osc = (const float*)(qsc + 1);
             int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
             const u16* qh_ = q_hi; const u16* ql_ = q_lo;
             void* args[] = {&wh, &wl, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &ql_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb};
             ISM_HIP(ctx, hipLaunchKernel(kern, grid, dim3(big_tile ? 512 : 256), args, lds, ctx->stream));
             ISM_CHECK_LAUNCH(ctx, "k_knn_l2_mfma16");
             }
-        } else if (metric == ISMHIP_METRIC_L2SQ) {
+        } else if (cmetric == ISMHIP_METRIC_L2SQ) {
             const int n_qt = (nq + KNN_BN - 1) / KNN_BN;
             hipLaunchKernelGGL(k_knn_l2_mfma<T>, dim3(8 * ((n_qt + 7) / 8) * n_splits), dim3(256), 0, ctx->stream, cb->words, cb->word_norm,
                                cb->n_words_pad / KNN_BM, cb->dim_pad, qq, nq, ldq, tiles_per_split, n_splits, cand_val, cand_idx, n_cand,
@@ -1930,8 +2044,8 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     // relative part of the candidate kernel's dot error (see the kernels): representation + accumulation (<= 2^-23 per add, any order)
     vp.dot_rel = mode == 0 ? (2.002f * 4.8828125e-04f + 1.01f * (float)cb->dim_pad * 1.1920929e-07f)
                : mode == 1 ? (3.1f * 1.52587890625e-05f + 1.01f * 3.f * (float)cb->dim_pad * 1.1920929e-07f) : vp.ku;
-    vp.cmax2 = cb->max_norm2;
-    vp.dabs_c = mode == 0 ? 6.103515625e-05f / cb->f16_scale : 0.f;
+    vp.cmax2 = xb->max_norm2;
+    vp.dabs_c = mode == 0 ? 6.103515625e-05f / xb->f16_scale : 0.f;
     vp.dabs_q = mode == 0 ? (const float*)(qsc + 2) : nullptr;
     vp.sqrt_dim = sqrtf((float)cb->dim_pad);
     vp.cn_acc = mode == 0 ? 1.01f * (float)(cb->dim_pad + 1) * 1.1920929e-07f : 0.f;
@@ -1951,6 +2065,9 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         pv.ku = vp.ku;
         hipLaunchKernelGGL(k_knn_rerank_pca, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
                            qq, nq, ldq, cand_idx, cand_val, n_cand, n_cand, cand_bound, n_bound, pv, k, idx_out, dist_out, flag_count, qrec, items);
+    } else if (hell) {
+        hipLaunchKernelGGL(k_knn_rerank_hell, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
+                           qq, nq, ldq, hell_q, xb->shadow_perm, cand_idx, cand_val, n_cand, n_cand, cand_bound, n_bound, vp, k, idx_out, dist_out, flag_count, qrec, items);
     } else
     hipLaunchKernelGGL(k_knn_rerank, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
                        qq, nq, ldq, metric, cand_idx, cand_val, n_cand, n_cand, cand_bound, n_bound, vp, k, idx_out, dist_out, flag_count, qrec, items);
@@ -2028,6 +2145,64 @@ int run_knn_two_stage(ismhip_ctx* ctx, const ismhip_codebook* cb, int nq, const 
     return ISMHIP_OK;
 }
 
+
+// sqrt of every element (rows padded to dim_pad with zeros); flag[0] |= 1 when an element is negative or NaN
+__global__ void k_sqrt_rows(const float* __restrict__ src, int n, int dim, int ld, int dim_pad, float* __restrict__ dst, uint32_t* __restrict__ flag) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < (size_t)n * dim_pad) {
+        const int row = (int)(i / dim_pad), col = (int)(i % dim_pad);
+        float v = 0.f;
+        if (col < dim) { v = src[(size_t)row * ld + col]; bad = !(v >= 0.f); }
+        dst[i] = sqrtf(v);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+// chi-square, two stages: Hellinger candidates on the matrix cores + exact chi-square re-rank and proof (k_knn_rerank_hell); the
+// queries that stage cannot prove are gathered and go through the VALU chi-square kernel (k_knn_chi2) with its own proof and
+// exact scan. One 8-byte read-back (negative flag of the batch; later the number of unproven queries) synchronises the call.
+int run_knn_chi2_hellinger(ismhip_ctx* ctx, const ismhip_codebook* cb, int nq, const float* q, int k, int32_t* idx_out, float* dist_out, bool& taken) {
+    taken = false;
+    float* sq = (float*)ism_scratch(ctx, SCR_KNN_QSQRT, (size_t)nq * cb->dim_pad * sizeof(float) + 16);
+    if (!sq) return ISMHIP_ERR_NOMEM;
+    uint32_t* flag = (uint32_t*)(sq + (size_t)nq * cb->dim_pad);
+    ISM_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const size_t tot = (size_t)nq * cb->dim_pad;
+    hipLaunchKernelGGL(k_sqrt_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, q, nq, cb->dim, cb->dim, cb->dim_pad, sq, flag);
+    ISM_CHECK_LAUNCH(ctx, "k_sqrt_rows");
+    uint32_t neg = 0;
+    ISM_HIP(ctx, hipMemcpyAsync(&neg, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (neg) return ISMHIP_OK;                                          // not histogram data: the caller takes the VALU kernel
+    taken = true;
+    KnnStage1 s1{nullptr, nullptr};
+    int rc = run_knn<4>(ctx, cb, ISMHIP_METRIC_CHI2, nq, q, k, idx_out, dist_out, &s1, nullptr, false, false, sq);
+    if (rc != ISMHIP_OK) return rc;
+    uint32_t n2u = 0;
+    ISM_HIP(ctx, hipMemcpyAsync(&n2u, s1.flag_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->knn_stage2_queries = n2u;
+    const int n2 = (int)n2u;
+    if (n2 == 0) { ctx->knn_stats[0] = ctx->knn_stats[1] = 0; return ISMHIP_OK; }
+    float* q2 = (float*)ism_scratch(ctx, SCR_KNN_Q2, (size_t)n2 * cb->dim * sizeof(float));
+    uint32_t* list2 = (uint32_t*)ism_scratch(ctx, SCR_KNN_LIST2, (size_t)n2 * (sizeof(uint32_t) + (size_t)k * (sizeof(int32_t) + sizeof(float))));
+    if (!q2 || !list2) return ISMHIP_ERR_NOMEM;
+    int32_t* idx2 = (int32_t*)(list2 + n2);
+    float* dist2 = (float*)(idx2 + (size_t)n2 * k);
+    hipLaunchKernelGGL(k_knn_gather_flagged, dim3(n2), dim3(256), 0, ctx->stream, s1.qrec, n2, q, cb->dim, q2, list2);
+    ISM_CHECK_LAUNCH(ctx, "k_knn_gather_flagged");
+    {
+        TimerScope t2(ctx, "knn_stage2");
+        rc = k > 2 ? run_knn<4>(ctx, cb, ISMHIP_METRIC_CHI2, n2, q2, k, idx2, dist2, nullptr, "knn_chi2_valu")
+                   : run_knn<2>(ctx, cb, ISMHIP_METRIC_CHI2, n2, q2, k, idx2, dist2, nullptr, "knn_chi2_valu");
+        if (rc != ISMHIP_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_knn_scatter_results, dim3((n2 * k + 255) / 256), dim3(256), 0, ctx->stream, list2, n2, k, idx2, dist2, idx_out, dist_out);
+    ISM_CHECK_LAUNCH(ctx, "k_knn_scatter_results");
+    return ISMHIP_OK;
+}
+
 }  // namespace
 
 // bf16 hi/lo and scaled-f16 images of the codebook for k_knn_l2_mfma16 (called once from ismhip_codebook_create)
@@ -2085,6 +2260,13 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
     if (metric == ISMHIP_METRIC_L2SQ && k <= 2 && ctx->knn_t == 0 && ctx->knn_mode == 0 && ctx->knn_two_stage && cb->words_f16t && nq >= 4096 &&
         cb->n_words_pad >= 4096 && !ctx->knn_small_tile && !ctx->knn_no_ring && cb->dim > 64)
         return run_knn_two_stage(ctx, cb, nq, q, k, idx_out, dist_out);
+    // chi-square on histogram data: Hellinger candidates on the matrix cores (run_knn_chi2_hellinger); a batch with a negative element
+    // keeps the VALU kernel
+    if (metric == ISMHIP_METRIC_CHI2 && cb->chi_shadow && ctx->knn_hellinger && ctx->knn_mode == 0 && ctx->knn_t == 0 && nq >= 256 && cb->n_words >= 1024) {
+        bool taken = false;
+        const int rc = run_knn_chi2_hellinger(ctx, cb, nq, q, k, idx_out, dist_out, taken);
+        if (rc != ISMHIP_OK || taken) return rc;
+    }
     if (ctx->knn_t == 1 && k <= 1) return run_knn<1>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
     if (ctx->knn_t == 3 && k <= 3) return run_knn<3>(ctx, cb, metric, nq, q, k, idx_out, dist_out);
     if (ctx->knn_t == 2 && k <= 2) return run_knn<2>(ctx, cb, metric, nq, q, k, idx_out, dist_out);

@@ -334,6 +334,39 @@ def _knn_flagged(ctx):
     return int(ctx.timer("knn_flagged_queries")[0]), int(ctx.timer("knn_flagged_items")[0])
 
 
+@pytest.mark.parametrize("dim", [352, 1344])
+def test_knn_chi2_hellinger_candidates_match_oracle(pkg, gpu, ora, dim):
+    """chi-square on histogram data: candidates from the squared-L2 MFMA kernels on sqrt images (chi2 >= |sqrt q - sqrt c|^2), exact
+    chi-square re-rank + proof (k_knn_rerank_hell), unproven queries through the VALU kernel. Sparse non-negative rows with exact zeros
+    (sum == 0 terms), duplicates (ties to the lowest row), exact hits; a batch with ONE negative element must keep the VALU path and
+    still match. Bit-exact against the oracle's functor."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(dim)
+    n_words, nq = 6000, 3000
+    protos = rng.random((50, dim)).astype(np.float32) ** 3
+    def draw(n):
+        x = protos[rng.integers(0, 50, n)] * (0.5 + rng.random((n, dim)).astype(np.float32)) * (rng.random((n, dim)) > 0.4)
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    words, q = draw(n_words), draw(nq)
+    words[3000:3004] = words[11]
+    q[:6] = words[:6]; q[6] = words[11]
+    host, cb = _cb(pkg, gpu, words)
+    ctx.timers_enable(True)
+    try:
+        for k in (1, 2, 3):
+            idx, dist = pkg.capi.knn(ctx, cb, 1, T(q, dev), k)
+            n2 = int(ctx.timer("knn_stage2_queries")[0])
+            widx, wdist = ora.knn(1, words, q, k)
+            assert np.array_equal(idx.cpu().numpy(), widx) and np.array_equal(dist.cpu().numpy(), wdist)
+            assert n2 < nq // 2, n2                                       # the Hellinger stage proved the bulk
+        qn = q.copy(); qn[17, 5] = -1e-3
+        idx, dist = pkg.capi.knn(ctx, cb, 1, T(qn, dev), 1)
+        widx, wdist = ora.knn(1, words, qn, 1)
+        assert np.array_equal(idx.cpu().numpy(), widx) and np.array_equal(dist.cpu().numpy(), wdist)
+    finally:
+        ctx.timers_enable(False)
+
+
 def test_knn_few_unproven_slots_take_the_split_scan(pkg, gpu, ora):
     """Six identical copies of one codeword inside ONE candidate slot (rows 0-3, 8, 9 of the first tile: same wave-row block, same
     accumulator half) overflow the slot's top-4 with equal scores, so the proof fails for exactly that (query, slot) pair. With so
