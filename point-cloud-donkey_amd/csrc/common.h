@@ -137,6 +137,7 @@ struct ismhip_ctx {
     bool xcd_map = true;         // env ISMHIP_XCD_MAP=0: per-object kernels on the plain object-major block order instead of the XCD-local map (A/B runs)
     float grid_xfrac = 0.f;      // env ISMHIP_GRID_XFRAC: x cells this many times finer than y/z cells (default ISM_GRID_XFRAC; A/B runs)
     int shot_var = 0;            // env ISMHIP_SHOT_VAR=2: k_shot on the contiguous candidate sweep instead of 16 interleaved segments (A/B runs; same histogram)
+    bool knn_hell_emit = true;   // env ISMHIP_KNN_HELL_EMIT=0: queries the Hellinger proof leaves open go to the VALU kernel instead of the list-and-evaluate stage (A/B runs)
     bool knn_hellinger = true;   // env ISMHIP_KNN_HELLINGER=0: chi-square candidates by the VALU kernel k_knn_chi2 only (A/B runs)
     int knn_t1 = 2;              // env ISMHIP_KNN_T1 = 1 | 2: candidates kept per lane slot in stage 1 of the two-stage search (A/B runs)
     float knn_pre_gamma = 1.5f;  // env ISMHIP_KNN_PRE_GAMMA: relaxation of the pre-pass start thresholds in units of the truncated second moment (A/B runs)
@@ -149,7 +150,7 @@ struct ismhip_ctx {
 enum ScratchSlot {
     SCR_KP_OFF = 1, SCR_TIE_LIST, SCR_TIE_REC, SCR_TIE_KEYS, SCR_COUNTERS, SCR_KNN_CAND_IDX, SCR_KNN_CAND_VAL,
     SCR_QNORM, SCR_FPFH_FLAG, SCR_FPFH_LIST, SCR_FPFH_SPFH, SCR_FPFH_LOOKUP, SCR_SLOT_OFF, SCR_CLASS_BW,
-    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK, SCR_KMEANS, SCR_KNN_CLOCK, SCR_PCA, SCR_KNN_THR0, SCR_KNN_QSQRT
+    SCR_COMPACT_KEEP, SCR_COMPACT_POS, SCR_OBJ_COUNT, SCR_QPAD, SCR_LRF_COV, SCR_KNN_FLAGS, SCR_KNN_QSPLIT, SCR_MAX_REC, SCR_QNORM2, SCR_KNN_Q2, SCR_KNN_LIST2, SCR_TRAIN, SCR_TRAIN2, SCR_MAX_WORK, SCR_KMEANS, SCR_KNN_CLOCK, SCR_PCA, SCR_KNN_THR0, SCR_KNN_QSQRT, SCR_KNN_HELL_EMIT
 };
 
 int  ism_set_err(ismhip_ctx* ctx, int code, const std::string& msg);

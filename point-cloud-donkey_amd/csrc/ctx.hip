@@ -75,6 +75,7 @@ static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out)
     { const char* e = getenv("ISMHIP_KNN_DBG"); ctx->knn_dbg = e ? atoi(e) : 0; }
     { const char* e = getenv("ISMHIP_KNN_NORING"); ctx->knn_no_ring = e && e[0] == '1'; }
     { const char* e = getenv("ISMHIP_KNN_KB32"); ctx->knn_kb32 = e && e[0] == '1'; }
+    { const char* e = getenv("ISMHIP_KNN_HELL_EMIT"); ctx->knn_hell_emit = !(e && e[0] == '0'); }
     { const char* e = getenv("ISMHIP_KNN_HELLINGER"); ctx->knn_hellinger = !(e && e[0] == '0'); }
     { const char* e = getenv("ISMHIP_KNN_T1"); if (e) ctx->knn_t1 = atoi(e); }
     { const char* e = getenv("ISMHIP_KNN_PRE_GAMMA"); if (e) ctx->knn_pre_gamma = (float)atof(e); }

@@ -353,14 +353,18 @@ __global__ void k_to_f16_tiled(const float* __restrict__ src, int n, int dim, in
 // 16-byte segments of a row are XOR-swizzled with row bits so that both the staging stores and the fragment reads (32 rows x one
 // segment per half-wave) are bank-conflict free: 64-B rows by (row>>2)&3, 128-B rows by (row>>1)&7.
 // ld = row stride (halves) of the 16-bit images, a multiple of 64 (zero padded); k_steps = ceil(dim / 16) MFMA k-steps carry data.
-template <int T, int WR, int WC, int MI, int NI, int NTERM, int KB>
+// EMIT = 1: no candidate lists; every row whose score is <= emit_tau[query] is appended to emit_list[query * emit_cap ...] (count in
+// emit_cnt[query], which may exceed emit_cap: the caller checks). Used by the chi-square search for the queries whose Hellinger
+// proof failed: with tau derived from the best chi-square value already found, the emitted rows are ALL rows that can still beat it.
+template <int T, int WR, int WC, int MI, int NI, int NTERM, int KB, int EMIT = 0>
 __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_mfma16(const u16* __restrict__ wh, const u16* __restrict__ wl,
                                                           const float* __restrict__ word_norm, int n_tiles_m, int ld, int k_steps,
                                                           const u16* __restrict__ qh, const u16* __restrict__ ql, int nq,
                                                           const float* __restrict__ out_scale,
                                                           int tiles_per_split, int n_splits,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
-                                                          float* __restrict__ cand_bound, int bound_stride) {
+                                                          float* __restrict__ cand_bound, int bound_stride,
+                                                          const float* __restrict__ emit_tau, uint32_t* __restrict__ emit_cnt, uint32_t* __restrict__ emit_list, int emit_cap) {
     constexpr int BM = WR * MI * 32, BN = WC * NI * 32, NT = WR * WC * 64;
     constexpr int SEGS = KB / 8;                      // 16-byte segments per row
     constexpr int KS = KB / 16;                       // MFMA k-steps per slice
@@ -397,8 +401,13 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_mfma16(const u16* __
     const int fsw = (r >> SW_SH) & SW_MASK;
 
     TopT<T + 1> top[NI];
+    float tau[NI];
 #pragma unroll
-    for (int n = 0; n < NI; ++n) top[n].init();
+    for (int n = 0; n < NI; ++n) {
+        top[n].init();
+        tau[n] = -__builtin_inff();
+        if (EMIT) { const int qi_ = qtile * BN + wc * (NI * 32) + n * 32 + r; if (qi_ < nq) tau[n] = emit_tau[qi_]; }
+    }
 
     for (int mt = mt0; mt < mt1; ++mt) {
         const size_t aoff = (size_t)(mt * BM + srow) * ld + sseg * 8;
@@ -485,10 +494,28 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_mfma16(const u16* __
             for (int e = 0; e < 16; ++e) cn[e] = sCn[wr * (MI * 32) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const float tau = top[ni].v[T];
+                if (EMIT) {
+                    bool any = false;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { acc[mi][ni][e] = cn[e] + oscale * acc[mi][ni][e]; any |= acc[mi][ni][e] <= tau[ni]; }
+                    if (__any(any)) {
+                        const int qi_ = qtile * BN + wc * (NI * 32) + ni * 32 + r;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            if (acc[mi][ni][e] <= tau[ni]) {
+                                const int row_ = mt * BM + wr * (MI * 32) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                                if (row_ < cand_stride) {                // EMIT: cand_stride = number of real rows (padding rows score +inf, tau may be +inf too)
+                                    const uint32_t slot = atomicAdd(&emit_cnt[qi_], 1u);
+                                    if (slot < (uint32_t)emit_cap) emit_list[(size_t)qi_ * emit_cap + slot] = (uint32_t)row_;
+                                }
+                            }
+                    }
+                    continue;
+                }
+                const float tau_ = top[ni].v[T];
                 bool any = false;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { acc[mi][ni][e] = cn[e] + oscale * acc[mi][ni][e]; any |= acc[mi][ni][e] < tau; }
+                for (int e = 0; e < 16; ++e) { acc[mi][ni][e] = cn[e] + oscale * acc[mi][ni][e]; any |= acc[mi][ni][e] < tau_; }
                 if (__any(any)) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
@@ -497,6 +524,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_knn_l2_mfma16(const u16* __
             }
         }
     }
+    if (EMIT) return;
     // candidates: slot = split*(2*WR*T) + (wr*2 + h)*T + t; bound slot = split*(2*WR) + wr*2 + h
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -1520,6 +1548,26 @@ __global__ __launch_bounds__(256) void k_knn_rerank_pca(const float* __restrict_
     knn_queue_unproven(viol, qi, lane, flag_count, qrec, items);
 }
 
+// fast chi-square of one row by a whole wave: every lane owns the 16-byte chunks lane, lane + 64, ... of the (zero padded) rows, all
+// of a row's loads are issued before the first is used (a dependent load per element made this 10 us per row), tree sum at the end.
+// Differs from the functor's sequential sum by at most ~2 ku relative. dim_pad <= 1344 (checked by the caller): <= 6 chunks per lane.
+#define CHI_FAST_CH 6
+__device__ __forceinline__ void chi2_fast_load_q(const float* __restrict__ qp, int n4, int lane, f32x4* qv) {
+#pragma unroll
+    for (int j = 0; j < CHI_FAST_CH; ++j) { const int g = lane + 64 * j; qv[j] = g < n4 ? *(const f32x4*)(qp + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+}
+__device__ __forceinline__ float chi2_fast(const f32x4* qv, const float* __restrict__ wp, int n4, int lane) {
+    f32x4 wv[CHI_FAST_CH];
+#pragma unroll
+    for (int j = 0; j < CHI_FAST_CH; ++j) { const int g = lane + 64 * j; wv[j] = g < n4 ? *(const f32x4*)(wp + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < CHI_FAST_CH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float sm = qv[j][e] + wv[j][e], df = qv[j][e] - wv[j][e]; part += sm > 0.f ? df * df / sm : 0.f; }
+    return wave_sum_f(part);
+}
+
 // ---- chi-square with candidates from the squared-L2 kernels on the SQUARE-ROOT images (Hellinger lower bound) --------------------
 // For non-negative a, b: (a - b)^2 / (a + b) = (sqrt a - sqrt b)^2 (sqrt a + sqrt b)^2 / (a + b) >= (sqrt a - sqrt b)^2, because
 // (sqrt a + sqrt b)^2 >= a + b; hence  chi2(q, c) >= H(q, c) = |sqrt q - sqrt c|^2 = |sqrt q|^2 + |sqrt c|^2 - 2 sqrt q . sqrt c:
@@ -1551,51 +1599,85 @@ __global__ __launch_bounds__(256) void k_knn_rerank_hell(const float* __restrict
     };
     // up to 256 candidates (the Hellinger bound is loose by up to a factor of two: dozens to hundreds of rows can lie below the
     // best chi-square value, so the candidate stage runs eight codebook splits): KNN_HELL_CPL per lane, +inf = empty / evaluated
-    int id[KNN_HELL_CPL]; float lb[KNN_HELL_CPL]; unsigned long long key[KNN_HELL_CPL];
+    int id[KNN_HELL_CPL]; float lb[KNN_HELL_CPL], fd[KNN_HELL_CPL]; unsigned long long key[KNN_HELL_CPL];
 #pragma unroll
     for (int c = 0; c < KNN_HELL_CPL; ++c) {
         const int j = lane + 64 * c;
-        id[c] = -1; lb[c] = __builtin_inff(); key[c] = ~0ull;
+        id[c] = -1; lb[c] = __builtin_inff(); fd[c] = __builtin_inff(); key[c] = ~0ull;
         if (j < n_cand) {
             const int x = cand_idx[(size_t)qi * cand_stride + j];
             if (x >= 0 && x < n_words) { id[c] = (int)perm[x]; lb[c] = lb_of(cand_val[(size_t)qi * cand_stride + j]); }
         }
     }
+    // Phase 1: a FAST chi-square (lanes sum their elements, wave tree sum) for the candidates in ascending LB order. The functor's own
+    // value f (one sequential chain of dim additions, ~5 us per row at 1344 elements) differs from it by at most 3 ku f, so with
+    // mg = 4 ku: stop when the next LB exceeds the k-th fast value by (1 + mg); phase 2 then walks the sequential chain only for the
+    // rows whose fast value is within (1 + 3 mg) of that k-th value -- nothing else can be among, or tie with, the k best.
+    const float mg = 4.f * vp.ku;
+    float kth_fast = __builtin_inff();
     {
-        __shared__ __attribute__((aligned(16))) float s_terms[4][1344];
-        float* sT = s_terms[threadIdx.x >> 6];
-        float kth = __builtin_inff(); int n_eval = 0;
+        // (rows are padded with zeros to dim_pad on the codebook side; the query row is when ldq > dim, else dim is a multiple of 4
+        // whenever dim_pad == dim, so whole 16-byte chunks up to dim rounded up to 4 are safe on both sides)
+        const int n4 = (ldq >= dim_pad ? dim_pad : dim) >> 2;
+        f32x4 qv[CHI_FAST_CH];
+        chi2_fast_load_q(qp, n4, lane, qv);
+        int n_eval = 0;
         for (;;) {
             float cur = lb[0];
 #pragma unroll
             for (int c = 1; c < KNN_HELL_CPL; ++c) cur = fminf(cur, lb[c]);
             const float mn = wave_min_f(cur);
             if (!(mn < __builtin_inff())) break;
-            if (n_eval >= k && mn * (1.f - vp.ku) > kth) break;
+            if (n_eval >= k && mn * (1.f - vp.ku) > kth_fast * (1.f + mg)) break;
             const unsigned long long eq = __ballot(cur == mn);
             const int src = __ffsll((long long)eq) - 1;
-            int mine = -1, cs = 0;                                     // the owning lane's slot that holds the minimum
+            int mine = -1, cs = 0;
 #pragma unroll
             for (int c = KNN_HELL_CPL - 1; c >= 0; --c) if (lb[c] == mn) { mine = id[c]; cs = c; }
+            const int cid = __shfl(mine, src, 64);
+            float d = chi2_fast(qv, words + (size_t)cid * dim_pad, n4, lane);
+            if (d != d) d = 0.f;                                        // NaN data: keep the row for the exact chain
+            if (lane == src) {
+#pragma unroll
+                for (int c = 0; c < KNN_HELL_CPL; ++c) if (c == cs) { fd[c] = d; lb[c] = __builtin_inff(); }
+            }
+            if (++n_eval >= k) {
+                float ff[KNN_HELL_CPL], m_ = __builtin_inff();
+#pragma unroll
+                for (int c = 0; c < KNN_HELL_CPL; ++c) ff[c] = fd[c];
+                for (int j = 0; j < k; ++j) {
+                    float lm = ff[0];
+#pragma unroll
+                    for (int c = 1; c < KNN_HELL_CPL; ++c) lm = fminf(lm, ff[c]);
+                    m_ = wave_min_f(lm);
+                    const unsigned long long e2 = __ballot(lm == m_);
+                    if (lane == __ffsll((long long)e2) - 1) {            // retire ONE instance
+                        bool gone = false;
+#pragma unroll
+                        for (int c = 0; c < KNN_HELL_CPL; ++c) if (!gone && ff[c] == m_) { ff[c] = __builtin_inff(); gone = true; }
+                    }
+                }
+                kth_fast = m_;
+            }
+        }
+    }
+    // Phase 2: the functor's sequential chain for the contenders
+    {
+        __shared__ __attribute__((aligned(16))) float s_terms[4][1344];
+        float* sT = s_terms[threadIdx.x >> 6];
+        const float win = kth_fast * (1.f + 3.f * mg);
+        for (;;) {
+            int mine = -1, cs = 0;
+#pragma unroll
+            for (int c = KNN_HELL_CPL - 1; c >= 0; --c) if (fd[c] <= win && key[c] == ~0ull && id[c] >= 0) { mine = id[c]; cs = c; }
+            const unsigned long long pend = __ballot(mine >= 0);
+            if (pend == 0ull) break;
+            const int src = __ffsll((long long)pend) - 1;
             const int cid = __shfl(mine, src, 64);
             const float d = wave_functor(ISMHIP_METRIC_CHI2, qp, words + (size_t)cid * dim_pad, dim, lane, sT);
             if (lane == src) {
 #pragma unroll
-                for (int c = 0; c < KNN_HELL_CPL; ++c) if (c == cs) { key[c] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id[c]; lb[c] = __builtin_inff(); }
-            }
-            if (++n_eval >= k) {
-                unsigned long long kk[KNN_HELL_CPL], m_ = ~0ull;
-#pragma unroll
-                for (int c = 0; c < KNN_HELL_CPL; ++c) kk[c] = key[c];
-                for (int j = 0; j < k; ++j) {
-                    unsigned long long lm = kk[0];
-#pragma unroll
-                    for (int c = 1; c < KNN_HELL_CPL; ++c) lm = kk[c] < lm ? kk[c] : lm;
-                    m_ = wave_min_u64(lm);
-#pragma unroll
-                    for (int c = 0; c < KNN_HELL_CPL; ++c) if (kk[c] == m_) kk[c] = ~0ull;
-                }
-                kth = __uint_as_float((unsigned)(m_ >> 32));
+                for (int c = 0; c < KNN_HELL_CPL; ++c) if (c == cs) { key[c] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id[c]; fd[c] = __builtin_inff(); }
             }
         }
     }
@@ -2010,7 +2092,8 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
             const float* word_norm = xb->word_norm; const float* osc = (const float*)(qsc + 1);
             int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
             const u16* qh_ = q_hi; const u16* ql_ = q_lo;
-            void* args[] = {&wh, &wl, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &ql_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb};
+            const float* no_tau = nullptr; uint32_t* no_u = nullptr; int no_cap = 0;
+            void* args[] = {&wh, &wl, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &ql_, &nq_, &osc, &tps, &nsp, &cand_val, &cand_idx, &ncand, &cand_bound, &nb, &no_tau, &no_u, &no_u, &no_cap};
             ISM_HIP(ctx, hipLaunchKernel(kern, grid, dim3(big_tile ? 512 : 256), args, lds, ctx->stream));
             ISM_CHECK_LAUNCH(ctx, "k_knn_l2_mfma16");
             }
@@ -2159,6 +2242,80 @@ __global__ void k_sqrt_rows(const float* __restrict__ src, int n, int dim, int l
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
+// ---- chi-square, k = 1: the queries the Hellinger proof left open ------------------------------------------------------------------
+// Such a query has dozens to hundreds of rows whose Hellinger distance lies below its best chi-square value (more than fixed-size
+// candidate lists hold), but stage 1 has already found a very good -- usually the -- nearest row, with exact value dk. Every row
+// that can still beat or tie it has LB(score) (1 - ku) <= dk, i.e. score <= tau(dk): k_hell_tau computes tau per query, the EMIT
+// variant of k_knn_l2_mfma16 sweeps the sqrt images once more and appends exactly those rows to a per-query list, k_hell_fast
+// evaluates a fast chi-square for every listed row (a wave each), k_hell_final walks the functor's sequential chain for the rows
+// within rounding of the smallest fast value and writes the winner. Proof by construction: a row that is not listed cannot win.
+#define HELL_EMIT_CAP 2048
+__global__ __launch_bounds__(256) void k_hell_tau(int n2, const uint32_t* __restrict__ list2, const float* __restrict__ sq2, int dim, int dim_pad,
+                                                  const float* __restrict__ dist_out, VerifyParams vp, float* __restrict__ tau) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n2) return;
+    const int lane = lane_id();
+    float qn2 = 0.f;
+    for (int c = lane; c < dim; c += 64) { const float v = sq2[(size_t)i * dim_pad + c]; qn2 += v * v; }
+    qn2 = wave_sum_f(qn2);
+    if (lane == 0) {
+        const float dk = dist_out[list2[i]];                             // k = 1: the best exact value of stage 1 (NaN: no candidate at all)
+        const float eps_s = (17.f * KNN_U * vp.cmax2 + (2.f * vp.dot_rel + 2.f * KNN_U) * sqrtf(qn2 * vp.cmax2) + 2.f * knn_abs_err(vp, qn2) + vp.cn_acc * vp.cmax2) * 1.00001f;
+        // not emitted  <=>  score > tau  =>  LB(score) (1 - ku) > dk  (LB as in k_knn_rerank_hell, |score| <= |sqrt q|^2 + |sqrt c|max^2)
+        float t = dk * (1.f + 2.f * vp.ku) - qn2 * (1.f - 16.f * KNN_U) + eps_s + 8.f * KNN_U * (qn2 + vp.cmax2 + dk);
+        if (!(dk == dk)) t = __builtin_inff();                           // nothing found so far: everything is a candidate (the cap will tell)
+        tau[i] = t;
+    }
+}
+// one workgroup per query: its four waves evaluate the fast chi-square of the listed rows, wave 0 then walks the sequential chain
+// for the rows within rounding of the smallest fast value (together with stage 1's answer) and writes the winner
+__global__ __launch_bounds__(256) void k_hell_eval(int n2, const uint32_t* __restrict__ list2, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ rows, int cap,
+                                                   const uint32_t* __restrict__ perm, const float* __restrict__ q, int dim, const float* __restrict__ words, int dim_pad, float ku,
+                                                   int32_t* __restrict__ idx_out, float* __restrict__ dist_out, uint32_t* __restrict__ overflow) {
+    __shared__ float s_fast[HELL_EMIT_CAP];
+    __shared__ __attribute__((aligned(16))) float s_terms[1344];
+    const int i = blockIdx.x;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t qi = list2[i];
+    const uint32_t n = cnt[i];
+    if (n > (uint32_t)cap) { if (threadIdx.x == 0) atomicAdd(overflow, 1u); return; }
+    const float* qp = q + (size_t)qi * dim;
+    {
+        const int n4 = dim >> 2;                                        // the caller's rows are dim floats apart: whole chunks only when dim % 4 == 0 (checked on the host)
+        f32x4 qv[CHI_FAST_CH];
+        chi2_fast_load_q(qp, n4, lane, qv);
+        for (uint32_t s_ = wv; s_ < n; s_ += 4) {
+            const float part = chi2_fast(qv, words + (size_t)perm[rows[(size_t)i * cap + s_]] * dim_pad, n4, lane);
+            if (lane == 0) s_fast[s_] = part;
+        }
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    float mn = __builtin_inff();
+    for (uint32_t s_ = lane; s_ < n; s_ += 64) mn = fminf(mn, s_fast[s_]);
+    mn = wave_min_f(mn);
+    const float win = mn * (1.f + 12.f * ku);                            // fast and chain values differ by <= 3 ku each way (see k_knn_rerank_hell)
+    unsigned long long best = ~0ull;
+    {
+        const int id0 = idx_out[qi];                                     // stage 1's answer stays in the race
+        if (id0 >= 0) best = ((unsigned long long)__float_as_uint(dist_out[qi]) << 32) | (unsigned)id0;
+    }
+    for (uint32_t s0 = 0; s0 < n; s0 += 64) {
+        const uint32_t s_ = s0 + lane;
+        const bool in = s_ < n && !(s_fast[s_] > win);
+        unsigned long long pend = __ballot(in);
+        const int row = in ? (int)perm[rows[(size_t)i * cap + s_]] : -1;
+        while (pend) {
+            const int src = __ffsll((long long)pend) - 1; pend &= pend - 1;
+            const int cid = __shfl(row, src, 64);
+            const float d = wave_functor(ISMHIP_METRIC_CHI2, qp, words + (size_t)cid * dim_pad, dim, lane, s_terms);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)cid;
+            best = key < best ? key : best;
+        }
+    }
+    if (lane == 0 && best != ~0ull) { idx_out[qi] = (int)(best & 0xffffffffull); dist_out[qi] = __uint_as_float((unsigned)(best >> 32)); }
+}
+
 // chi-square, two stages: Hellinger candidates on the matrix cores + exact chi-square re-rank and proof (k_knn_rerank_hell); the
 // queries that stage cannot prove are gathered and go through the VALU chi-square kernel (k_knn_chi2) with its own proof and
 // exact scan. One 8-byte read-back (negative flag of the batch; later the number of unproven queries) synchronises the call.
@@ -2192,6 +2349,59 @@ int run_knn_chi2_hellinger(ismhip_ctx* ctx, const ismhip_codebook* cb, int nq, c
     float* dist2 = (float*)(idx2 + (size_t)n2 * k);
     hipLaunchKernelGGL(k_knn_gather_flagged, dim3(n2), dim3(256), 0, ctx->stream, s1.qrec, n2, q, cb->dim, q2, list2);
     ISM_CHECK_LAUNCH(ctx, "k_knn_gather_flagged");
+    if (k == 1 && ctx->knn_hell_emit) {
+        // k = 1: list every row that can still beat stage 1's answer and evaluate those (see k_hell_tau)
+        uint32_t over = 0;
+        {
+        TimerScope t2(ctx, "knn_stage2");
+        const ismhip_codebook* xb = cb->chi_shadow;
+        const int dp = cb->dim_pad, cap = HELL_EMIT_CAP;
+        const int n2p = (n2 + 127) / 128 * 128;
+        const size_t b_sq2 = (size_t)n2 * dp * 4, b_tau = (size_t)n2p * 4, b_cnt = (size_t)n2p * 4 + 64, b_rows = (size_t)n2 * cap * 4, b_img = (size_t)n2p * cb->ld16 * 2;
+        char* buf = (char*)ism_scratch(ctx, SCR_KNN_HELL_EMIT, b_sq2 + b_tau + b_cnt + b_rows + b_img + 64);
+        if (!buf) return ISMHIP_ERR_NOMEM;
+        float* sq2 = (float*)buf; float* tau = (float*)(buf + b_sq2); uint32_t* cnt = (uint32_t*)(buf + b_sq2 + b_tau);
+        uint32_t* sc = cnt + n2p;                                       // [0..2] f16 scalars of the gathered batch, [8] overflow counter
+        uint32_t* rows = (uint32_t*)(buf + b_sq2 + b_tau + b_cnt); u16* qimg = (u16*)(buf + b_sq2 + b_tau + b_cnt + b_rows);
+        ISM_HIP(ctx, hipMemsetAsync(cnt, 0, b_cnt, ctx->stream));
+        hipLaunchKernelGGL(k_knn_gather_flagged, dim3(n2), dim3(256), 0, ctx->stream, s1.qrec, n2, (const float*)sq, dp, sq2, list2);
+        ISM_CHECK_LAUNCH(ctx, "k_knn_gather_flagged");
+        hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, ctx->stream, (const float*)sq2, n2, cb->dim, dp, sc);
+        ISM_CHECK_LAUNCH(ctx, "k_absmax");
+        const size_t tot = (size_t)n2p * cb->ld16;
+        hipLaunchKernelGGL(k_to_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)sq2, n2, cb->dim, dp, n2p, cb->ld16, sc, xb->f16_scale, qimg);
+        ISM_CHECK_LAUNCH(ctx, "k_to_f16");
+        VerifyParams vp;
+        vp.ku = 1.01f * (float)dp * KNN_U;
+        vp.dot_rel = 2.002f * 4.8828125e-04f + 1.01f * (float)dp * 1.1920929e-07f;
+        vp.cmax2 = xb->max_norm2; vp.dabs_c = 6.103515625e-05f / xb->f16_scale; vp.dabs_q = (const float*)(sc + 2);
+        vp.sqrt_dim = sqrtf((float)dp); vp.cn_acc = 0.f;
+        hipLaunchKernelGGL(k_hell_tau, dim3((n2 + 3) / 4), dim3(256), 0, ctx->stream, n2, (const uint32_t*)list2, (const float*)sq2, cb->dim, dp, (const float*)dist_out, vp, tau);
+        ISM_CHECK_LAUNCH(ctx, "k_hell_tau");
+        {
+            const void* kern = (const void*)k_knn_l2_mfma16<4, 2, 2, 2, 2, 1, 64, 1>;
+            const size_t lds = (size_t)2 * (128 + 128) * 64 * sizeof(u16) + 128 * sizeof(float);
+            if (!ctx->attr_done.count(kern)) { ISM_HIP(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ctx->attr_done.insert(kern); }
+            const int n_qt = n2p / 128, n_mt = cb->n_words_pad / 128;
+            int nsp = std::max(1, std::min(n_mt / 2, (2048 + 8 * ((n_qt + 7) / 8) - 1) / (8 * ((n_qt + 7) / 8))));
+            int tps = (n_mt + nsp - 1) / nsp; nsp = (n_mt + tps - 1) / tps;
+            const u16* wh = xb->words_f16; const u16* wl = nullptr; const float* word_norm = xb->word_norm; const float* osc = (const float*)(sc + 1);
+            int n_tiles_m = n_mt, ld16 = cb->ld16, k_steps = (cb->dim + 15) / 16, nq_ = n2, ncand = cb->n_words, nb = 0, cap_ = cap;
+            const u16* qh_ = qimg; const u16* ql_ = nullptr; float* nf = nullptr; int* ni = nullptr; const float* tau_ = tau;
+            void* args[] = {&wh, &wl, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &ql_, &nq_, &osc, &tps, &nsp, &nf, &ni, &ncand, &nf, &nb, &tau_, &cnt, &rows, &cap_};
+            ISM_HIP(ctx, hipLaunchKernel(kern, dim3(8 * ((n_qt + 7) / 8) * nsp), dim3(256), args, lds, ctx->stream));
+            ISM_CHECK_LAUNCH(ctx, "k_knn_l2_mfma16<emit>");
+        }
+        hipLaunchKernelGGL(k_hell_eval, dim3(n2), dim3(256), 0, ctx->stream, n2, (const uint32_t*)list2, (const uint32_t*)cnt, (const uint32_t*)rows, cap,
+                           (const uint32_t*)xb->shadow_perm, q, cb->dim, (const float*)cb->words, dp, vp.ku, idx_out, dist_out, sc + 8);
+        ISM_CHECK_LAUNCH(ctx, "k_hell_eval");
+        ISM_HIP(ctx, hipMemcpyAsync(&over, sc + 8, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        ctx->knn_stats[0] = over; ctx->knn_stats[1] = 0;
+        if (over == 0) return ISMHIP_OK;                                // every list fitted: done
+        // some query has more than HELL_EMIT_CAP rows below its best value: the VALU kernel answers for all gathered queries
+    }
     {
         TimerScope t2(ctx, "knn_stage2");
         rc = k > 2 ? run_knn<4>(ctx, cb, ISMHIP_METRIC_CHI2, n2, q2, k, idx2, dist2, nullptr, "knn_chi2_valu")
@@ -2262,7 +2472,7 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
         return run_knn_two_stage(ctx, cb, nq, q, k, idx_out, dist_out);
     // chi-square on histogram data: Hellinger candidates on the matrix cores (run_knn_chi2_hellinger); a batch with a negative element
     // keeps the VALU kernel
-    if (metric == ISMHIP_METRIC_CHI2 && cb->chi_shadow && ctx->knn_hellinger && ctx->knn_mode == 0 && ctx->knn_t == 0 && nq >= 256 && cb->n_words >= 1024) {
+    if (metric == ISMHIP_METRIC_CHI2 && cb->chi_shadow && ctx->knn_hellinger && ctx->knn_mode == 0 && ctx->knn_t == 0 && nq >= 256 && cb->n_words >= 1024 && cb->dim % 4 == 0) {
         bool taken = false;
         const int rc = run_knn_chi2_hellinger(ctx, cb, nq, q, k, idx_out, dist_out, taken);
         if (rc != ISMHIP_OK || taken) return rc;
