@@ -88,11 +88,29 @@ CONFIGS = {
 }
 
 
+def visible_gpus():
+    """GPUs this process may use, WITHOUT touching the HIP runtime (a launcher that initialised the GPU must not start the ranks):
+    the visible-devices variables if set, else the KFD topology (nodes with SIMDs are GPUs). None = unknown (the ranks then validate
+    their own LOCAL_RANK)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    try:
+        for node in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            for line in open(node):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        return None
+    return n or None
+
+
 def spawn_ranks(args):
     """--gpus N without a launcher: start the N ranks as a child torch.distributed.run BEFORE this process touches a GPU."""
-    import torch                                   # device_count() does not initialise the GPU on this image
-    have = torch.cuda.device_count()
-    if have < args.gpus:
+    have = visible_gpus()
+    if have is not None and have < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible; refusing to run fewer ranks than asked\n")
         return 2
     s = socket.socket()

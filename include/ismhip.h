@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ISMHIP_ABI_VERSION 3
+#define ISMHIP_ABI_VERSION 4
 
 #define ISMHIP_OK               0
 #define ISMHIP_ERR_INVALID     -1   /* bad argument (null pointer, negative size, unsupported value) */
@@ -56,6 +56,13 @@ extern "C" {
  * the search radius, suppressNeighborMaxima2 :227-268; "Merge" is not built) */
 #define ISMHIP_MAXFILTER_NONE   0
 #define ISMHIP_MAXFILTER_SIMPLE 1
+#define ISMHIP_MAXFILTER_MERGE  2
+/* Voting.SingleObjectMaxType in SingleObjectMode (voting_mean_shift.cpp:80, 124-157; maxima_handler.h:45-46): "Default" / "None" (and
+ * every type outside single-object mode) run the mean shift; the other three place ONE maximum per class at the cloud centroid */
+#define ISMHIP_SOM_MEANSHIFT              0
+#define ISMHIP_SOM_BANDWIDTH              1
+#define ISMHIP_SOM_MODEL_RADIUS           2
+#define ISMHIP_SOM_COMPLETE_VOTING_SPACE  3
 
 #define ISMHIP_SHOT_DIM   352
 #define ISMHIP_CSHOT_DIM 1344
@@ -107,6 +114,9 @@ int  ismhip_estimate_normals(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius,
 int  ismhip_estimate_normals_pca(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, int orientation, float* nx_out, float* ny_out, float* nz_out);
 /* per-object centroid (features_shot.cpp:45-51) -> centroid_out[n_obj*3] */
 int  ismhip_cloud_centroids(ismhip_ctx* ctx, const ismhip_cloud* cloud, float* centroid_out);
+/* SingleObjectHelper::getModelRadius (voting/single_object_mode_helper.cpp:15-27): per object the largest distance of a (finite)
+ * point from centroid[n_obj*3] (device, e.g. ismhip_cloud_centroids) -> radius_out[n_obj] (device) */
+int  ismhip_cloud_radii(ismhip_ctx* ctx, const ismhip_cloud* cloud, const float* centroid, float* radius_out);
 
 /* ---- local reference frames: Features::computeSHOTReferenceFrames (features/features.cpp:238-252)
  *      -> pcl::SHOTLocalReferenceFrameEstimationOMP (arithmetic as third_party/pcl_shot_na_lrf/shot_na_lrf.hpp:48-178
@@ -231,8 +241,16 @@ typedef struct ismhip_maxima_params {
     float min_threshold;            /* Voting.MinThreshold (negative = relative to best) */
     int   best_k;                   /* Voting.BestK (<=0: all) */
     int   max_maxima;               /* capacity of the output per object */
-    int   max_filter;               /* Voting.MaxFilterType: ISMHIP_MAXFILTER_NONE | _SIMPLE (MaximaHandler::filterMaxima, maxima_handler.cpp:272-296);
-                                       not applied in single-object mode: pass NONE there (voting.cpp:262-268) */
+    int   max_filter;               /* Voting.MaxFilterType: ISMHIP_MAXFILTER_NONE | _SIMPLE | _MERGE (MaximaHandler::filterMaxima,
+                                       maxima_handler.cpp:272-440); not applied in single-object mode: pass NONE there (voting.cpp:262-268) */
+    /* ---- ABI 4 (zero-initialise the struct: all of these are optional) */
+    const float* vote_bbox_quat;    /* device [n_slots*4] (w,x,y,z), the vote_bbox_quat_out of ismhip_cast_votes: Voting.AverageRotation
+                                       (voting.cpp:210-215, Utils::quatWeightedAverage utils.cpp:617-665; see DESIGN.md §7 for the
+                                       eigenvector choice); NULL = off */
+    float* max_bbox_quat_out;       /* device [n_obj*max_maxima*4]; required iff vote_bbox_quat is given */
+    int   single_object_max_type;   /* ISMHIP_SOM_* */
+    const float* object_centroid;   /* device [n_obj*3]: ismhip_cloud_centroids of the objects' clouds (ISMHIP_SOM_BANDWIDTH and up) */
+    const float* object_radius;     /* device [n_obj]: ismhip_cloud_radii (ISMHIP_SOM_MODEL_RADIUS) */
 } ismhip_maxima_params;
 
 /* slot_offsets_h[n_obj+1]: vote-slot range of each object. Outputs per object o, maximum m (sorted by
@@ -301,6 +319,9 @@ typedef struct ismhip_hough_params {
     int   best_k;                   /* Voting.BestK (<=0: all) */
     int   max_maxima;               /* capacity of the output per object */
     int   max_filter;               /* as ismhip_maxima_params.max_filter; the radius is bin_size / 2 (voting_hough_3d.cpp:45) */
+    /* ---- ABI 4 (zero-initialise the struct) */
+    const float* vote_bbox_quat;    /* Voting.AverageRotation, as in ismhip_maxima_params */
+    float* max_bbox_quat_out;
 } ismhip_hough_params;
 int  ismhip_hough3d_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* slot_offsets_h,
                            const float* vote_pos, const float* vote_weight, const int32_t* vote_class,

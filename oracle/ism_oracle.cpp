@@ -692,13 +692,48 @@ void suppress_neighbor_maxima(const std::vector<V3>& centers, const std::vector<
 
 struct Maximum {
     V3 pos; float weight; int cls; int inst; float inst_weight; V3 bbox; int n_votes;
+    float quat[4] = {1.f, 0.f, 0.f, 0.f};
 };
+
+// Utils::quatWeightedAverage (utils/utils.cpp:617-665): scatter matrix sum w q q^T (float sums, member order), then an eigenvector.
+// The reference takes whichever eigenvector Eigen::EigenSolver lists FIRST (its loop over "eigenvalues.cols()" only ever looks at
+// index 0 of an unordered general solver): not reproducible. This restatement and the HIP path take the eigenvector of the LARGEST
+// eigenvalue of the symmetric matrix (cyclic Jacobi in double) with its first non-zero component positive. Parity unpinned.
+void quat_from_scatter(const float* S, float* q) {
+    double A[4][4] = {{S[0], S[1], S[2], S[3]}, {S[1], S[4], S[5], S[6]}, {S[2], S[5], S[7], S[8]}, {S[3], S[6], S[8], S[9]}};
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+        if (!(off > 1e-30)) break;
+        for (int p = 0; p < 3; ++p) for (int r = p + 1; r < 4; ++r) {
+            if (std::fabs(A[p][r]) < 1e-300) continue;
+            const double theta = (A[r][r] - A[p][p]) / (2.0 * A[p][r]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+            const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+            for (int k = 0; k < 4; ++k) { const double x = A[k][p], y = A[k][r]; A[k][p] = c * x - sn * y; A[k][r] = sn * x + c * y; }
+            for (int k = 0; k < 4; ++k) { const double x = A[p][k], y = A[r][k]; A[p][k] = c * x - sn * y; A[r][k] = sn * x + c * y; }
+            for (int k = 0; k < 4; ++k) { const double x = V[k][p], y = V[k][r]; V[k][p] = c * x - sn * y; V[k][r] = sn * x + c * y; }
+        }
+    }
+    int best = 0;
+    for (int i = 1; i < 4; ++i) if (A[i][i] > A[best][best]) best = i;
+    double v[4] = {V[0][best], V[1][best], V[2][best], V[3][best]};
+    double sgn = 1.0;
+    for (int i = 0; i < 4; ++i) if (v[i] != 0.0) { sgn = v[i] < 0 ? -1.0 : 1.0; break; }
+    for (int i = 0; i < 4; ++i) q[i] = static_cast<float>(sgn * v[i]);
+}
+void quat_scatter_add(float* S, float w, const float* q) {
+    S[0] += w * q[0] * q[0]; S[1] += w * q[0] * q[1]; S[2] += w * q[0] * q[2]; S[3] += w * q[0] * q[3];
+    S[4] += w * q[1] * q[1]; S[5] += w * q[1] * q[2]; S[6] += w * q[1] * q[3];
+    S[7] += w * q[2] * q[2]; S[8] += w * q[2] * q[3]; S[9] += w * q[3] * q[3];
+}
 
 
 // Voting::findMaxima per-maximum block (voting.cpp:131-236): instance id by the largest summed weight (ties and the map order
 // give the smallest id), weight = sum of the cluster's vote weights, weighted mean bounding-box size.
 void append_maximum(const std::vector<MSVote>& votes, const std::vector<V3>& vbbox, const std::vector<int>& cluster, const V3& pos, int c,
-                    int min_votes_threshold, std::vector<Maximum>& maxima) {
+                    int min_votes_threshold, std::vector<Maximum>& maxima, const float* vbq = nullptr) {
     if (static_cast<int>(cluster.size()) < min_votes_threshold || cluster.empty()) return;
     std::map<unsigned, float> instance_weights;
     for (int vi : cluster) {
@@ -721,7 +756,56 @@ void append_maximum(const std::vector<MSVote>& votes, const std::vector<V3>& vbb
     m.weight = maxWeight;
     bs[0] /= maxWeight; bs[1] /= maxWeight; bs[2] /= maxWeight;
     m.bbox = bs;
+    if (vbq) {                                     // Voting.AverageRotation (voting.cpp:186-215)
+        float S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int vi : cluster) quat_scatter_add(S, votes[vi].w, vbq + static_cast<size_t>(votes[vi].slot) * 4);
+        quat_from_scatter(S, m.quat);
+    }
     maxima.push_back(m);
+}
+
+// MaximaHandler::filterMaxima "Merge" = mergeAndFilterMaxima(maxima, true) (maxima_handler.cpp:300-387) with mergeMaxima (:390-440).
+// The list enters in class order, then iFindMaxima order (the reference's order inside a class is unordered: omp critical push).
+// merged_maxima starts with maxima.size() default-constructed entries (weight 0): they only matter if no merged weight is > 0.
+void filter_maxima_merge(std::vector<Maximum>& maxima, const float* class_bw, float bandwidth) {
+    auto sdist = [&](int cls) { return class_bw ? class_bw[cls] : bandwidth; };
+    std::vector<Maximum> out;
+    std::vector<bool> dirty(maxima.size(), false);
+    for (size_t i = 0; i < maxima.size(); ++i) {
+        if (dirty[i]) continue;
+        const float sd = sdist(maxima[i].cls);
+        std::vector<size_t> close;
+        for (size_t j = i + 1; j < maxima.size(); ++j) {
+            if (dirty[j]) continue;
+            const float dist = norm3(maxima[j].pos.data(), maxima[i].pos.data());
+            if (dist < sd && sdist(maxima[j].cls) <= sd) { close.push_back(j); dirty[j] = true; }
+        }
+        if (close.empty()) { out.push_back(maxima[i]); continue; }
+        close.push_back(i);
+        std::map<unsigned, std::vector<size_t>> same;                       // class id -> members in list order
+        for (size_t x : close) same[static_cast<unsigned>(maxima[x].cls)].push_back(x);
+        Maximum best; best.weight = 0; best.cls = -1; best.inst = -1; best.inst_weight = 0; best.pos = {0, 0, 0}; best.bbox = {0, 0, 0}; best.n_votes = 0;
+        bool have = false;
+        for (auto& kv : same) {
+            Maximum r; r.pos = {0, 0, 0}; r.weight = 0; r.bbox = {0, 0, 0}; r.n_votes = 0; r.cls = -1; r.inst = -1; r.inst_weight = 0;
+            std::map<unsigned, float> inst;
+            for (size_t x : kv.second) {
+                const Maximum& m = maxima[x];
+                for (int d = 0; d < 3; ++d) r.pos[d] = (r.pos[d] * r.weight + m.pos[d] * m.weight) / (r.weight + m.weight);
+                for (int d = 0; d < 3; ++d) r.bbox[d] = (r.bbox[d] * r.weight + m.bbox[d] * m.weight) / (r.weight + m.weight);
+                { float S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; quat_scatter_add(S, r.weight, r.quat); quat_scatter_add(S, m.weight, m.quat); quat_from_scatter(S, r.quat); }
+                r.cls = m.cls; r.weight += m.weight; r.n_votes += m.n_votes;
+                auto it = inst.find(static_cast<unsigned>(m.inst));
+                if (it != inst.end()) it->second += m.inst_weight; else inst.insert({static_cast<unsigned>(m.inst), m.inst_weight});
+                unsigned max_id = 0; float bw = 0; bool hv = false;
+                for (auto& e : inst) if (e.second > bw) { bw = e.second; max_id = e.first; hv = true; }
+                r.inst = hv ? static_cast<int>(max_id) : -1; r.inst_weight = hv ? inst[max_id] : 0.f;
+            }
+            if (r.weight > best.weight) { best = r; have = true; }
+        }
+        if (have) out.push_back(best);
+    }
+    maxima.swap(out);
 }
 
 // Voting::findMaxima tail (voting.cpp:272, 298-323, 441-462): sort, normalise, MinThreshold, BestK, outputs of one object
@@ -745,7 +829,8 @@ void filter_maxima_simple(std::vector<Maximum>& maxima, float radius) {
 }
 
 void finish_object(std::vector<Maximum>& maxima, int o, int C, int cap, float min_threshold, int best_k,
-                   int32_t* n_max_out, float* mpos, float* mw, int32_t* mcls, int32_t* minst, float* miw, float* mbs, int32_t* mnv, float* class_score) {
+                   int32_t* n_max_out, float* mpos, float* mw, int32_t* mcls, int32_t* minst, float* miw, float* mbs, int32_t* mnv, float* class_score,
+                   float* mbq = nullptr) {
         // sort (stable; std::sort in the reference leaves equal weights unordered), voting.cpp:272
         std::stable_sort(maxima.begin(), maxima.end(), [](const Maximum& a, const Maximum& b) { return a.weight > b.weight; });
         // normalizeWeights :441-462
@@ -772,6 +857,7 @@ void finish_object(std::vector<Maximum>& maxima, int o, int C, int cap, float mi
             mw[t] = ok ? maxima[i].weight : 0.f; mcls[t] = ok ? maxima[i].cls : -1; minst[t] = ok ? maxima[i].inst : -1;
             miw[t] = ok ? maxima[i].inst_weight : 0.f; mnv[t] = ok ? maxima[i].n_votes : 0;
             if (mbs) { mbs[t * 3] = ok ? maxima[i].bbox[0] : 0.f; mbs[t * 3 + 1] = ok ? maxima[i].bbox[1] : 0.f; mbs[t * 3 + 2] = ok ? maxima[i].bbox[2] : 0.f; }
+            if (mbq) for (int d = 0; d < 4; ++d) mbq[t * 4 + d] = ok ? maxima[i].quat[d] : (d == 0 ? 1.f : 0.f);
         }
 }
 }  // namespace
@@ -1166,8 +1252,7 @@ int ismref_create_seeds(int n, const float* pos, const float* w, float bin_size,
 
 /* Voting::findMaxima + VotingMeanShift::iFindMaxima (ref: voting/voting.cpp:79-328, voting_mean_shift.cpp:39-177).
  * Votes of one class are taken in slot order (the reference's order is nondeterministic, voting.cpp:73-76).
- * Out of scope here as in the product: RANSAC vote filter, global features, single-object max types other
- * than "None"/"Default", quaternion averaging (bbox rotation is not reported). */
+ * Out of scope here as in the product: RANSAC vote filter, global features. */
 int ismref_find_maxima(int n_obj, const uint32_t* so, const float* vpos, const float* vw, const int32_t* vcls,
                        const int32_t* vinst, const float* vbs, const ismref_maxima_params* P,
                        int32_t* n_max_out, float* mpos, float* mw, int32_t* mcls, int32_t* minst, float* miw,
@@ -1188,7 +1273,23 @@ int ismref_find_maxima(int n_obj, const uint32_t* so, const float* vpos, const f
                 vbbox.push_back(vbs ? V3{vbs[s * 3], vbs[s * 3 + 1], vbs[s * 3 + 2]} : V3{0, 0, 0});
             }
             if (votes.empty()) continue;            // class not present in m_votes
-            const float h = P->class_bandwidth ? P->class_bandwidth[c] : P->bandwidth;   // :48-49
+            float h = P->class_bandwidth ? P->class_bandwidth[c] : P->bandwidth;   // :48-49
+            if (P->single_object_max_type != 0) {
+                // voting_mean_shift.cpp:124-157: one maximum at the cloud centroid; bandwidth = the class's search distance |
+                // SingleObjectHelper::getModelRadius | getVotingSpaceSize (single_object_mode_helper.cpp:15-40)
+                const float* q = P->object_centroid + static_cast<size_t>(o) * 3;
+                if (P->single_object_max_type == 2) h = P->object_radius[o];
+                else if (P->single_object_max_type == 3) {
+                    float md = 0;
+                    for (auto& v : votes) { const float dx = v.p[0] - q[0], dy = v.p[1] - q[1], dz = v.p[2] - q[2]; const float d = dx * dx + dy * dy + dz * dz; md = md > d ? md : d; }
+                    h = std::sqrt(md);
+                }
+                const V3 pos = {q[0], q[1], q[2]};
+                std::vector<int> cluster;
+                (void)estimate_density(votes, pos.data(), h, P->kernel, true, &cluster, nb);
+                append_maximum(votes, vbbox, cluster, pos, c, P->min_votes_threshold, maxima, P->vote_bbox_quat);
+                continue;
+            }
             std::vector<MSVote> seeds;
             create_seeds(votes, (h * 2.0f) / sqrtf(2), seeds);                              // :33-37, :83
             // iDoMeanShift :201-244
@@ -1221,11 +1322,12 @@ int ismref_find_maxima(int n_obj, const uint32_t* so, const float* vpos, const f
                 std::vector<int> cluster;
                 float density = estimate_density(votes, pos.data(), h, P->kernel, true, &cluster, nb);
                 (void)density;
-                append_maximum(votes, vbbox, cluster, pos, c, P->min_votes_threshold, maxima);
+                append_maximum(votes, vbbox, cluster, pos, c, P->min_votes_threshold, maxima, P->vote_bbox_quat);
             }
         }
         if (P->max_filter == 1) filter_maxima_simple(maxima, P->bandwidth);
-        finish_object(maxima, o, C, cap, P->min_threshold, P->best_k, n_max_out, mpos, mw, mcls, minst, miw, mbs, mnv, class_score);
+        if (P->max_filter == 2) filter_maxima_merge(maxima, P->class_bandwidth, P->bandwidth);
+        finish_object(maxima, o, C, cap, P->min_threshold, P->best_k, n_max_out, mpos, mw, mcls, minst, miw, mbs, mnv, class_score, P->max_bbox_quat_out);
     }
     return 0;
 }
@@ -1325,11 +1427,12 @@ int ismref_hough3d_maxima(int n_obj, const uint32_t* so, const float* vpos, cons
                     cx += votes[vi].p[0] * votes[vi].w; cy += votes[vi].p[1] * votes[vi].w; cz += votes[vi].p[2] * votes[vi].w;
                     wsum += votes[vi].w;
                 }
-                append_maximum(votes, vbbox, kv.second.second, V3{cx / wsum, cy / wsum, cz / wsum}, c, P->min_votes_threshold, maxima);
+                append_maximum(votes, vbbox, kv.second.second, V3{cx / wsum, cy / wsum, cz / wsum}, c, P->min_votes_threshold, maxima, P->vote_bbox_quat);
             }
         }
         if (P->max_filter == 1) filter_maxima_simple(maxima, P->bin_size / 2);
-        finish_object(maxima, o, C, cap, P->min_threshold, P->best_k, n_max_out, mpos, mw, mcls, minst, miw, mbs, mnv, class_score);
+        if (P->max_filter == 2) filter_maxima_merge(maxima, nullptr, P->bin_size / 2);
+        finish_object(maxima, o, C, cap, P->min_threshold, P->best_k, n_max_out, mpos, mw, mcls, minst, miw, mbs, mnv, class_score, P->max_bbox_quat_out);
     }
     return 0;
 }

@@ -32,7 +32,12 @@ typedef struct ismref_maxima_params {
     float min_threshold;
     int   best_k;
     int   max_maxima;
-    int   max_filter;    /* 0 none, 1 "Simple" (MaximaHandler::filterMaxima, maxima_handler.cpp:272-296) */
+    int   max_filter;    /* 0 none, 1 "Simple", 2 "Merge" (MaximaHandler::filterMaxima, maxima_handler.cpp:272-440) */
+    const float* vote_bbox_quat;    /* [n_slots*4] or NULL: Voting.AverageRotation (voting.cpp:210-215) */
+    float* max_bbox_quat_out;       /* [n_obj*max_maxima*4] or NULL */
+    int   single_object_max_type;   /* 0 mean shift, 1 BANDWIDTH, 2 MODEL_RADIUS, 3 COMPLETE_VOTING_SPACE (voting_mean_shift.cpp:124-157) */
+    const float* object_centroid;   /* [n_obj*3] */
+    const float* object_radius;     /* [n_obj] */
 } ismref_maxima_params;
 
 void ismref_set_num_threads(int n);
@@ -121,6 +126,8 @@ typedef struct ismref_hough_params {
     int   best_k;
     int   max_maxima;
     int   max_filter;
+    const float* vote_bbox_quat;
+    float* max_bbox_quat_out;
 } ismref_hough_params;
 int  ismref_hough3d_maxima(int n_obj, const uint32_t* slot_offsets,
                            const float* vote_pos, const float* vote_weight, const int32_t* vote_class,

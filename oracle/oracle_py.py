@@ -18,7 +18,9 @@ class MaximaParams(C.Structure):
     _fields_ = [("n_classes", C.c_int), ("class_bandwidth", C.c_void_p), ("bandwidth", C.c_float),
                 ("threshold", C.c_float), ("max_iter", C.c_int), ("kernel", C.c_int), ("suppression", C.c_int),
                 ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int),
-                ("max_maxima", C.c_int), ("max_filter", C.c_int)]
+                ("max_maxima", C.c_int), ("max_filter", C.c_int),
+                ("vote_bbox_quat", C.c_void_p), ("max_bbox_quat_out", C.c_void_p), ("single_object_max_type", C.c_int),
+                ("object_centroid", C.c_void_p), ("object_radius", C.c_void_p)]
 
 
 def build():
@@ -220,12 +222,18 @@ def cast_votes(cb, weight_flags, lrf, kx, ky, kz, idx, dist):
 
 
 def find_maxima(slot_offsets, votes, n_classes, bandwidth, threshold=1e-3, max_iter=1000, kernel=0, suppression=0,
-                min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16, class_bandwidth=None, max_filter=0):
+                min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16, class_bandwidth=None, max_filter=0,
+                average_rotation=False, single_object_max_type=0, object_centroid=None, object_radius=None):
     so = _u(slot_offsets)
     n_obj = len(so) - 1
     cbw = _f(class_bandwidth)
+    bq = _f(votes["bbox_quat"]) if average_rotation else None
+    bq_out = np.empty((n_obj, max_maxima, 4), np.float32) if average_rotation else None
+    oc, orad = _f(object_centroid), _f(object_radius)
     P = MaximaParams(n_classes, cbw.ctypes.data if cbw is not None else None, bandwidth, threshold, max_iter, kernel, suppression,
-                     min_votes_threshold, min_threshold, best_k, max_maxima, max_filter)
+                     min_votes_threshold, min_threshold, best_k, max_maxima, max_filter,
+                     bq.ctypes.data if bq is not None else None, bq_out.ctypes.data if bq_out is not None else None, single_object_max_type,
+                     oc.ctypes.data if oc is not None else None, orad.ctypes.data if orad is not None else None)
     out = dict(n=np.empty(n_obj, np.int32), pos=np.empty((n_obj, max_maxima, 3), np.float32),
                weight=np.empty((n_obj, max_maxima), np.float32), cls=np.empty((n_obj, max_maxima), np.int32),
                inst=np.empty((n_obj, max_maxima), np.int32), inst_weight=np.empty((n_obj, max_maxima), np.float32),
@@ -236,22 +244,29 @@ def find_maxima(slot_offsets, votes, n_classes, bandwidth, threshold=1e-3, max_i
     lib().ismref_find_maxima(C.c_int(n_obj), _p(so), _p(pos), _p(w), _p(cls), _p(inst), _p(bs), C.byref(P), _p(out["n"]), _p(out["pos"]),
                              _p(out["weight"]), _p(out["cls"]), _p(out["inst"]), _p(out["inst_weight"]), _p(out["bbox_size"]),
                              _p(out["n_votes"]), _p(out["class_score"]))
+    if bq_out is not None:
+        out["bbox_quat"] = bq_out
     return out
 
 
 class HoughParams(C.Structure):
     _fields_ = [("n_classes", C.c_int), ("min_coord", C.c_float * 3), ("max_coord", C.c_float * 3), ("bin_size", C.c_float),
                 ("class_bin", C.c_void_p), ("use_interpolation", C.c_int), ("rel_threshold", C.c_float),
-                ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int), ("max_maxima", C.c_int), ("max_filter", C.c_int)]
+                ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int), ("max_maxima", C.c_int), ("max_filter", C.c_int),
+                ("vote_bbox_quat", C.c_void_p), ("max_bbox_quat_out", C.c_void_p)]
 
 
 def hough3d_maxima(slot_offsets, votes, n_classes, bin_size, min_coord=(-5, -5, -5), max_coord=(5, 5, 5), use_interpolation=True,
-                   rel_threshold=0.8, min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16, class_bin=None, max_filter=0):
+                   rel_threshold=0.8, min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16, class_bin=None, max_filter=0,
+                   average_rotation=False):
     so = _u(slot_offsets)
     n_obj = len(so) - 1
     cb = _f(class_bin)
+    bq = _f(votes["bbox_quat"]) if average_rotation else None
+    bq_out = np.empty((n_obj, max_maxima, 4), np.float32) if average_rotation else None
     P = HoughParams(n_classes, (C.c_float * 3)(*min_coord), (C.c_float * 3)(*max_coord), bin_size, cb.ctypes.data if cb is not None else None,
-                    1 if use_interpolation else 0, rel_threshold, min_votes_threshold, min_threshold, best_k, max_maxima, max_filter)
+                    1 if use_interpolation else 0, rel_threshold, min_votes_threshold, min_threshold, best_k, max_maxima, max_filter,
+                    bq.ctypes.data if bq is not None else None, bq_out.ctypes.data if bq_out is not None else None)
     out = dict(n=np.empty(n_obj, np.int32), pos=np.empty((n_obj, max_maxima, 3), np.float32),
                weight=np.empty((n_obj, max_maxima), np.float32), cls=np.empty((n_obj, max_maxima), np.int32),
                inst=np.empty((n_obj, max_maxima), np.int32), inst_weight=np.empty((n_obj, max_maxima), np.float32),
@@ -262,6 +277,8 @@ def hough3d_maxima(slot_offsets, votes, n_classes, bin_size, min_coord=(-5, -5, 
     lib().ismref_hough3d_maxima(C.c_int(n_obj), _p(so), _p(pos), _p(w), _p(cls), _p(inst), _p(bs), C.byref(P), _p(out["n"]), _p(out["pos"]),
                                 _p(out["weight"]), _p(out["cls"]), _p(out["inst"]), _p(out["inst_weight"]), _p(out["bbox_size"]),
                                 _p(out["n_votes"]), _p(out["class_score"]))
+    if bq_out is not None:
+        out["bbox_quat"] = bq_out
     return out
 
 

@@ -16,12 +16,14 @@ METRIC_L2SQ, METRIC_CHI2 = 0, 1
 W_CLASS, W_VOTE, W_MATCHING, W_CODEWORD = 1, 2, 4, 8
 KERNEL_GAUSSIAN, KERNEL_UNIFORM = 0, 1
 SUPPRESS_AVERAGE, SUPPRESS_SUPPRESS, SUPPRESS_NONE = 0, 1, 2
+MAXFILTER_NONE, MAXFILTER_SIMPLE, MAXFILTER_MERGE = 0, 1, 2
+SOM_MEANSHIFT, SOM_BANDWIDTH, SOM_MODEL_RADIUS, SOM_COMPLETE_VOTING_SPACE = 0, 1, 2, 3
 ERR_NODEVICE = -5
 
 EXPORTS = [
     "ismhip_abi_version", "ismhip_ctx_create", "ismhip_ctx_create_on_stream", "ismhip_ctx_destroy", "ismhip_sync", "ismhip_last_error",
     "ismhip_timers_enable", "ismhip_timers_reset", "ismhip_timer_get",
-    "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids", "ismhip_estimate_normals", "ismhip_estimate_normals_pca",
+    "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids", "ismhip_cloud_radii", "ismhip_estimate_normals", "ismhip_estimate_normals_pca",
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
     "ismhip_compact_features", "ismhip_voxel_keypoints", "ismhip_gather_columns",
     "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word", "ismhip_codebook_stage1_dims",
@@ -33,13 +35,16 @@ class MaximaParams(C.Structure):
     _fields_ = [("n_classes", C.c_int), ("class_bandwidth_h", C.c_void_p), ("bandwidth", C.c_float),
                 ("threshold", C.c_float), ("max_iter", C.c_int), ("kernel", C.c_int), ("suppression", C.c_int),
                 ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int),
-                ("max_maxima", C.c_int), ("max_filter", C.c_int)]
+                ("max_maxima", C.c_int), ("max_filter", C.c_int),
+                ("vote_bbox_quat", C.c_void_p), ("max_bbox_quat_out", C.c_void_p), ("single_object_max_type", C.c_int),
+                ("object_centroid", C.c_void_p), ("object_radius", C.c_void_p)]
 
 
 class HoughParams(C.Structure):
     _fields_ = [("n_classes", C.c_int), ("min_coord", C.c_float * 3), ("max_coord", C.c_float * 3), ("bin_size", C.c_float),
                 ("class_bin_h", C.c_void_p), ("use_interpolation", C.c_int), ("rel_threshold", C.c_float),
-                ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int), ("max_maxima", C.c_int), ("max_filter", C.c_int)]
+                ("min_votes_threshold", C.c_int), ("min_threshold", C.c_float), ("best_k", C.c_int), ("max_maxima", C.c_int), ("max_filter", C.c_int),
+                ("vote_bbox_quat", C.c_void_p), ("max_bbox_quat_out", C.c_void_p)]
 
 
 class IsmHipError(RuntimeError):
@@ -249,6 +254,14 @@ def cloud_centroids(ctx, cloud, device):
     return out
 
 
+def cloud_radii(ctx, cloud, centroid):
+    """SingleObjectHelper::getModelRadius per object: farthest point from centroid [n_obj, 3] (device)"""
+    torch = _torch()
+    out = torch.empty((cloud.n_obj,), dtype=torch.float32, device=centroid.device)
+    ctx.check(lib().ismhip_cloud_radii(ctx._h, cloud._h, _p(centroid), _p(out)), "ismhip_cloud_radii")
+    return out
+
+
 def center_dist(ctx, cloud, kp_offsets, kpx, kpy, kpz):
     torch = _torch()
     ko = _u32(kp_offsets)
@@ -351,14 +364,20 @@ def cast_votes(ctx, cb, weight_flags, lrf, kpx, kpy, kpz, idx, dist, want_bbox=F
 
 def find_maxima(ctx, slot_offsets, votes, n_classes, bandwidth, threshold=1e-3, max_iter=1000, kernel=KERNEL_GAUSSIAN,
                 suppression=SUPPRESS_AVERAGE, min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16,
-                class_bandwidth=None, max_filter=0):
+                class_bandwidth=None, max_filter=0, average_rotation=False, single_object_max_type=SOM_MEANSHIFT,
+                object_centroid=None, object_radius=None):
+    """average_rotation: votes["bbox_quat"] in, out["bbox_quat"] per maximum; single_object_max_type != SOM_MEANSHIFT needs
+    object_centroid [n_obj,3] (and object_radius [n_obj] for SOM_MODEL_RADIUS) as device tensors"""
     torch = _torch()
     so = _u32(slot_offsets)
     n_obj = len(so) - 1
     dev = votes["pos"].device
     cbw = None if class_bandwidth is None else np.ascontiguousarray(np.asarray(class_bandwidth, dtype=np.float32))
+    bq_out = torch.empty((n_obj, max_maxima, 4), dtype=torch.float32, device=dev) if average_rotation else None
     P = MaximaParams(n_classes, cbw.ctypes.data if cbw is not None else None, bandwidth, threshold, max_iter, kernel, suppression,
-                     min_votes_threshold, min_threshold, best_k, max_maxima, max_filter)
+                     min_votes_threshold, min_threshold, best_k, max_maxima, max_filter,
+                     _p(votes["bbox_quat"]).value if average_rotation else None, _p(bq_out).value, single_object_max_type,
+                     _p(object_centroid).value, _p(object_radius).value)
     out = dict(
         n=torch.empty((n_obj,), dtype=torch.int32, device=dev),
         pos=torch.empty((n_obj, max_maxima, 3), dtype=torch.float32, device=dev),
@@ -374,19 +393,24 @@ def find_maxima(ctx, slot_offsets, votes, n_classes, bandwidth, threshold=1e-3, 
                                        _p(votes["inst"]), _p(votes.get("bbox_size")), C.byref(P), _p(out["n"]), _p(out["pos"]),
                                        _p(out["weight"]), _p(out["cls"]), _p(out["inst"]), _p(out["inst_weight"]), _p(out["bbox_size"]),
                                        _p(out["n_votes"]), _p(out["class_score"])), "ismhip_find_maxima")
+    if bq_out is not None:
+        out["bbox_quat"] = bq_out
     return out
 
 
 def hough3d_maxima(ctx, slot_offsets, votes, n_classes, bin_size, min_coord=(-5, -5, -5), max_coord=(5, 5, 5), use_interpolation=True,
-                   rel_threshold=0.8, min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16, class_bin=None, max_filter=0):
+                   rel_threshold=0.8, min_votes_threshold=1, min_threshold=0.0, best_k=-1, max_maxima=16, class_bin=None, max_filter=0,
+                   average_rotation=False):
     """VotingHough3D on the device: same outputs as find_maxima"""
     torch = _torch()
     so = _u32(slot_offsets)
     n_obj = len(so) - 1
     dev = votes["pos"].device
     cb = None if class_bin is None else np.ascontiguousarray(np.asarray(class_bin, dtype=np.float32))
+    bq_out = torch.empty((n_obj, max_maxima, 4), dtype=torch.float32, device=dev) if average_rotation else None
     P = HoughParams(n_classes, (C.c_float * 3)(*min_coord), (C.c_float * 3)(*max_coord), bin_size, cb.ctypes.data if cb is not None else None,
-                    1 if use_interpolation else 0, rel_threshold, min_votes_threshold, min_threshold, best_k, max_maxima, max_filter)
+                    1 if use_interpolation else 0, rel_threshold, min_votes_threshold, min_threshold, best_k, max_maxima, max_filter,
+                    _p(votes["bbox_quat"]).value if average_rotation else None, _p(bq_out).value)
     out = dict(
         n=torch.empty((n_obj,), dtype=torch.int32, device=dev),
         pos=torch.empty((n_obj, max_maxima, 3), dtype=torch.float32, device=dev),
@@ -402,6 +426,8 @@ def hough3d_maxima(ctx, slot_offsets, votes, n_classes, bin_size, min_coord=(-5,
                                           _p(votes["inst"]), _p(votes.get("bbox_size")), C.byref(P), _p(out["n"]), _p(out["pos"]),
                                           _p(out["weight"]), _p(out["cls"]), _p(out["inst"]), _p(out["inst_weight"]), _p(out["bbox_size"]),
                                           _p(out["n_votes"]), _p(out["class_score"])), "ismhip_hough3d_maxima")
+    if bq_out is not None:
+        out["bbox_quat"] = bq_out
     return out
 
 

@@ -103,7 +103,8 @@ static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out)
     (void)hipMemcpy(ctx->lut_srgb, srgb.data(), 256 * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(ctx->lut_sxyz, sxyz.data(), 4000 * 4, hipMemcpyHostToDevice);
     if (hipMalloc((void**)&ctx->truncated_d, 4) != hipSuccess) { delete ctx; return ISMHIP_ERR_NOMEM; }
-    (void)hipMemset(ctx->truncated_d, 0, 4);
+    (void)hipMemset(ctx->truncated_d, 0, 4);      // before the first launch on any stream: the device is idle
+    (void)hipDeviceSynchronize();
     *out = ctx;
     return ISMHIP_OK;
 }
@@ -126,16 +127,21 @@ int ismhip_ctx_destroy(ismhip_ctx* ctx) {
 
 int ismhip_sync(ismhip_ctx* ctx) {
     if (!ctx) return ISMHIP_ERR_INVALID;
-    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->truncated_d) {                // caps of the maxima kernels (128 per object and class, 1024 per object): never silent
+        // read and cleared ON the ctx stream: a null-stream memset is not ordered against an owned (non-blocking) stream and could wipe
+        // the count of a find_maxima launched right after this call
         uint32_t n = 0;
-        ISM_HIP(ctx, hipMemcpy(&n, ctx->truncated_d, 4, hipMemcpyDeviceToHost));
+        ISM_HIP(ctx, hipMemcpyAsync(&n, ctx->truncated_d, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (n) {
-            ISM_HIP(ctx, hipMemset(ctx->truncated_d, 0, 4));
+            ISM_HIP(ctx, hipMemsetAsync(ctx->truncated_d, 0, 4, ctx->stream));
+            ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
             return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "find_maxima / hough3d_maxima: " + std::to_string(n) +
                                " (object, class) lists exceeded 128 maxima per class or 1024 per object since the last sync; the results of those objects are truncated");
         }
+        return ISMHIP_OK;
     }
+    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ISMHIP_OK;
 }
 

@@ -145,6 +145,26 @@ __global__ __launch_bounds__(256) void k_members(const uint32_t* __restrict__ pt
     members[b + cell_start[(size_t)o * ISM_GRID_STRIDE + c] + rank_of_pt[i]] = i - b;
 }
 
+// SingleObjectHelper::getModelRadius (single_object_mode_helper.cpp:15-27): max over the points of |p - centroid| (Eigen norm: sqrt of
+// the float sum x^2 + y^2 + z^2); max is order-free, points with a non-finite coordinate never compare greater
+__global__ __launch_bounds__(256) void k_cloud_radii(const uint32_t* __restrict__ pt_off, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                     const float* __restrict__ centroid, float* __restrict__ radius) {
+    __shared__ float s_m[4];
+    const int o = blockIdx.x;
+    const float cx = centroid[o * 3], cy = centroid[o * 3 + 1], cz = centroid[o * 3 + 2];
+    float m = 0.f;
+    for (uint32_t i = pt_off[o] + threadIdx.x; i < pt_off[o + 1]; i += 256) {
+        const float dx = x[i] - cx, dy = y[i] - cy, dz = z[i] - cz;
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (d > m) m = d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) radius[o] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+}
+
 // Scatter into the cell-sorted packed arrays. The position of a point inside its cell is its rank BY ORIGINAL INDEX among the
 // cell's members (a stable counting sort), not the atomic arrival rank of k_count: the sorted copy, and with it the order of
 // every floating-point accumulation over a neighbourhood (LRF covariance, FPFH sums), is the same from run to run.
@@ -314,6 +334,13 @@ int ismhip_cloud_centroids(ismhip_ctx* ctx, const ismhip_cloud* cloud, float* ce
     if (!ctx || !cloud || !centroid_out) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "cloud_centroids: bad argument");
     hipLaunchKernelGGL(k_centroids, dim3((cloud->n_obj + 63) / 64), dim3(64), 0, ctx->stream, cloud->meta, cloud->n_obj, centroid_out);
     ISM_CHECK_LAUNCH(ctx, "k_centroids");
+    return ISMHIP_OK;
+}
+
+int ismhip_cloud_radii(ismhip_ctx* ctx, const ismhip_cloud* cloud, const float* centroid, float* radius_out) {
+    if (!ctx || !cloud || !centroid || !radius_out) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "cloud_radii: bad argument");
+    hipLaunchKernelGGL(k_cloud_radii, dim3(cloud->n_obj), dim3(256), 0, ctx->stream, cloud->pt_off, cloud->x, cloud->y, cloud->z, centroid, radius_out);
+    ISM_CHECK_LAUNCH(ctx, "k_cloud_radii");
     return ISMHIP_OK;
 }
 

@@ -18,7 +18,7 @@ namespace {
 #define MX_MAXM 1024       // maxima kept per object before sort/normalise
 #define MX_BIAS (1 << 20)
 #define MX_MAXM_C 128      // maxima kept per (object, class)
-#define MX_REC 12          // pos[3], weight, instance (bits), instance weight, bbox[3], n_votes (bits), 2 spare
+#define MX_REC 16          // pos[3], weight, instance (bits), instance weight, bbox[3], n_votes (bits), bbox quaternion (w,x,y,z), 2 spare
 
 struct MaxArgs {
     const uint32_t* slot_off; const float* vpos; const float* vw; const int32_t* vcls; const int32_t* vinst; const float* vbs;
@@ -28,6 +28,8 @@ struct MaxArgs {
     float* rec; int32_t* rec_count;      // per (object, class): up to MX_MAXM_C records of MX_REC floats
     unsigned char* work; const uint32_t* work_off; const uint32_t* class_count;   // big objects: per-(object, class) vote arrays in HBM
     uint32_t* truncated;                 // ctx counter: maxima dropped by a cap (MX_MAXM_C per class, MX_MAXM per object); ismhip_sync reports it
+    const float* vbq; float* mbq;        // Voting.AverageRotation: bbox quaternions of the votes (w,x,y,z) in, of the maxima out (both or neither)
+    int som_type; const float* obj_centroid; const float* obj_radius;   // single-object max types (voting_mean_shift.cpp:124-157)
 };
 #define MX_LDS_SLOTS 2048  // vote slots per object that fit the LDS-resident kernels
 #define MX_WORK_STRIDE 72  // bytes of workspace per vote slot (65 used by k_find_maxima, 37 by k_hough3d)
@@ -83,6 +85,42 @@ __device__ __forceinline__ float dist3(float ax, float ay, float az, float bx, f
     return sqrtf(dx * dx + dy * dy + dz * dz);
 }
 
+// Utils::quatWeightedAverage (utils/utils.cpp:617-665): the "mean" of unit quaternions = dominant eigenvector of the scatter matrix
+// sum_k w_k q_k q_k^T. The reference solves it with Eigen::EigenSolver and then looks at eigenvalue 0 only (its loop runs to
+// eigenvalues.cols() == 1), i.e. it returns whichever eigenvector the unordered general solver lists first: not reproducible. Here:
+// cyclic Jacobi in double on the symmetric 4x4 matrix, the eigenvector of the LARGEST eigenvalue, sign chosen so that its first
+// non-zero component (w first) is positive (q and -q are the same rotation). Stated deviation, DESIGN.md §7.
+// S = upper triangle row by row: (00 01 02 03 11 12 13 22 23 33).
+__device__ inline void quat_from_scatter(const float* S, float* q) {
+    double A[4][4] = {{S[0], S[1], S[2], S[3]}, {S[1], S[4], S[5], S[6]}, {S[2], S[5], S[7], S[8]}, {S[3], S[6], S[8], S[9]}};
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+        if (!(off > 1e-30)) break;
+        for (int p = 0; p < 3; ++p) for (int r = p + 1; r < 4; ++r) {
+            if (fabs(A[p][r]) < 1e-300) continue;
+            const double theta = (A[r][r] - A[p][p]) / (2.0 * A[p][r]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+            for (int k = 0; k < 4; ++k) { const double x = A[k][p], y = A[k][r]; A[k][p] = c * x - sn * y; A[k][r] = sn * x + c * y; }
+            for (int k = 0; k < 4; ++k) { const double x = A[p][k], y = A[r][k]; A[p][k] = c * x - sn * y; A[r][k] = sn * x + c * y; }
+            for (int k = 0; k < 4; ++k) { const double x = V[k][p], y = V[k][r]; V[k][p] = c * x - sn * y; V[k][r] = sn * x + c * y; }
+        }
+    }
+    int best = 0;
+    for (int i = 1; i < 4; ++i) if (A[i][i] > A[best][best]) best = i;
+    double v[4] = {V[0][best], V[1][best], V[2][best], V[3][best]};
+    double sgn = 1.0;
+    for (int i = 0; i < 4; ++i) if (v[i] != 0.0) { sgn = v[i] < 0 ? -1.0 : 1.0; break; }
+    for (int i = 0; i < 4; ++i) q[i] = (float)(sgn * v[i]);
+}
+__device__ __forceinline__ void quat_scatter_add(float* S, float w, const float* q) {
+    S[0] += w * q[0] * q[0]; S[1] += w * q[0] * q[1]; S[2] += w * q[0] * q[2]; S[3] += w * q[0] * q[3];
+    S[4] += w * q[1] * q[1]; S[5] += w * q[1] * q[2]; S[6] += w * q[1] * q[3];
+    S[7] += w * q[2] * q[2]; S[8] += w * q[2] * q[3]; S[9] += w * q[3] * q[3];
+}
+
 __device__ __forceinline__ float block_sum_f(float v, float* s_red) {   // 256 threads
     v = wave_sum_f(v);
     __syncthreads();
@@ -125,9 +163,9 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
     if (tid == 0) { s_nmax = 0; a.rec_count[(size_t)o * C + c] = 0; }
     __syncthreads();
     {
-        const float h = a.class_bw ? a.class_bw[c] : a.bandwidth;          // voting_mean_shift.cpp:48-49
-        const float h2 = (float)((double)h * (double)h);
-        const float hh = h * h;
+        float h = a.class_bw ? a.class_bw[c] : a.bandwidth;                // voting_mean_shift.cpp:48-49
+        float h2 = (float)((double)h * (double)h);
+        float hh = h * h;
         // ---- ordered compaction of the class's votes into LDS
         if (tid == 0) s_n = 0;
         __syncthreads();
@@ -152,6 +190,28 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
         }
         const int n = min(s_n, cap);
         if (n == 0) return;                                       // class absent from m_votes (uniform across the block)
+        if (a.som_type != ISMHIP_SOM_MEANSHIFT) {
+            // Single-object mode with SingleObjectMaxType BANDWIDTH / MODEL_RADIUS / COMPLETE_VOTING_SPACE (voting_mean_shift.cpp:124-157):
+            // no mean shift; ONE maximum per class at the centroid of the object's cloud, density and reweighting with the bandwidth
+            // of the type: the class's search distance | the farthest cloud point from the centroid (single_object_mode_helper.cpp:15-27)
+            // | the farthest vote of the class from the centroid (:29-40, squaredNorm then sqrt)
+            const float qx = a.obj_centroid[o * 3], qy = a.obj_centroid[o * 3 + 1], qz = a.obj_centroid[o * 3 + 2];
+            if (a.som_type == ISMHIP_SOM_MODEL_RADIUS) h = a.obj_radius[o];
+            else if (a.som_type == ISMHIP_SOM_COMPLETE_VOTING_SPACE) {
+                float md = 0.f;
+                for (int i = tid; i < n; i += 256) { const float dx = vx[i] - qx, dy = vy[i] - qy, dz = vz[i] - qz; md = fmaxf(md, dx * dx + dy * dy + dz * dz); }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) md = fmaxf(md, __shfl_xor(md, off, 64));
+                __syncthreads();
+                if (lane == 0) s_redf[wv] = md;
+                __syncthreads();
+                h = sqrtf(fmaxf(fmaxf(s_redf[0], s_redf[1]), fmaxf(s_redf[2], s_redf[3])));
+                __syncthreads();
+            }
+            h2 = (float)((double)h * (double)h); hh = h * h;
+            if (tid == 0) { ctr2[0] = make_float4(qx, qy, qz, 0.f); s_np = 1; }
+            __syncthreads();
+        } else {
         // ---- seeds: unique cells of edge 2h/sqrt(2), key floor(x/edge + 0.5), (z,y,x) order (:431-481)
         const float bin = (h * 2.0f) / sqrtf(2.0f);
         int P = 1; while (P < n) P <<= 1;
@@ -287,11 +347,13 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
             s_np = np;
         }
         __syncthreads();
+        }   // mean shift / single-object type
         const int np = s_np;
         // ---- per maximum: density + in-place reweighting (:289-328) and the Voting::findMaxima block (voting.cpp:131-236)
         for (int pi = 0; pi < np; ++pi) {
             const float4 p = ctr2[pi];
             int cnt = 0; float sw = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            float qs[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             for (int i = tid; i < n; i += 256) {
                 const float d2 = sqdist3(vx[i], vy[i], vz[i], p.x, p.y, p.z);
                 const bool in = d2 < h2;
@@ -301,12 +363,17 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
                     vw[i] = w;
                     cnt++; sw += w;
                     if (a.vbs) { const size_t s = (size_t)vslot[i] * 3; b0 += w * a.vbs[s]; b1 += w * a.vbs[s + 1]; b2 += w * a.vbs[s + 2]; }
+                    if (a.vbq) quat_scatter_add(qs, w, a.vbq + (size_t)vslot[i] * 4);
                 }
             }
             cnt = block_sum_i(cnt, s_redi);
             if (cnt < a.min_votes || cnt == 0) continue;      // uniform across the block
             sw = block_sum_f(sw, s_redf);
             b0 = block_sum_f(b0, s_redf); b1 = block_sum_f(b1, s_redf); b2 = block_sum_f(b2, s_redf);
+            if (a.vbq) {
+#pragma unroll
+                for (int e = 0; e < 10; ++e) qs[e] = block_sum_f(qs[e], s_redf);
+            }
             __syncthreads();
             // instance id with the largest summed weight; ties -> smallest id; weights <= 0 never win (voting.cpp:139-165).
             // Per-instance sums in an LDS hash table (open addressing, keys = instance ids, values = 2^-32 fixed point updated with
@@ -356,6 +423,8 @@ __global__ __launch_bounds__(256) void k_find_maxima(MaxArgs a) {
                     r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = sw;
                     r[4] = __int_as_float(bestS > 0.f ? bestI : -1); r[5] = bestS > 0.f ? bestS : 0.f;
                     r[6] = b0 / sw; r[7] = b1 / sw; r[8] = b2 / sw; r[9] = __int_as_float(cnt);
+                    r[10] = 1.f; r[11] = 0.f; r[12] = 0.f; r[13] = 0.f;
+                    if (a.vbq) quat_from_scatter(qs, r + 10);          // voting.cpp:210-215
                     s_nmax = m + 1;
                 } else atomicAdd(a.truncated, 1u);
             }
@@ -414,6 +483,73 @@ __global__ __launch_bounds__(64) void k_finalize_maxima(MaxArgs a) {
         for (int r = 0; r < kept; ++r) { s_w[r] = s_tw[r]; s_iw[r] = s_tiw[r]; s_src[r] = s_tsrc[r]; s_cls[r] = s_tcls[r]; s_order[r] = r; }
         nm = kept;
     }
+    if (a.max_filter == ISMHIP_MAXFILTER_MERGE && nm > 1) {
+        // MaximaHandler::filterMaxima "Merge" -> mergeAndFilterMaxima(maxima, true) (maxima_handler.cpp:300-387) with mergeMaxima
+        // (:390-440), on the raw weights and in the reference's list order (classes ascending, then the order iFindMaxima produced).
+        // For every not yet consumed maximum i: the later maxima closer than i's search distance whose own search distance is not
+        // larger are consumed; if there are any, they and i are grouped by class (ascending), every group is merged (running weighted
+        // means of position and box size, weights added, instance weights tallied per instance id, quaternion average of the running
+        // result and the member), and the heaviest merged maximum (the first one among equals) replaces the whole neighbourhood.
+        float* recs = a.rec + (size_t)o * C * MX_MAXM_C * MX_REC;
+        int kept = 0;
+        for (int i = 0; i < nm; ++i) s_order[i] = 1;                      // 1 = not consumed ("dirty" is 0)
+        for (int i = 0; i < nm; ++i) {
+            if (!s_order[i]) continue;
+            const float* ri = recs + (size_t)s_src[i] * MX_REC;
+            const float sd = a.class_bw ? a.class_bw[s_cls[i]] : a.bandwidth;
+            int nclose = 0;                                               // members in s_tsrc[] (list order: the consumed ones, then i)
+            for (int j = i + 1; j < nm; ++j) {
+                if (!s_order[j]) continue;
+                const float* rj = recs + (size_t)s_src[j] * MX_REC;
+                const float osd = a.class_bw ? a.class_bw[s_cls[j]] : a.bandwidth;
+                if (dist3(rj[0], rj[1], rj[2], ri[0], ri[1], ri[2]) < sd && osd <= sd) { s_tsrc[nclose++] = j; s_order[j] = 0; }
+            }
+            if (nclose == 0) { s_iw2[kept++] = i; continue; }
+            s_tsrc[nclose++] = i;
+            float best[MX_REC]; float best_w = 0.f; int best_cls = -1; bool have = false;     // VotingMaximum(): weight 0
+            for (int cc = 0; cc < C; ++cc) {                              // std::map<unsigned, ...>: ascending class id
+                float m[MX_REC]; bool any = false;
+                float mw = 0.f, px = 0.f, py = 0.f, pz = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f; int nv = 0;
+                float mq[4] = {1.f, 0.f, 0.f, 0.f};
+                int inst_id[64]; float inst_w[64]; int n_inst = 0;       // instance tally of the group (more than 64 distinct ids: the rest is ignored)
+                int bi = -1;
+                for (int t = 0; t < nclose; ++t) {
+                    const int x = s_tsrc[t];
+                    if (s_cls[x] != cc) continue;
+                    const float* rx = recs + (size_t)s_src[x] * MX_REC;
+                    const float w = s_w[x];
+                    any = true;
+                    px = (px * mw + rx[0] * w) / (mw + w); py = (py * mw + rx[1] * w) / (mw + w); pz = (pz * mw + rx[2] * w) / (mw + w);
+                    b0 = (b0 * mw + rx[6] * w) / (mw + w); b1 = (b1 * mw + rx[7] * w) / (mw + w); b2 = (b2 * mw + rx[8] * w) / (mw + w);
+                    { float S[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; quat_scatter_add(S, mw, mq); quat_scatter_add(S, w, rx + 10); quat_from_scatter(S, mq); }
+                    mw += w; nv += __float_as_int(rx[9]);
+                    const int iid = __float_as_int(rx[4]);
+                    int k = 0; for (; k < n_inst; ++k) if (inst_id[k] == iid) break;
+                    if (k == n_inst && n_inst < 64) { inst_id[n_inst] = iid; inst_w[n_inst] = 0.f; ++n_inst; }
+                    if (k < n_inst) inst_w[k] += s_iw[x];
+                    bi = -1;                                              // largest tally, lowest id among equals (std::map order), tallies <= 0 never win
+                    for (int k2 = 0; k2 < n_inst; ++k2) {
+                        const float w2 = inst_w[k2];
+                        if (w2 > 0.f && (bi < 0 || w2 > inst_w[bi] || (w2 == inst_w[bi] && (unsigned)inst_id[k2] < (unsigned)inst_id[bi]))) bi = k2;
+                    }
+                }
+                if (!any) continue;
+                m[0] = px; m[1] = py; m[2] = pz; m[3] = mw; m[4] = __int_as_float(bi >= 0 ? inst_id[bi] : -1); m[5] = bi >= 0 ? inst_w[bi] : 0.f;
+                m[6] = b0; m[7] = b1; m[8] = b2; m[9] = __int_as_float(nv); m[10] = mq[0]; m[11] = mq[1]; m[12] = mq[2]; m[13] = mq[3]; m[14] = 0.f; m[15] = 0.f;
+                if (mw > best_w) { for (int e = 0; e < MX_REC; ++e) best[e] = m[e]; best_w = mw; best_cls = cc; have = true; }
+            }
+            if (have) {
+                float* wr = recs + (size_t)s_src[i] * MX_REC;             // the merged maximum takes i's record
+                for (int e = 0; e < MX_REC; ++e) wr[e] = best[e];
+                s_w[i] = best_w; s_iw[i] = best[5]; s_cls[i] = best_cls;
+                s_iw2[kept++] = i;
+            }
+        }
+        for (int r = 0; r < kept; ++r) { const int i = s_iw2[r]; s_tw[r] = s_w[i]; s_tiw[r] = s_iw[i]; s_tsrc[r] = s_src[i]; s_tcls[r] = s_cls[i]; }
+        for (int r = 0; r < kept; ++r) { s_w[r] = s_tw[r]; s_iw[r] = s_tiw[r]; s_src[r] = s_tsrc[r]; s_cls[r] = s_tcls[r]; }
+        nm = kept;
+    }
+    for (int i = 0; i < nm; ++i) s_order[i] = i;
     for (int i = 1; i < nm; ++i) {
         const int v = s_order[i]; int j = i - 1;
         while (j >= 0 && s_w[s_order[j]] < s_w[v]) { s_order[j + 1] = s_order[j]; --j; }
@@ -445,6 +581,7 @@ __global__ __launch_bounds__(64) void k_finalize_maxima(MaxArgs a) {
         a.mw[t] = ok ? s_w[m] : 0.f; a.mcls[t] = ok ? s_cls[m] : -1; a.minst[t] = ok ? __float_as_int(r[4]) : -1;
         a.miw[t] = ok ? s_iw[m] : 0.f; a.mnv[t] = ok ? __float_as_int(r[9]) : 0;
         if (a.mbs) { a.mbs[t * 3] = ok ? r[6] : 0.f; a.mbs[t * 3 + 1] = ok ? r[7] : 0.f; a.mbs[t * 3 + 2] = ok ? r[8] : 0.f; }
+        if (a.mbq) { a.mbq[t * 4] = ok ? r[10] : 1.f; a.mbq[t * 4 + 1] = ok ? r[11] : 0.f; a.mbq[t * 4 + 2] = ok ? r[12] : 0.f; a.mbq[t * 4 + 3] = ok ? r[13] : 0.f; }
     }
 }
 
@@ -461,6 +598,7 @@ __global__ __launch_bounds__(64) void k_finalize_maxima(MaxArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------------
 #define HG_FIX 1099511627776.0            /* 2^40 */
 struct HoughArgs {
+    const float* vbq;                    // Voting.AverageRotation: bbox quaternions of the votes, or NULL
     const uint32_t* slot_off; const float* vpos; const float* vw; const int32_t* vcls; const int32_t* vinst; const float* vbs;
     int n_classes; const float* class_bin; float bin; float minc[3], maxc[3]; int use_int; float rel; int min_votes, cap, tile_edge;
     float* rec; int32_t* rec_count; int32_t* overflow;
@@ -627,6 +765,7 @@ __global__ __launch_bounds__(256) void k_hough3d(HoughArgs a) {
         const long long mb = s_mbin[pi];
         const int mbx = (int)(mb % cnt[0]), mby = (int)((mb / cnt[0]) % cnt[1]), mbz = (int)(mb / ((long long)cnt[0] * cnt[1]));
         int vcnt = 0; float sw = 0.f, px = 0.f, py = 0.f, pz = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        float qs[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int i = tid; i < n; i += 256) {
             const HgBin b = hg_bin(a, bin, cnt, vx[i], vy[i], vz[i]);
             bool in = b.in;
@@ -648,6 +787,7 @@ __global__ __launch_bounds__(256) void k_hough3d(HoughArgs a) {
                 const float w = vw[i];
                 vcnt++; sw += w; px += vx[i] * w; py += vy[i] * w; pz += vz[i] * w;
                 if (a.vbs) { const size_t s = (size_t)vslot[i] * 3; b0 += w * a.vbs[s]; b1 += w * a.vbs[s + 1]; b2 += w * a.vbs[s + 2]; }
+                if (a.vbq) quat_scatter_add(qs, w, a.vbq + (size_t)vslot[i] * 4);
             }
         }
         vcnt = block_sum_i(vcnt, s_redi);
@@ -655,6 +795,10 @@ __global__ __launch_bounds__(256) void k_hough3d(HoughArgs a) {
         sw = block_sum_f(sw, s_redf);
         px = block_sum_f(px, s_redf); py = block_sum_f(py, s_redf); pz = block_sum_f(pz, s_redf);
         b0 = block_sum_f(b0, s_redf); b1 = block_sum_f(b1, s_redf); b2 = block_sum_f(b2, s_redf);
+        if (a.vbq) {
+#pragma unroll
+            for (int e = 0; e < 10; ++e) qs[e] = block_sum_f(qs[e], s_redf);
+        }
         __syncthreads();
         // instance tally: as k_find_maxima (LDS hash, 2^-32 fixed point, ties -> smallest id, weights <= 0 never win)
         const int HEMPTY = (int)0x80000000;
@@ -698,6 +842,8 @@ __global__ __launch_bounds__(256) void k_hough3d(HoughArgs a) {
                 r[0] = px / sw; r[1] = py / sw; r[2] = pz / sw; r[3] = sw;
                 r[4] = __int_as_float(bestS > 0.f ? bestI : -1); r[5] = bestS > 0.f ? bestS : 0.f;
                 r[6] = b0 / sw; r[7] = b1 / sw; r[8] = b2 / sw; r[9] = __int_as_float(vcnt);
+                r[10] = 1.f; r[11] = 0.f; r[12] = 0.f; r[13] = 0.f;
+                if (a.vbq) quat_from_scatter(qs, r + 10);
                 s_nmax = m + 1;
             } else atomicAdd(a.truncated, 1u);
         }
@@ -763,8 +909,15 @@ extern "C" int ismhip_find_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t* sl
     a.n_classes = P->n_classes; a.class_bw = bw; a.bandwidth = P->bandwidth; a.threshold = P->threshold; a.max_iter = P->max_iter;
     a.kernel = P->kernel; a.suppression = P->suppression; a.min_votes = P->min_votes_threshold; a.min_threshold = P->min_threshold;
     a.best_k = P->best_k; a.max_maxima = P->max_maxima; a.cap = cap;
-    if (P->max_filter != ISMHIP_MAXFILTER_NONE && P->max_filter != ISMHIP_MAXFILTER_SIMPLE) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "find_maxima: MaxFilterType other than None / Simple not built");
+    if (P->max_filter != ISMHIP_MAXFILTER_NONE && P->max_filter != ISMHIP_MAXFILTER_SIMPLE && P->max_filter != ISMHIP_MAXFILTER_MERGE)
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "find_maxima: MaxFilterType");
     a.max_filter = P->max_filter; a.filter_radius = P->bandwidth;      // MaximaHandler::m_radius = the configured bandwidth (voting_mean_shift.cpp:46)
+    if ((P->vote_bbox_quat == nullptr) != (P->max_bbox_quat_out == nullptr)) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "find_maxima: vote_bbox_quat and max_bbox_quat_out go together");
+    a.vbq = P->vote_bbox_quat; a.mbq = P->max_bbox_quat_out;
+    a.som_type = P->single_object_max_type; a.obj_centroid = P->object_centroid; a.obj_radius = P->object_radius;
+    if (a.som_type < ISMHIP_SOM_MEANSHIFT || a.som_type > ISMHIP_SOM_COMPLETE_VOTING_SPACE) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "find_maxima: single_object_max_type");
+    if (a.som_type != ISMHIP_SOM_MEANSHIFT && (!a.obj_centroid || (a.som_type == ISMHIP_SOM_MODEL_RADIUS && !a.obj_radius)))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "find_maxima: single-object max types need object_centroid (and object_radius for MODEL_RADIUS)");
     a.n_max = n_maxima_out; a.mpos = max_pos_out; a.mw = max_weight_out; a.mcls = max_class_out; a.minst = max_instance_out;
     a.miw = max_instance_weight_out; a.mbs = max_bbox_size_out; a.mnv = max_n_votes_out; a.class_score = class_score_out;
     if (!ctx->attr_done.count((const void*)k_find_maxima<false>)) {      // the attribute is per device: remembered per ctx, not per process
@@ -834,8 +987,13 @@ extern "C" int ismhip_hough3d_maxima(ismhip_ctx* ctx, int n_obj, const uint32_t*
     MaxArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n_classes = P->n_classes; a.min_threshold = P->min_threshold; a.best_k = P->best_k; a.max_maxima = P->max_maxima;
-    if (P->max_filter != ISMHIP_MAXFILTER_NONE && P->max_filter != ISMHIP_MAXFILTER_SIMPLE) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "hough3d_maxima: MaxFilterType other than None / Simple not built");
+    if (P->max_filter != ISMHIP_MAXFILTER_NONE && P->max_filter != ISMHIP_MAXFILTER_SIMPLE && P->max_filter != ISMHIP_MAXFILTER_MERGE)
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "hough3d_maxima: MaxFilterType");
+    if (P->max_filter == ISMHIP_MAXFILTER_MERGE && P->class_bin_h) return ism_set_err(ctx, ISMHIP_ERR_UNSUPPORTED, "hough3d_maxima: MaxFilterType Merge with per-class bin sizes not built");
     a.max_filter = P->max_filter; a.filter_radius = P->bin_size / 2;   // MaximaHandler::setRadius(BinSize[0] / 2) (voting_hough_3d.cpp:45)
+    a.bandwidth = P->bin_size / 2;                                     // getSearchDistForClass of the Merge filter (class_bw stays NULL)
+    if ((P->vote_bbox_quat == nullptr) != (P->max_bbox_quat_out == nullptr)) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "hough3d_maxima: vote_bbox_quat and max_bbox_quat_out go together");
+    h.vbq = P->vote_bbox_quat; a.mbq = P->max_bbox_quat_out;
     a.n_max = n_maxima_out; a.mpos = max_pos_out; a.mw = max_weight_out; a.mcls = max_class_out; a.minst = max_instance_out;
     a.miw = max_instance_weight_out; a.mbs = max_bbox_size_out; a.mnv = max_n_votes_out; a.class_score = class_score_out;
     a.rec = h.rec; a.rec_count = h.rec_count;

@@ -423,7 +423,8 @@ extern "C" int ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim
     hipLaunchKernelGGL(k_tr_stats1, dim3(gn), dim3(256), 0, st, n_words_p, vote_off, vote_feature, feat_class, vote_word, num_features, words_per_class);
     hipLaunchKernelGGL(k_tr_weights, dim3(2048), dim3(256), 0, st, (uint32_t)na, n_votes_p, vote_word, vote_off, vote_feature, vote_xyz, lrf9, kpx, kpy, kpz, center,
                        vote_weight, overflow);
-    if (codewords != desc) {                                          // clustered codebooks can have codewords with thousands of votes
+    {   // codewords with 2049 .. 32768 votes: clustered codebooks, but also a hub word or many duplicate descriptors with Clustering
+        // "None" and k > 1 / KNNRule (every tie goes to the lowest row) -- the kernel skips every smaller word by itself
         if (!ctx->attr_done.count((const void*)k_tr_weights_big)) {
             TR_HIP(hipFuncSetAttribute((const void*)k_tr_weights_big, hipFuncAttributeMaxDynamicSharedMemorySize, TR_MAXM_BIG * 4));
             ctx->attr_done.insert((const void*)k_tr_weights_big);

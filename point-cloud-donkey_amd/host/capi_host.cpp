@@ -118,7 +118,8 @@ int ism3d_set_dimensions(void* m, unsigned class_id, const float* in4) { GUARD((
 // detectBatch over concatenated SoA arrays; outputs per object up to max_maxima records sorted by weight
 int ism3d_detect_batch(void* m, int n_obj, const uint32_t* pt_off, const float* x, const float* y, const float* z, const float* nx, const float* ny,
                        const float* nz, const uint32_t* rgba, int max_maxima, int32_t* n_out, float* pos_out, float* weight_out, int32_t* cls_out,
-                       int32_t* inst_out, int32_t* nvotes_out) {
+                       int32_t* inst_out, int32_t* nvotes_out, float* quat_out /* [n_obj*max_maxima*4] boundingBox.rotQuat, may be NULL */,
+                       int32_t* n_total_out /* [n_obj] maxima the model returned (may exceed max_maxima), may be NULL */) {
     GUARD(
         std::vector<PointCloud> clouds(n_obj);
         std::vector<const PointCloud*> ptrs;
@@ -131,12 +132,14 @@ int ism3d_detect_batch(void* m, int n_obj, const uint32_t* pt_off, const float* 
         for (int o = 0; o < n_obj; ++o) {
             const int nm = std::min((int)res[o].size(), max_maxima);
             n_out[o] = nm;
+            if (n_total_out) n_total_out[o] = (int)res[o].size();
             for (int i = 0; i < max_maxima; ++i) {
                 const size_t t = (size_t)o * max_maxima + i;
                 const bool ok = i < nm;
                 pos_out[t * 3] = ok ? res[o][i].position[0] : 0; pos_out[t * 3 + 1] = ok ? res[o][i].position[1] : 0; pos_out[t * 3 + 2] = ok ? res[o][i].position[2] : 0;
                 weight_out[t] = ok ? res[o][i].weight : 0; cls_out[t] = ok ? (int)res[o][i].classId : -1; inst_out[t] = ok ? (int)res[o][i].instanceId : -1;
                 nvotes_out[t] = ok ? res[o][i].numVotes : 0;
+                if (quat_out) for (int d = 0; d < 4; ++d) quat_out[t * 4 + d] = ok ? res[o][i].boundingBox.rotQuat[d] : (d == 0 ? 1.f : 0.f);
             }
         }
         return 0;)

@@ -63,7 +63,8 @@ public:
     ismhip_cloud* cloud = nullptr;
     bool has_color = false;
     // vote space of the current batch (Voting::m_votes)
-    DevBuf v_pos, v_w, v_cls, v_inst, v_cw, v_bs, idx, dist;
+    DevBuf v_pos, v_w, v_cls, v_inst, v_cw, v_bs, v_bq, idx, dist;
+    DevBuf obj_cen, obj_rad;              // per-object cloud centroid / farthest point (single-object max types)
     std::vector<uint32_t> slot_off;
     size_t n_slots = 0;
     int n_classes = 0;
@@ -539,12 +540,12 @@ void Codebook::castVotes(DeviceSession& s, const DeviceFeatures& f, int metric, 
     if (qdesc) s.check(ismhip_sync(s.ctx), "ismhip_sync");     // the partial descriptors are released when this function returns
     const int maxv = ismhip_codebook_max_votes_per_word(m_dev);
     const size_t ns = (size_t)n * k * maxv;
-    s.v_pos.reserve(ns * 12); s.v_w.reserve(ns * 4); s.v_cls.reserve(ns * 4); s.v_inst.reserve(ns * 4); s.v_cw.reserve(ns * 4); s.v_bs.reserve(ns * 12);
+    s.v_pos.reserve(ns * 12); s.v_w.reserve(ns * 4); s.v_cls.reserve(ns * 4); s.v_inst.reserve(ns * 4); s.v_cw.reserve(ns * 4); s.v_bs.reserve(ns * 12); s.v_bq.reserve(ns * 16);
     const uint32_t flags = (m_useClassWeight ? ISMHIP_W_CLASS : 0u) | (m_useVoteWeight ? ISMHIP_W_VOTE : 0u) |
                            (m_useMatchingWeight ? ISMHIP_W_MATCHING : 0u) | (m_useCodewordWeight ? ISMHIP_W_CODEWORD : 0u);
     s.check(ismhip_cast_votes(s.ctx, m_dev, flags, (int)n, f.lrf.as<float>(), f.kx.as<float>(), f.ky.as<float>(), f.kz.as<float>(), k, s.idx.as<int32_t>(),
                               s.dist.as<float>(), s.v_pos.as<float>(), s.v_w.as<float>(), s.v_cls.as<int32_t>(), s.v_inst.as<int32_t>(), s.v_cw.as<int32_t>(),
-                              nullptr, s.v_bs.as<float>()), "ismhip_cast_votes");
+                              s.v_bq.as<float>(), s.v_bs.as<float>()), "ismhip_cast_votes");
     s.n_slots = ns;
     for (int o = 0; o <= s.n_obj; ++o) s.slot_off[o] = f.off[o] * (uint32_t)(k * maxv);
     s.n_classes = (int)m_data.class_sigma.size();
@@ -749,16 +750,37 @@ void Voting::clear() {}
 std::vector<std::vector<VotingMaximum>> Voting::findMaxima(DeviceSession& s) {
     if (m_use_global_features) throw RuntimeException("UseGlobalFeatures is out of scope of the MI355X path (SURVEY §2 row 10)");
     if (m_vote_filtering_with_ransac) throw RuntimeException("RansacVoteFiltering is not built on the MI355X path");
-    if (m_max_filter_type != "None" && m_max_filter_type != "Simple") throw RuntimeException("MaxFilterType \"" + m_max_filter_type + "\" is not built (built: \"None\", \"Simple\")");
-    if (m_single_object_mode && m_max_type_param != "None" && m_max_type_param != "Default")
-        throw RuntimeException("SingleObjectMaxType \"" + m_max_type_param + "\" is not built (only \"None\"/\"Default\")");
+    if (m_max_filter_type != "None" && m_max_filter_type != "Simple" && m_max_filter_type != "Merge")
+        LOG_ERROR("Invalid maxima filter type specified: " << m_max_filter_type << "! No filtering is performed!");            // maxima_handler.cpp:292-295
+    if (m_max_type_param != "None" && m_max_type_param != "Default" && m_max_type_param != "BandwidthVotes" && m_max_type_param != "VotingSpaceVotes" &&
+        m_max_type_param != "ModelRadiusVotes")
+        LOG_WARN("Invalid single object maximum type: " << m_max_type_param << "! Using default instead.");                   // maxima_handler.h:53-57
     std::vector<std::vector<VotingMaximum>> out(s.n_obj);
     if (s.n_slots == 0) return out;
+    if (singleObjectMaxType() != ISMHIP_SOM_MEANSHIFT) {       // voting_mean_shift.cpp:124-157: the query point is the centroid of the object's cloud
+        s.obj_cen.reserve((size_t)s.n_obj * 12); s.obj_rad.reserve((size_t)s.n_obj * 4);
+        s.check(ismhip_cloud_centroids(s.ctx, s.cloud, s.obj_cen.as<float>()), "ismhip_cloud_centroids");
+        s.check(ismhip_cloud_radii(s.ctx, s.cloud, s.obj_cen.as<float>(), s.obj_rad.as<float>()), "ismhip_cloud_radii");
+    }
     iFindMaxima(s, out);
     return out;
 }
+int Voting::singleObjectMaxType() const {                      // maxima_handler.h:42-58; only consulted in single-object mode (voting_mean_shift.cpp:80)
+    if (!m_single_object_mode) return ISMHIP_SOM_MEANSHIFT;
+    if (m_max_type_param == "BandwidthVotes") return ISMHIP_SOM_BANDWIDTH;
+    if (m_max_type_param == "VotingSpaceVotes") return ISMHIP_SOM_COMPLETE_VOTING_SPACE;
+    if (m_max_type_param == "ModelRadiusVotes") return ISMHIP_SOM_MODEL_RADIUS;
+    return ISMHIP_SOM_MEANSHIFT;
+}
+int Voting::maxFilter() const {                                // voting.cpp:262-268: no inter-class filter in single-object mode
+    if (m_single_object_mode) return ISMHIP_MAXFILTER_NONE;
+    return m_max_filter_type == "Simple" ? ISMHIP_MAXFILTER_SIMPLE : (m_max_filter_type == "Merge" ? ISMHIP_MAXFILTER_MERGE : ISMHIP_MAXFILTER_NONE);
+}
 
-struct Voting::MaximaBuffers { DevBuf n_max, pos, w, cls, inst, iw, bs, nv, score; int M = 32; void reserve(int n_obj, int C); };
+// M = maxima per object the buffers hold. The reference returns every maximum (voting.cpp:236-272), the device call a fixed capacity:
+// the host asks for 32 and, when some object fills them all, again for 1024 = the kernels' own per-object limit, beyond which
+// ismhip_sync reports the truncation.
+struct Voting::MaximaBuffers { DevBuf n_max, pos, w, cls, inst, iw, bs, bq, nv, score; int M = 32; void reserve(int n_obj, int C); };
 VotingMeanShift::VotingMeanShift() {              // voting_mean_shift.cpp:20-27
     addParameter(m_bandwidth, "Bandwidth", 0.2f);
     addParameter(m_threshold, "Threshold", 1e-3f);
@@ -768,29 +790,36 @@ VotingMeanShift::VotingMeanShift() {              // voting_mean_shift.cpp:20-27
 }
 void VotingMeanShift::iFindMaxima(DeviceSession& s, std::vector<std::vector<VotingMaximum>>& out) {
     const int C = std::max(1, s.n_classes);
-    const int M = 32;
-    ismhip_maxima_params P;
+    for (int M : {32, 1024}) {
+    ismhip_maxima_params P{};
     const std::vector<float> class_bw = searchDistPerClass(m_bandwidth, C);      // voting_mean_shift.cpp:46-49
     P.n_classes = C; P.class_bandwidth_h = class_bw.empty() ? nullptr : class_bw.data(); P.bandwidth = m_bandwidth; P.threshold = m_threshold; P.max_iter = m_maxIter;
     P.kernel = m_kernel == "Uniform" ? ISMHIP_KERNEL_UNIFORM : ISMHIP_KERNEL_GAUSSIAN;
     P.suppression = m_maxima_suppression_type == "Average" ? ISMHIP_SUPPRESS_AVERAGE : (m_maxima_suppression_type == "Suppress" ? ISMHIP_SUPPRESS_SUPPRESS : ISMHIP_SUPPRESS_NONE);
     P.min_votes_threshold = m_minVotesThreshold; P.min_threshold = m_minThreshold; P.best_k = m_bestK; P.max_maxima = M;
-    P.max_filter = (!m_single_object_mode && m_max_filter_type == "Simple") ? ISMHIP_MAXFILTER_SIMPLE : ISMHIP_MAXFILTER_NONE;   // voting.cpp:262-268
+    P.max_filter = maxFilter();
     MaximaBuffers B; B.M = M; B.reserve(s.n_obj, C);
+    if (m_averageRotation) { P.vote_bbox_quat = s.v_bq.as<float>(); P.max_bbox_quat_out = B.bq.as<float>(); }              // voting.cpp:210-215
+    P.single_object_max_type = singleObjectMaxType(); P.object_centroid = s.obj_cen.as<float>(); P.object_radius = s.obj_rad.as<float>();
     s.check(ismhip_find_maxima(s.ctx, s.n_obj, s.slot_off.data(), s.v_pos.as<float>(), s.v_w.as<float>(), s.v_cls.as<int32_t>(), s.v_inst.as<int32_t>(),
                                s.v_bs.as<float>(), &P, B.n_max.as<int32_t>(), B.pos.as<float>(), B.w.as<float>(), B.cls.as<int32_t>(), B.inst.as<int32_t>(),
                                B.iw.as<float>(), B.bs.as<float>(), B.nv.as<int32_t>(), B.score.as<float>()), "ismhip_find_maxima");
-    collectMaxima(s, B, out);
+    if (collectMaxima(s, B, out, m_averageRotation) || M == 1024) break;
+    }
 }
 void Voting::MaximaBuffers::reserve(int n_obj, int C) {
     const size_t t = (size_t)n_obj * M;
     n_max.reserve((size_t)n_obj * 4); pos.reserve(t * 12); w.reserve(t * 4); cls.reserve(t * 4); inst.reserve(t * 4); iw.reserve(t * 4); bs.reserve(t * 12);
-    nv.reserve(t * 4); score.reserve((size_t)n_obj * C * 4);
+    nv.reserve(t * 4); score.reserve((size_t)n_obj * C * 4); bq.reserve(t * 16);
 }
-void Voting::collectMaxima(DeviceSession& s, MaximaBuffers& b, std::vector<std::vector<VotingMaximum>>& out) {
+// returns false when some object filled all M slots (the caller asks again with more room)
+bool Voting::collectMaxima(DeviceSession& s, MaximaBuffers& b, std::vector<std::vector<VotingMaximum>>& out, bool with_quat) {
     const int M = b.M; const size_t t = (size_t)s.n_obj * M;
-    std::vector<int32_t> hn, hcls, hinst, hnv; std::vector<float> hpos, hw, hiw, hbs;
-    s.d2h(hn, b.n_max, s.n_obj); s.d2h(hpos, b.pos, t * 3); s.d2h(hw, b.w, t); s.d2h(hcls, b.cls, t); s.d2h(hinst, b.inst, t); s.d2h(hiw, b.iw, t); s.d2h(hbs, b.bs, t * 3); s.d2h(hnv, b.nv, t);
+    std::vector<int32_t> hn, hcls, hinst, hnv; std::vector<float> hpos, hw, hiw, hbs, hbq;
+    s.d2h(hn, b.n_max, s.n_obj);
+    for (int o = 0; o < s.n_obj; ++o) if (hn[o] >= M && M < 1024) return false;
+    if (with_quat) s.d2h(hbq, b.bq, t * 4);
+    s.d2h(hpos, b.pos, t * 3); s.d2h(hw, b.w, t); s.d2h(hcls, b.cls, t); s.d2h(hinst, b.inst, t); s.d2h(hiw, b.iw, t); s.d2h(hbs, b.bs, t * 3); s.d2h(hnv, b.nv, t);
     for (int o = 0; o < s.n_obj; ++o)
         for (int m = 0; m < hn[o]; ++m) {
             const size_t i = (size_t)o * M + m;
@@ -798,8 +827,10 @@ void Voting::collectMaxima(DeviceSession& s, MaximaBuffers& b, std::vector<std::
             vm.position = {hpos[i * 3], hpos[i * 3 + 1], hpos[i * 3 + 2]}; vm.weight = hw[i]; vm.classId = (unsigned)hcls[i]; vm.instanceId = (unsigned)hinst[i];
             vm.instanceWeight = hiw[i]; vm.numVotes = hnv[i];
             vm.boundingBox.position = vm.position; vm.boundingBox.size = {hbs[i * 3], hbs[i * 3 + 1], hbs[i * 3 + 2]};
+            if (with_quat) vm.boundingBox.rotQuat = {hbq[i * 4], hbq[i * 4 + 1], hbq[i * 4 + 2], hbq[i * 4 + 3]};
             out[o].push_back(vm);
         }
+    return true;
 }
 
 VotingHough3D::VotingHough3D() {                  // voting_hough_3d.cpp:15-26
@@ -812,7 +843,8 @@ VotingHough3D::VotingHough3D() {                  // voting_hough_3d.cpp:15-26
 void VotingHough3D::iFindMaxima(DeviceSession& s, std::vector<std::vector<VotingMaximum>>& out) {
     if (m_single_object_mode) LOG_WARN("SingleObjectMode is not supported with Hough3D - switch to MeanShift to use it!");   // :42-43
     const int C = std::max(1, s.n_classes);
-    ismhip_hough_params P;
+    for (int M : {32, 1024}) {
+    ismhip_hough_params P{};
     P.n_classes = C;
     for (int d = 0; d < 3; ++d) { P.min_coord[d] = (float)m_minCoord[d]; P.max_coord[d] = (float)m_maxCoord[d]; }
     // :45-47: MaximaHandler::setRadius(BinSize[0] / 2); the bins become cubes of edge 2 * getSearchDistForClass (= BinSize[0] with "Config")
@@ -822,12 +854,14 @@ void VotingHough3D::iFindMaxima(DeviceSession& s, std::vector<std::vector<Voting
     P.class_bin_h = class_bin.empty() ? nullptr : class_bin.data();
     P.use_interpolation = m_useInterpolation ? 1 : 0; P.rel_threshold = m_relThreshold;
     P.min_votes_threshold = m_minVotesThreshold; P.min_threshold = m_minThreshold; P.best_k = m_bestK;
-    P.max_filter = (!m_single_object_mode && m_max_filter_type == "Simple") ? ISMHIP_MAXFILTER_SIMPLE : ISMHIP_MAXFILTER_NONE;
-    MaximaBuffers B; P.max_maxima = B.M; B.reserve(s.n_obj, C);
+    P.max_filter = maxFilter();
+    MaximaBuffers B; B.M = M; P.max_maxima = B.M; B.reserve(s.n_obj, C);
+    if (m_averageRotation) { P.vote_bbox_quat = s.v_bq.as<float>(); P.max_bbox_quat_out = B.bq.as<float>(); }
     s.check(ismhip_hough3d_maxima(s.ctx, s.n_obj, s.slot_off.data(), s.v_pos.as<float>(), s.v_w.as<float>(), s.v_cls.as<int32_t>(), s.v_inst.as<int32_t>(),
                                   s.v_bs.as<float>(), &P, B.n_max.as<int32_t>(), B.pos.as<float>(), B.w.as<float>(), B.cls.as<int32_t>(), B.inst.as<int32_t>(),
                                   B.iw.as<float>(), B.bs.as<float>(), B.nv.as<int32_t>(), B.score.as<float>()), "ismhip_hough3d_maxima");
-    collectMaxima(s, B, out);
+    if (collectMaxima(s, B, out, m_averageRotation) || M == 1024) break;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1237,15 +1271,19 @@ std::vector<std::vector<VotingMaximum>> ImplicitShapeModel::detectBatch(const st
 
 std::tuple<std::vector<VotingMaximum>, std::map<std::string, double>> ImplicitShapeModel::detect(const PointCloud& pointCloud, bool hasNormals) {
     if (pointCloud.empty()) { LOG_WARN("point cloud is empty"); return std::make_tuple(std::vector<VotingMaximum>(), m_processing_times); }
-    if (!hasNormals) throw RuntimeException("input cloud has no normals: normal estimation on the device is not built yet (SURVEY §8f row 3)");
-    auto r = detectBatch({&pointCloud});
+    // hasNormals == false (the reference's detect(PointCloud<PointT>) overload, :575-581): whatever normals the cloud carries are ignored and
+    // estimated again; hasNormals == true is still checked against the FIRST point (:615-625) inside computeFeatures (firstNormalValid)
+    PointCloud stripped;
+    const PointCloud* in = &pointCloud;
+    if (!hasNormals) { stripped = pointCloud; stripped.nx.assign(stripped.size(), 0.f); stripped.ny.assign(stripped.size(), 0.f); stripped.nz.assign(stripped.size(), 0.f); in = &stripped; }
+    auto r = detectBatch({in});
     LOG_INFO("detected " << r[0].size() << " maxima");
     return std::make_tuple(r[0], m_processing_times);
 }
 bool ImplicitShapeModel::detect(const std::string& filename, std::vector<VotingMaximum>& maxima, std::map<std::string, double>& times) {   // :564-573
     std::shared_ptr<PointCloud> c = loadPointCloud(filename);
     if (!c) return false;
-    std::tie(maxima, times) = detect(*c, true);
+    std::tie(maxima, times) = detect(*c, true);      // "true is assumed because of point type" (:568); the first normal decides (firstNormalValid)
     return true;
 }
 

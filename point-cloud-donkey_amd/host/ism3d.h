@@ -395,7 +395,9 @@ protected:
     virtual void iFindMaxima(DeviceSession& s, std::vector<std::vector<VotingMaximum>>& out) = 0;
     // device outputs of ismhip_find_maxima / ismhip_hough3d_maxima -> VotingMaximum lists
     struct MaximaBuffers;                                        // defined in ism3d.cpp (device buffers)
-    static void collectMaxima(DeviceSession& s, MaximaBuffers& b, std::vector<std::vector<VotingMaximum>>& out);
+    static bool collectMaxima(DeviceSession& s, MaximaBuffers& b, std::vector<std::vector<VotingMaximum>>& out, bool with_quat);
+    int singleObjectMaxType() const;                             // ISMHIP_SOM_* from SingleObjectMode / SingleObjectMaxType
+    int maxFilter() const;                                       // ISMHIP_MAXFILTER_* from MaxFilterType
     float m_minThreshold; int m_minVotesThreshold; int m_bestK; bool m_averageRotation;
     std::string m_radiusType; float m_radiusFactor; std::string m_max_filter_type, m_max_type_param;
     bool m_single_object_mode; bool m_use_global_features; bool m_vote_filtering_with_ransac;

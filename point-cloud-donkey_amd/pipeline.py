@@ -38,6 +38,10 @@ class IsmConfig:
     min_threshold: float = 0.0
     best_k: int = -1
     max_maxima: int = 16
+    average_rotation: bool = False   # Voting.AverageRotation (voting.cpp:210-215): out["bbox_quat"]
+    max_filter: str = "None"         # Voting.MaxFilterType: "None" | "Simple" | "Merge" (ignored in single-object mode, voting.cpp:262-268)
+    single_object_mode: bool = False # Voting.SingleObjectMode
+    single_object_max_type: str = "Default"   # Voting.SingleObjectMaxType: "Default" | "BandwidthVotes" | "ModelRadiusVotes" | "VotingSpaceVotes"
     use_partial_shot: bool = False   # Codebook.UsePartialShot / PartialShotType (SHOT-352 only, codebook.cpp:416-475)
     partial_shot_type: str = "front"
     voting: str = "MeanShift"        # Voting.Type: "MeanShift" | "Hough3D"
@@ -262,51 +266,27 @@ class Recognizer:
             idx, dist = capi.knn_ratio(ctx, cb, c.metric, q, c.distance_ratio_threshold)
         else:
             idx, dist = capi.knn(ctx, cb, c.metric, q, c.k)
-        votes = capi.cast_votes(ctx, cb, c.weight_flags, f["lrf"], f["kx"], f["ky"], f["kz"], idx, dist)
+        votes = capi.cast_votes(ctx, cb, c.weight_flags, f["lrf"], f["kx"], f["ky"], f["kz"], idx, dist, want_bbox=c.average_rotation)
         slot_off = f["off"].astype(np.uint64) * (c.k * cb.max_votes)
+        max_filter = capi.MAXFILTER_NONE if c.single_object_mode else {"Simple": capi.MAXFILTER_SIMPLE, "Merge": capi.MAXFILTER_MERGE}.get(c.max_filter, capi.MAXFILTER_NONE)
         if c.voting == "Hough3D":
             mx = capi.hough3d_maxima(ctx, slot_off.astype(np.uint32), votes, c.n_classes, c.hough_bin_size, c.hough_min_coord, c.hough_max_coord,
-                                     c.hough_use_interpolation, c.hough_rel_threshold, c.min_votes_threshold, c.min_threshold, c.best_k, c.max_maxima)
+                                     c.hough_use_interpolation, c.hough_rel_threshold, c.min_votes_threshold, c.min_threshold, c.best_k, c.max_maxima,
+                                     max_filter=max_filter, average_rotation=c.average_rotation)
         else:
+            som = capi.SOM_MEANSHIFT if not c.single_object_mode else {"BandwidthVotes": capi.SOM_BANDWIDTH, "ModelRadiusVotes": capi.SOM_MODEL_RADIUS,
+                                                                      "VotingSpaceVotes": capi.SOM_COMPLETE_VOTING_SPACE}.get(c.single_object_max_type, capi.SOM_MEANSHIFT)
+            cen = rad = None
+            if som != capi.SOM_MEANSHIFT:                      # the query point is the centroid of the object's cloud (voting_mean_shift.cpp:126-132)
+                cen = capi.cloud_centroids(ctx, f["cloud"], b.x.device)
+                rad = capi.cloud_radii(ctx, f["cloud"], cen)
             mx = capi.find_maxima(ctx, slot_off.astype(np.uint32), votes, c.n_classes, c.bandwidth, c.threshold, c.max_iter,
                                   capi.KERNEL_GAUSSIAN if c.kernel == "Gaussian" else capi.KERNEL_UNIFORM,
                                   {"Average": capi.SUPPRESS_AVERAGE, "Suppress": capi.SUPPRESS_SUPPRESS}.get(c.maxima_suppression, capi.SUPPRESS_NONE),
-                                  c.min_votes_threshold, c.min_threshold, c.best_k, c.max_maxima)
+                                  c.min_votes_threshold, c.min_threshold, c.best_k, c.max_maxima, max_filter=max_filter,
+                                  average_rotation=c.average_rotation, single_object_max_type=som, object_centroid=cen, object_radius=rad)
         if keep_intermediates:
             mx.update(features=f, idx=idx, dist=dist, votes=votes, slot_off=slot_off.astype(np.uint32))
         else:
             mx["_keep"] = (f, idx, dist, votes)   # outputs are produced asynchronously: keep inputs alive until the caller syncs
         return mx
-
-
-def class_sigmas_numpy(metric, feats, feat_class, feat_model, activated, n_classes):
-    """per-class sigma of Codebook::activate step 1 (codebook/codebook.cpp:94-193), float32 accumulation."""
-    out = np.full(n_classes, np.nan, np.float32)
-    for c in range(n_classes):
-        ids = np.nonzero(feat_class == c)[0]
-        if len(ids) == 0:
-            continue
-        ids = ids[np.argsort(feat_model[ids], kind="stable")]
-        max_elements = int(np.sqrt(float(len(ids))))
-        words = activated[ids][:max_elements]
-        words = words[words >= 0]
-        models = feat_model[ids]
-        allf = []
-        for m in np.unique(models):           # ascending = visiting order
-            if len(allf) >= max_elements:
-                break
-            allf.extend(ids[models == m].tolist())
-        A = feats[np.asarray(allf, np.int64)].astype(np.float32)
-        B = feats[words].astype(np.float32)
-        if metric == capi.METRIC_L2SQ:
-            d = ((A[:, None, :] - B[None, :, :]) ** 2).sum(-1, dtype=np.float32)
-        else:
-            s = A[:, None, :] + B[None, :, :]
-            diff = A[:, None, :] - B[None, :, :]
-            d = np.where(s > 0, diff * diff / np.where(s > 0, s, 1), 0).sum(-1, dtype=np.float32)
-        d = d.reshape(-1).astype(np.float32)
-        num = d.size
-        mean = np.float32(d.sum(dtype=np.float32) / np.float32(num))
-        var = np.float32(((d - mean) ** 2).sum(dtype=np.float32))
-        out[c] = var / np.float32(num - 1) if num > 1 else np.float32(np.nan)
-    return out

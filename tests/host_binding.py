@@ -129,9 +129,10 @@ class Model:
         c = None if rgba is None else np.ascontiguousarray(rgba, np.uint32)
         n = np.empty(n_obj, np.int32); pos = np.empty((n_obj, max_maxima, 3), np.float32); w = np.empty((n_obj, max_maxima), np.float32)
         cls = np.empty((n_obj, max_maxima), np.int32); inst = np.empty((n_obj, max_maxima), np.int32); nv = np.empty((n_obj, max_maxima), np.int32)
+        quat = np.empty((n_obj, max_maxima, 4), np.float32); n_total = np.empty(n_obj, np.int32)
         self._ck(self.L.ism3d_detect_batch(self.h, n_obj, _p(po), _p(x), _p(y), _p(z), _p(nx), _p(ny), _p(nz), _p(c), max_maxima, _p(n), _p(pos), _p(w),
-                                           _p(cls), _p(inst), _p(nv)), "detectBatch")
-        return dict(n=n, pos=pos, weight=w, cls=cls, inst=inst, n_votes=nv)
+                                           _p(cls), _p(inst), _p(nv), _p(quat), _p(n_total)), "detectBatch")
+        return dict(n=n, pos=pos, weight=w, cls=cls, inst=inst, n_votes=nv, bbox_quat=quat, n_total=n_total)
 
     def detect_file(self, path):
         cls, w = C.c_int32(), C.c_float()

@@ -819,6 +819,146 @@ def test_find_maxima_matches_oracle(pkg, gpu, ora, suppression, kernel):
     assert want["n"][1] == 0 and want["n"].max() >= 2
 
 
+def _with_quats(rng, v):
+    """bbox quaternions per vote slot: a few base rotations per blob-ish neighbourhood + jitter, unit length"""
+    n = len(v["weight"])
+    base = rng.normal(size=(6, 4)); base /= np.linalg.norm(base, axis=1, keepdims=True)
+    q = base[rng.integers(0, 6, n)] + 0.05 * rng.normal(size=(n, 4))
+    q *= np.where(rng.random(n) < 0.5, -1.0, 1.0)[:, None]           # q and -q are the same rotation: the scatter matrix does not care
+    v = dict(v); v["bbox_quat"] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    return v
+
+
+def _same_rotation(a, b, atol):
+    """quaternions equal up to the global sign"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    d = np.minimum(np.abs(a - b).max(-1), np.abs(a + b).max(-1))
+    return bool((d < atol).all()), float(d.max())
+
+
+@pytest.mark.parametrize("voting", ["meanshift", "hough"])
+def test_average_rotation_matches_oracle_and_closed_form(pkg, gpu, ora, voting):
+    """Voting.AverageRotation (voting.cpp:186-215 -> Utils::quatWeightedAverage, utils.cpp:617-665): per maximum the dominant
+    eigenvector of sum w q q^T over its votes. HIP vs oracle on random scenes; and a closed form: two votes with the SAME weight and
+    quaternions q1, q2 average to (q1 + q2) / |q1 + q2| (and one vote returns its own quaternion)."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(61)
+    off, v = _vote_scene(rng, 10, 4)
+    v = _with_quats(rng, v)
+    tv = {k2: T(a, dev) for k2, a in v.items()}
+    if voting == "meanshift":
+        kw = dict(n_classes=4, bandwidth=0.5, max_maxima=12, min_votes_threshold=2, average_rotation=True)
+        got = pkg.capi.find_maxima(ctx, off, tv, **kw); want = ora.find_maxima(off, v, **kw)
+    else:
+        kw = dict(n_classes=4, bin_size=0.5, max_maxima=12, min_votes_threshold=2, rel_threshold=0.3, average_rotation=True)
+        got = pkg.capi.hough3d_maxima(ctx, off, tv, **kw); want = ora.hough3d_maxima(off, v, **kw)
+    assert np.array_equal(got["n"].cpu().numpy(), want["n"]) and want["n"].sum() > 10
+    assert np.array_equal(got["cls"].cpu().numpy(), want["cls"])
+    ok, err = _same_rotation(got["bbox_quat"].cpu().numpy(), want["bbox_quat"], 2e-4)
+    assert ok, err
+    # closed form
+    q1 = np.asarray([0.9, 0.1, -0.3, 0.2]); q1 /= np.linalg.norm(q1)
+    q2 = np.asarray([0.7, -0.4, 0.1, 0.5]); q2 /= np.linalg.norm(q2)
+    v2 = dict(pos=np.asarray([[0, 0, 0], [0.01, 0, 0], [3, 3, 3]], np.float32), weight=np.asarray([0.5, 0.5, 1.0], np.float32),
+              cls=np.asarray([0, 0, 1], np.int32), inst=np.zeros(3, np.int32), bbox_size=np.ones((3, 3), np.float32),
+              bbox_quat=np.stack([q1, q2, q2]).astype(np.float32))
+    off2 = np.asarray([0, 3], np.uint32)
+    tv2 = {k2: T(a, dev) for k2, a in v2.items()}
+    if voting == "meanshift":
+        kw = dict(n_classes=2, bandwidth=0.5, max_maxima=4, min_votes_threshold=1, average_rotation=True, kernel=1)   # uniform kernel: equal weights stay equal
+        outs = [pkg.capi.find_maxima(ctx, off2, tv2, **kw), ora.find_maxima(off2, v2, **kw)]
+    else:
+        kw = dict(n_classes=2, bin_size=1.0, max_maxima=4, min_votes_threshold=1, average_rotation=True, use_interpolation=False)
+        outs = [pkg.capi.hough3d_maxima(ctx, off2, tv2, **kw), ora.hough3d_maxima(off2, v2, **kw)]
+    mean = (q1 + q2) / np.linalg.norm(q1 + q2)
+    for o_ in outs:
+        cls = np.asarray(o_["cls"].cpu() if hasattr(o_["cls"], "cpu") else o_["cls"])[0]
+        bq = np.asarray(o_["bbox_quat"].cpu() if hasattr(o_["bbox_quat"], "cpu") else o_["bbox_quat"])[0]
+        assert sorted(cls[:2].tolist()) == [0, 1]
+        assert _same_rotation(bq[list(cls[:2]).index(0)], mean, 1e-5)[0]
+        assert _same_rotation(bq[list(cls[:2]).index(1)], q2, 1e-5)[0]
+
+
+@pytest.mark.parametrize("som", [1, 2, 3])
+def test_single_object_max_types_match_oracle(pkg, gpu, ora, som):
+    """SingleObjectMode with SingleObjectMaxType BANDWIDTH / MODEL_RADIUS / COMPLETE_VOTING_SPACE (voting_mean_shift.cpp:124-157,
+    single_object_mode_helper.cpp:15-40): no mean shift, one maximum per class at the centroid of the object's cloud, density and
+    reweighting with the type's bandwidth. Centroid and model radius come from the device cloud (ismhip_cloud_centroids / _radii)
+    and are checked against numpy first."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(70 + som)
+    off, v = _vote_scene(rng, 8, 4)
+    objs = [make_cloud(rng, 1200 + 100 * o, ("sphere", "ellipsoid", "plane")[o % 3], noise=0.01) for o in range(8)]
+    objs = [((p + rng.uniform(-1, 1, 3)).astype(np.float32), n_) for p, n_ in objs]            # off-centre clouds
+    sc = Scene(pkg, gpu, objs, [p[:8] for p, _ in objs], 0.15)
+    cen = pkg.capi.cloud_centroids(ctx, sc.cloud, dev)
+    rad = pkg.capi.cloud_radii(ctx, sc.cloud, cen)
+    cen_h, rad_h = cen.cpu().numpy(), rad.cpu().numpy()
+    for o in range(8):
+        s, e = sc.pt_off[o], sc.pt_off[o + 1]
+        c64 = sc.p[s:e].astype(np.float64).mean(0)
+        assert np.abs(cen_h[o] - c64).max() < 1e-5
+        d = np.sqrt(((sc.p[s:e] - cen_h[o]) ** 2).sum(1, dtype=np.float32))
+        assert abs(rad_h[o] - d.max()) < 1e-5 * max(1.0, d.max())
+    tv = {k2: T(a, dev) for k2, a in v.items()}
+    kw = dict(n_classes=4, bandwidth=0.8, max_maxima=8, min_votes_threshold=1, single_object_max_type=som)
+    got = pkg.capi.find_maxima(ctx, off, tv, object_centroid=cen, object_radius=rad, **kw)
+    want = ora.find_maxima(off, v, object_centroid=cen_h, object_radius=rad_h, **kw)
+    assert np.array_equal(got["n"].cpu().numpy(), want["n"])
+    assert np.array_equal(got["cls"].cpu().numpy(), want["cls"]) and np.array_equal(got["inst"].cpu().numpy(), want["inst"])
+    assert np.array_equal(got["n_votes"].cpu().numpy(), want["n_votes"])
+    np.testing.assert_allclose(got["weight"].cpu().numpy(), want["weight"], atol=TOL)
+    np.testing.assert_allclose(got["pos"].cpu().numpy(), want["pos"], atol=1e-6)
+    np.testing.assert_allclose(got["bbox_size"].cpu().numpy(), want["bbox_size"], atol=1e-3)
+    # every maximum sits at its object's centroid, at most one per class that has votes (a class whose votes all lie outside the
+    # type's bandwidth gets none)
+    n = want["n"]
+    assert n.sum() >= 4
+    for o in range(8):
+        assert n[o] <= len(set(v["cls"][off[o]:off[o + 1]][v["cls"][off[o]:off[o + 1]] >= 0].tolist()))
+        assert len(set(want["cls"][o, :n[o]].tolist())) == n[o]
+        for m in range(n[o]):
+            assert np.abs(want["pos"][o, m] - cen_h[o]).max() < 1e-6
+
+
+def test_max_filter_merge_matches_oracle(pkg, gpu, ora):
+    """MaxFilterType "Merge" (maxima_handler.cpp:300-440): neighbourhoods of maxima closer than the first one's search distance are
+    merged per class (running weighted means, instance tallies, quaternion average) and replaced by the heaviest merged maximum.
+    Scenes with blobs of DIFFERENT classes on top of each other and same-class blobs just outside the intra-class suppression."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(83)
+    pos, w, cls, inst, bs, off = [], [], [], [], [], [0]
+    for o in range(12):
+        for b in range(rng.integers(2, 4)):
+            centre = rng.uniform(-1.5, 1.5, 3)
+            for c in rng.choice(5, size=rng.integers(1, 4), replace=False):      # several classes vote for (almost) the same place
+                m = rng.integers(8, 60)
+                pos.append(centre + rng.uniform(-0.2, 0.2, 3) + 0.08 * rng.normal(size=(m, 3))); w.append(rng.uniform(0.2, 1.0, m))
+                cls.append(np.full(m, c)); inst.append(rng.integers(0, 3, m)); bs.append(rng.uniform(0.5, 1.5, (m, 3)))
+        off.append(sum(len(x) for x in pos))
+    v = dict(pos=np.concatenate(pos).astype(np.float32), weight=np.concatenate(w).astype(np.float32), cls=np.concatenate(cls).astype(np.int32),
+             inst=np.concatenate(inst).astype(np.int32), bbox_size=np.concatenate(bs).astype(np.float32))
+    v = _with_quats(rng, v)
+    off = np.asarray(off, np.uint32)
+    tv = {k2: T(a, dev) for k2, a in v.items()}
+    cbw = np.asarray([0.5, 0.6, 0.4, 0.5, 0.7], np.float32)
+    for class_bandwidth in (None, cbw):
+        kw = dict(n_classes=5, bandwidth=0.5, max_maxima=16, min_votes_threshold=2, max_filter=2, average_rotation=True, class_bandwidth=class_bandwidth)
+        got = pkg.capi.find_maxima(ctx, off, tv, **kw)
+        want = ora.find_maxima(off, v, **kw)
+        plain = ora.find_maxima(off, v, **dict(kw, max_filter=0))
+        assert want["n"].sum() < plain["n"].sum()                                # neighbourhoods really were merged away
+        assert np.array_equal(got["n"].cpu().numpy(), want["n"])
+        assert np.array_equal(got["cls"].cpu().numpy(), want["cls"]) and np.array_equal(got["inst"].cpu().numpy(), want["inst"])
+        assert np.array_equal(got["n_votes"].cpu().numpy(), want["n_votes"])
+        np.testing.assert_allclose(got["weight"].cpu().numpy(), want["weight"], atol=TOL)
+        np.testing.assert_allclose(got["inst_weight"].cpu().numpy(), want["inst_weight"], atol=TOL)
+        np.testing.assert_allclose(got["pos"].cpu().numpy(), want["pos"], atol=2e-3)
+        np.testing.assert_allclose(got["bbox_size"].cpu().numpy(), want["bbox_size"], atol=1e-3)
+        ok, err = _same_rotation(got["bbox_quat"].cpu().numpy(), want["bbox_quat"], 5e-4)
+        assert ok, err
+
+
 def test_maxima_of_objects_with_more_slots_than_fit_lds(pkg, gpu, ora):
     """More than 2048 vote slots in one object (codewords with many votes, K > 1): the per-class vote arrays move from LDS to a
     workspace in HBM, laid out per (object, class) from a class tally. Same oracle, same tolerances as the LDS-resident kernels;
@@ -1072,6 +1212,25 @@ def _training_set(rng, n, D, n_proto=60, n_classes=4):
     lrf = Q.reshape(n, 9).astype(np.float32); kp = rng.normal(size=(n, 3)).astype(np.float32)
     centre = rng.normal(size=(10 * n_classes, 3)).astype(np.float32)[model]
     return feats, cls, model, lrf, kp, centre
+
+
+def test_train_activate_hub_word_with_more_than_2048_votes(pkg, gpu, ora):
+    """Clustering "None", k = 2, no clean-up: 2500 identical descriptors all activate the lowest two of their rows (ties go to the
+    lowest row), so those two words carry > 2048 votes each -- the range k_tr_weights leaves to k_tr_weights_big, which used to be
+    launched for clustered codebooks only (the vote weights of such a word stayed uninitialised)."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(77)
+    feats, cls, model, lrf, kp, centre = _training_set(rng, 4000, 32)
+    feats[700:3200] = feats[700]                                      # 2500 copies of one descriptor
+    got = pkg.capi.train_activate(ctx, 0, T(feats, dev), T(lrf, dev), T(kp[:, 0], dev), T(kp[:, 1], dev), T(kp[:, 2], dev), cls, model, centre,
+                                  k=2, clean_up=False, n_classes=4)
+    want = ora.activate(0, feats, lrf, kp, cls, model, centre, k=2, clean_up=False, n_classes=4)
+    assert np.diff(want["vote_offsets"].astype(np.int64)).max() > 2048
+    for key in ("word_src", "vote_offsets", "vote_feature"):
+        assert np.array_equal(got[key], want[key]), key
+    assert np.isfinite(got["vote_weight"]).all()
+    np.testing.assert_allclose(got["vote_weight"], want["vote_weight"], atol=2e-6)
+    np.testing.assert_allclose(got["vote_class_weight"], want["vote_class_weight"], rtol=1e-6, atol=1e-12)
 
 
 @pytest.mark.parametrize("init", ["FLANN_CENTERS_RANDOM", "FLANN_CENTERS_GONZALES", "FLANN_CENTERS_KMEANSPP"])

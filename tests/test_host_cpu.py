@@ -20,7 +20,7 @@ def test_c_abi_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/ismhip.h but not exported by libismhip.so"
     assert sorted(pkg.capi.EXPORTS) == declared
-    assert L.ismhip_abi_version() == 3
+    assert L.ismhip_abi_version() == 4
 
 
 def test_no_cpu_fallback(pkg):

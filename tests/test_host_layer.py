@@ -348,6 +348,70 @@ def test_host_hough3d_voting_matches_python_harness(pkg, gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("opts", ["average_rotation+merge", "single_object_bandwidth", "single_object_radius", "single_object_space", "many_maxima"])
+def test_host_voting_options_match_python_harness(pkg, gpu, opts):
+    """Voting options the shipped configs set and round 2 refused or ignored, through the C++ host with the reference's key names:
+    AverageRotation (bounding-box quaternion per maximum), MaxFilterType "Merge", SingleObjectMode with SingleObjectMaxType
+    BandwidthVotes / ModelRadiusVotes / VotingSpaceVotes; and an object with more maxima than the host's first 32-slot request
+    (BestK -1, MinThreshold 0, tiny bandwidth): the reference returns all of them, so must the host (second request with 1024)."""
+    ctx, dev = gpu
+    train, test = _dataset(pkg, 3, 9, 6)
+    order = sorted(range(9), key=lambda i: (train.label(i), i))
+    vp = {"MinThreshold": 0.0, "MinVotesThreshold": 1, "BestK": -1, "Bandwidth": 0.6}
+    kw = dict(n_classes=3, max_maxima=1024 if opts == "many_maxima" else 16)
+    if opts == "average_rotation+merge":
+        vp.update(AverageRotation=True, MaxFilterType="Merge"); kw.update(average_rotation=True, max_filter="Merge")
+    elif opts.startswith("single_object"):
+        t = {"single_object_bandwidth": "BandwidthVotes", "single_object_radius": "ModelRadiusVotes", "single_object_space": "VotingSpaceVotes"}[opts]
+        vp.update(SingleObjectMode=True, SingleObjectMaxType=t, MaxFilterType="Simple")          # the filter is skipped in single-object mode
+        kw.update(single_object_mode=True, single_object_max_type=t, max_filter="Simple")
+    else:
+        vp.update(Bandwidth=0.08, MaximaSuppression="Suppress"); kw.update(bandwidth=0.08, maxima_suppression="Suppress")
+    m = hb.Model()
+    m.config_from_json(_cfg(**{"Children/Voting/Parameters": vp}))
+    for i in order:
+        o = train.get(i)
+        m.add_training(o["xyz"], o["normals"], o["label"], i)
+    m.train()
+    rec = pkg.pipeline.Recognizer(ctx, pkg.pipeline.IsmConfig(**kw))
+    rec.train([pkg.pipeline.DeviceBatch(train.batch(order), dev)], instance_ids=order)
+    if opts == "average_rotation+merge":
+        # the harness trains without bounding boxes; the host stores box quaternion * conj(q(LRF)) and the box size per vote
+        # (codeword_distribution.cpp:63-70): run the harness on the HOST's codebook so that both see the same vote boxes
+        cbh = m.codebook_all()
+        assert cbh["words"].shape == rec.cb_host["words"].shape and np.abs(cbh["words"] - rec.cb_host["words"]).max() < 1e-4
+        rec.load_codebook({k: cbh[k] for k in ("words", "vote_offsets", "vote_xyz", "vote_class", "vote_instance", "class_sigma", "word_weight",
+                                               "vote_weight", "vote_class_weight", "vote_bbox_quat", "vote_bbox_size", "word_class")})
+    nb = test.batch(range(6))
+    M = kw["max_maxima"]
+    got = m.detect_batch(nb["pt_off"], nb["xyz"], nb["normals"], max_maxima=M)
+    want = rec.detect(pkg.pipeline.DeviceBatch(nb, dev))
+    ctx.sync()
+    wn = want["n"].cpu().numpy()
+    assert np.array_equal(got["n_total"], wn), (got["n_total"], wn)
+    if opts == "many_maxima":
+        assert wn.max() > 32, wn                                          # the construction really exceeded the first request
+    for o in range(6):
+        k = int(wn[o])
+        assert np.array_equal(got["cls"][o, :k], want["cls"][o, :k].cpu().numpy())
+        # (VotingSpaceVotes: the bandwidth IS the distance of the farthest vote, so that vote sits on the d^2 < h^2 edge and the 1e-5
+        # differences between the host's and the harness's keypoints can flip it -- the device itself is checked against the oracle
+        # on identical votes in test_single_object_max_types_match_oracle)
+        np.testing.assert_allclose(got["weight"][o, :k], want["weight"][o, :k].cpu().numpy(), atol=1e-2 if opts == "single_object_space" else 1e-4)
+        np.testing.assert_allclose(got["pos"][o, :k], want["pos"][o, :k].cpu().numpy(), atol=1e-3)
+        if opts == "average_rotation+merge":
+            a, b = got["bbox_quat"][o, :k].astype(np.float64), want["bbox_quat"][o, :k].cpu().numpy().astype(np.float64)
+            assert np.minimum(np.abs(a - b).max(-1), np.abs(a + b).max(-1)).max() < 1e-3
+            assert np.abs(np.linalg.norm(a, axis=1) - 1).max() < 1e-4
+    if opts.startswith("single_object"):
+        assert (wn <= 3).all() and wn.sum() >= 6                             # at most one maximum per class, at the cloud centroid
+        cen = np.stack([nb["xyz"][nb["pt_off"][o]:nb["pt_off"][o + 1]].astype(np.float64).mean(0) for o in range(6)])
+        for o in range(6):
+            for i in range(int(wn[o])):
+                assert np.abs(got["pos"][o, i] - cen[o]).max() < 1e-4
+
+
+@pytest.mark.gpu
 def test_host_partial_shot_and_bandwidth_types(pkg, gpu, tmp_path):
     """UsePartialShot / PartialShotType, BinOrBandwidthType ObjectRadius and MaxFilterType Simple through the C++ host (the size
     hints travel in the .ismd): the model still tells the synthetic classes apart, and the per-class hints are the training objects'."""
