@@ -416,12 +416,163 @@ def hough3d_three_bins():
                 tol=2e-6)
 
 
+def activate_weights():
+    """Round 3, KAT A: Codebook::activate on six 2-d features of two classes (codebook.cpp:64-368, codeword_distribution.cpp:169-243),
+    Clustering "None", K = 1, no clean-up, squared L2, identity reference frames. Class-major rows:
+        0: A0 (0,0)   1: A1 (0,0)   2: A2 (10,0)   |   3: B0 (0,0)   4: B1 (10,0)   5: B2 (20,0)
+    Exact duplicates activate the LOWEST row, so the kept codewords are rows 0 (votes of features 0,1,3), 2 (features 2,4), 5 (5).
+    computeWeights: vote i of a codeword with member features j gets the MEDIAN over j of exp(-|kp_j - kp_i|^2 / 0.25) (identity
+    frames: centre_ij - modelCentre_i = kp_j - kp_i). Word 0 has three members (odd list), word 2 two (even list: mean of both).
+    Statistical weights term1 * term2 * term3 with m_term3 keyed by CLASS only, the last codeword (ascending id) that holds the
+    class wins (codebook.cpp:325-339):
+        votes per class and word: c0 {w0: 2, w2: 1}, c1 {w0: 1, w2: 1, w5: 1}; features per class 3 and 3
+        sum[w] = 2/3 + 1/3 = 1, 1/3 + 1/3 = 2/3, 1/3;  term1 = 1/2 (c0: two words), 1/3 (c1: three);  term2 = 1/3, 1/2, 1
+        term3[c0]: w0 -> (2/3)/1, then w2 -> (1/3)/(2/3) = 1/2 (kept);  term3[c1]: 1/3, 1/2, then w5 -> (1/3)/(1/3) = 1 (kept)
+        class weights: w0: c0 1/2*1/3*1/2 = 1/12, c1 1/3*1/3*1 = 1/9;  w2: c0 1/2*1/2*1/2 = 1/8, c1 1/3*1/2*1 = 1/6;  w5: c1 1/3
+      (a per-codeword term3 would give w0/c0 = 1/2*1/3*2/3 = 1/9: the vector tells the two apart)."""
+    feats = [[0, 0], [0, 0], [10, 0], [0, 0], [10, 0], [20, 0]]
+    kp = [[0, 0, 0], [0.5, 0, 0], [0, 0, 0], [0, 1, 0], [0.3, 0.4, 0], [0, 0, 0]]
+    cls = [0, 0, 0, 1, 1, 1]
+    model = [0, 0, 1, 2, 3, 4]
+    centre = [[1, 2, 3]] * 6
+    e1, e4 = float(np.exp(-1.0)), float(np.exp(-4.0))
+    return dict(feats=feats, kp=kp, cls=cls, model=model, centre=centre, k=1, n_classes=2,
+                word_src=[0, 2, 5], vote_offsets=[0, 3, 5, 6], vote_feature=[0, 1, 3, 2, 4, 5],
+                vote_weight=[e1, e1, e4, (1.0 + e1) / 2, (1.0 + e1) / 2, 1.0],
+                vote_class_weight=[1 / 12, 1 / 12, 1 / 9, 1 / 8, 1 / 6, 1 / 3],
+                vote_xyz=[[1 - k_[0], 2 - k_[1], 3 - k_[2]] for k_ in (kp[0], kp[1], kp[3], kp[2], kp[4], kp[5])], tol=2e-6)
+
+
+def meanshift_step_and_double_reweight():
+    """Round 3, KAT B: VotingMeanShift with Bandwidth 1, MaxIter 0 (the do-while loop runs exactly ONE mean-shift step per seed,
+    voting_mean_shift.cpp:221-242), Gaussian kernel, MaximaSuppression "Suppress". Everything below is evaluated here in float64
+    straight from the formulas:
+      seeds: cells of edge 2h/sqrt(2), key floor(x/edge + 0.5), seed = key * edge
+      step : c' = sum g_i x_i / sum g_i over the votes with d_i^2 < h^2, g_i = 0.5 exp(-d_i^2 / (2 h^2)) w_i
+      density at a centre = sum exp(-d^2 / (2 h^2)) w over the votes within h; greedy suppression by descending density
+      final pass IN suppression order: w_i <- exp(-d_i^2 / (2 h^2)) w_i IN PLACE for the votes within h, maximum weight = their sum
+    class 0: three votes in one cell -> one seed at the origin -> one step -> one maximum (new centre, reweighted sum)
+    class 1: one vote exactly on its seed -> weight 1 (pins the normalisation)
+    class 2: votes A (w 4), B (w 4) 1.6 apart and M (w 1) between them: two maxima 1.34 apart; M lies within h of BOTH, so it is
+             reweighted twice -- the second maximum (A's, lower density) sees M's already reduced weight (4.609 instead of 4.765)."""
+    h = 1.0
+    edge = 2 * h / np.sqrt(2.0)
+    votes = {0: [([0.2, 0, 0], 1.0), ([-0.1, 0, 0], 2.0), ([0.5, 0, 0], 1.0)],
+             1: [([3 * float(f32(edge)), 0, 0], 1.0)],
+             2: [([10, 0, 0], 4.0), ([10, 1.6, 0], 4.0), ([10, 0.8, 0], 1.0)]}
+    maxima = []
+    for c, vs in votes.items():
+        P = np.asarray([v[0] for v in vs], float); W = np.asarray([v[1] for v in vs], float)
+        keys = sorted({tuple(np.floor(p / edge + 0.5).astype(int)[::-1]) for p in P})          # (z, y, x) order
+        centres = []
+        for kz, ky, kx in keys:
+            s0 = np.asarray([kx, ky, kz], float) * edge
+            d2 = ((P - s0) ** 2).sum(1); m = d2 < h * h
+            if not m.any():
+                continue
+            g = 0.5 * np.exp(-d2[m] / (2 * h * h)) * W[m]
+            centres.append((g[:, None] * P[m]).sum(0) / g.sum())
+        dens = []
+        for cc in centres:
+            d2 = ((P - cc) ** 2).sum(1); m = d2 < h * h
+            dens.append((np.exp(-d2[m] / (2 * h * h)) * W[m]).sum())
+        order, work = [], list(dens)
+        while True:                                                   # suppressNeighborMaxima: first largest, drop everything closer than h
+            mi = int(np.argmax(work)) if max(work) > -1 else -1
+            if mi < 0 or work[mi] == -1:
+                break
+            order.append(mi); c0 = centres[mi]; work[mi] = -1
+            for i, cc in enumerate(centres):
+                if np.linalg.norm(cc - c0) < h:
+                    work[i] = -1
+        Wc = W.copy()
+        for mi in order:
+            d2 = ((P - centres[mi]) ** 2).sum(1); m = d2 < h * h
+            Wc[m] = np.exp(-d2[m] / (2 * h * h)) * Wc[m]
+            maxima.append(dict(cls=c, pos=centres[mi].tolist(), raw=float(Wc[m].sum()), n_votes=int(m.sum())))
+    assert len(maxima) == 4 and abs(maxima[2]["raw"] - 4.7653) < 1e-3 and abs(maxima[3]["raw"] - 4.6091) < 1e-3, maxima
+    maxima.sort(key=lambda m_: -m_["raw"])
+    tot = sum(m_["raw"] for m_ in maxima)
+    pos, w, cls = [], [], []
+    for c, vs in votes.items():
+        for p_, w_ in vs:
+            pos.append(p_); w.append(w_); cls.append(c)
+    return dict(pos=pos, w=w, cls=cls, inst=[0] * len(w), n_classes=3, bandwidth=h, max_iter=0, suppression=1,
+                expected_cls=[m_["cls"] for m_ in maxima], expected_pos=[m_["pos"] for m_ in maxima],
+                expected_weight=[m_["raw"] / tot for m_ in maxima], expected_n_votes=[m_["n_votes"] for m_ in maxima],
+                single_reweight_would_be=4.76505 / (tot - 4.60908 + 4.76505), tol=2e-6)
+
+
+def _pair_features(p1, n1, p2, n2):
+    """pcl::computePairFeatures restated (SURVEY Appendix A.4) in float64"""
+    p1, n1, p2, n2 = (np.asarray(a, float) for a in (p1, n1, p2, n2))
+    dp = p2 - p1; f4 = np.linalg.norm(dp)
+    a1 = n1 @ dp / f4; a2 = n2 @ dp / f4
+    if np.arccos(abs(a1)) > np.arccos(abs(a2)):
+        n1, n2 = n2, n1; dp = -dp; f3 = -a2
+    else:
+        f3 = a1
+    v = np.cross(dp, n1); v /= np.linalg.norm(v)
+    w = np.cross(n1, v)
+    return float(np.arctan2(w @ n2, n1 @ n2)), float(v @ n2), float(f3), float(f4)
+
+
+def fpfh_three_points():
+    """Round 3, KAT C: three surface points that all see each other, a keypoint at DIFFERENT distances from them. SPFH(p): every
+    pair (p, q != p) adds 100 / (n - 1) = 50 to one bin of each 11-bin block (bins floor(11 (f1 + pi) / 2pi), floor(11 (f2 + 1) / 2),
+    floor(11 (f3 + 1) / 2), clamped to 0..10). FPFH(keypoint) = sum_q SPFH(q) / d_q^2, every block rescaled to 100, i.e. the
+    SPFHs are mixed with weights (1/d_q^2) / sum(1/d^2): with d = 0.1, 0.2, 0.4 that is 16/21, 4/21, 1/21."""
+    pts = [[0.1, 0, 0], [-0.2, 0, 0], [0, 0.4, 0]]
+    s = 1 / np.sqrt(2.0)
+    nrm = [[0, 0, 1], [0, s, s], [s, 0, s]]
+    kp = [0, 0, 0]
+    spfh = np.zeros((3, 33))
+    for i in range(3):
+        for j in range(3):
+            if i == j:
+                continue
+            f1, f2, f3, _ = _pair_features(pts[i], nrm[i], pts[j], nrm[j])
+            b = [int(np.floor(11 * (f1 + np.pi) / (2 * np.pi))), int(np.floor(11 * (f2 + 1) / 2)), int(np.floor(11 * (f3 + 1) / 2))]
+            for blk, bb in enumerate(b):
+                spfh[i, 11 * blk + min(10, max(0, bb))] += 50.0
+    d2 = np.asarray([((np.asarray(p) - kp) ** 2).sum() for p in pts])
+    wq = (1 / d2) / (1 / d2).sum()
+    exp = (wq[:, None] * spfh).sum(0)
+    assert abs(wq[0] - 16 / 21) < 1e-12 and np.allclose(exp.reshape(3, 11).sum(1), 100)
+    assert len(set(np.round(exp[exp > 0], 6))) >= 3                      # the three weights really show up as different bin values
+    return dict(points=pts, normals=nrm, keypoint=kp, radius=1.0, expected=exp.tolist(), spfh=spfh.tolist(), mix=wq.tolist(), tol=1e-3)
+
+
+def lrf_majority_sign():
+    """Round 3, KAT D: SHOT reference frame of five neighbours (the minimum) with an ASYMMETRIC sign vote (shot_na_lrf.hpp:48-178 /
+    SURVEY Appendix A.1): covariance sum (r - d) v v^T / sum (r - d) in float64, x = eigenvector of the largest eigenvalue, z = of the
+    smallest; x is flipped so that at least as many neighbours have v.x >= 0 as not: here 3 neighbours on one side, 2 on the other
+    (no tie rule involved); z likewise with 4 against 1; y = z cross x."""
+    pts = np.asarray([[0.30, 0.05, 0.012], [0.25, -0.05, 0.008], [0.20, 0.02, 0.011], [-0.28, 0.04, -0.009], [-0.22, -0.06, 0.010]])
+    r = 0.5
+    d = np.linalg.norm(pts, axis=1); wgt = r - d
+    cov = (wgt[:, None, None] * pts[:, :, None] * pts[:, None, :]).sum(0) / wgt.sum()
+    ev, evec = np.linalg.eigh(cov)
+    x, z = evec[:, 2].copy(), evec[:, 0].copy()
+    px = int((pts @ x >= 0).sum()); pz = int((pts @ z >= 0).sum())
+    assert {px, 5 - px} == {3, 2} and {pz, 5 - pz} == {4, 1}
+    if 2 * px - 5 < 0:
+        x = -x
+    if 2 * pz - 5 < 0:
+        z = -z
+    y = np.cross(z, x)
+    assert x[0] > 0.9 and z[2] > 0.9                                       # towards the three neighbours at +x, the four at +z
+    return dict(points=pts.tolist(), keypoint=[0, 0, 0], radius=r, expected=np.concatenate([x, y, z]).tolist(), counts=[3, 2, 4, 1], tol=2e-6)
+
+
 def main():
     kat = dict(shot_sector_centres=shot_sector_centres(), lrf_paraboloid=lrf_paraboloid(), rgb2lab=rgb2lab_cases(),
                fpfh_two_points=fpfh_two_points(), distances=distances(), rotations=rotations(), seeds_order=seeds_order(),
                voxel_grid=voxel_grid(), knn_ties=knn_ties(), shot_off_centre=shot_off_centre(), cshot_colour_pairs=cshot_colour_pairs(),
                cast_votes_vector=cast_votes_vector(), knn_rule_table=knn_rule_table(), maxima_thresholds=maxima_thresholds(),
-               hough3d_three_bins=hough3d_three_bins())
+               hough3d_three_bins=hough3d_three_bins(), activate_weights=activate_weights(),
+               meanshift_step_and_double_reweight=meanshift_step_and_double_reweight(), fpfh_three_points=fpfh_three_points(),
+               lrf_majority_sign=lrf_majority_sign())
     with open(OUT, "w") as f:
         json.dump(kat, f, indent=1)
     print("wrote", OUT)

@@ -106,3 +106,48 @@ def hough3d_three_bins(hough):
         np.testing.assert_allclose(np.asarray(out["weight"])[0, :n], k["expected_weight"], atol=k["tol"])
         assert np.asarray(out["inst"])[0, :n].tolist() == k["expected_inst"] and np.asarray(out["n_votes"])[0, :n].tolist() == k["expected_n_votes"]
         np.testing.assert_allclose(np.asarray(out["class_score"])[0], [0.5, 0.0], atol=k["tol"])
+
+
+# ---- round-3 vectors ---------------------------------------------------------------------------------------------------------
+def activate_weights(activate):
+    """activate(metric, feats, lrf, kp, cls, model, centre, k, clean_up, n_classes) -> dict as oracle_py.activate"""
+    k = KAT["activate_weights"]
+    n = len(k["cls"])
+    out = activate(0, np.asarray(k["feats"], np.float32), np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (n, 1)), np.asarray(k["kp"], np.float32),
+                   np.asarray(k["cls"], np.uint32), np.asarray(k["model"], np.uint32), np.asarray(k["centre"], np.float32), k["k"], False, k["n_classes"])
+    assert np.asarray(out["word_src"]).tolist() == k["word_src"]
+    assert np.asarray(out["vote_offsets"]).tolist() == k["vote_offsets"]
+    assert np.asarray(out["vote_feature"]).tolist() == k["vote_feature"]
+    np.testing.assert_allclose(np.asarray(out["vote_xyz"]).reshape(-1, 3), k["vote_xyz"], atol=k["tol"])
+    np.testing.assert_allclose(out["vote_weight"], k["vote_weight"], atol=k["tol"])             # medians: odd list, even list, single
+    np.testing.assert_allclose(out["vote_class_weight"], k["vote_class_weight"], rtol=1e-6)    # term1 * term2 * term3, class-keyed term3
+
+
+def meanshift_step_and_double_reweight(find_maxima):
+    k = KAT["meanshift_step_and_double_reweight"]
+    v = dict(pos=np.asarray(k["pos"], np.float32), weight=np.asarray(k["w"], np.float32), cls=np.asarray(k["cls"], np.int32),
+             inst=np.asarray(k["inst"], np.int32))
+    out = find_maxima([0, len(v["weight"])], v, n_classes=k["n_classes"], bandwidth=k["bandwidth"], max_iter=k["max_iter"], suppression=k["suppression"],
+                      max_maxima=8)
+    n = int(np.asarray(out["n"])[0])
+    assert n == 4
+    assert np.asarray(out["cls"])[0, :n].tolist() == k["expected_cls"]
+    assert np.asarray(out["n_votes"])[0, :n].tolist() == k["expected_n_votes"]
+    np.testing.assert_allclose(np.asarray(out["pos"])[0, :n], k["expected_pos"], atol=5e-6)       # ONE mean-shift step from each seed
+    np.testing.assert_allclose(np.asarray(out["weight"])[0, :n], k["expected_weight"], atol=k["tol"])
+    assert abs(float(np.asarray(out["weight"])[0, 1]) - k["single_reweight_would_be"]) > 1e-3    # the doubly reweighted vote really is in the second maximum
+
+
+def fpfh_three_points(fpfh33):
+    """fpfh33(points, normals, keypoint, radius) -> 33 values"""
+    k = KAT["fpfh_three_points"]
+    d = fpfh33(np.asarray(k["points"], np.float32), np.asarray(k["normals"], np.float32), np.asarray(k["keypoint"], np.float32), k["radius"])
+    np.testing.assert_allclose(d, k["expected"], atol=k["tol"])
+    np.testing.assert_allclose(np.asarray(d).reshape(3, 11).sum(1), 100.0, atol=1e-3)
+
+
+def lrf_majority_sign(shot_lrf):
+    """shot_lrf(points, keypoint, radius) -> 9 values"""
+    k = KAT["lrf_majority_sign"]
+    f = np.asarray(shot_lrf(np.asarray(k["points"], np.float32), np.asarray(k["keypoint"], np.float32), k["radius"]))
+    np.testing.assert_allclose(f, k["expected"], atol=k["tol"])

@@ -1378,6 +1378,44 @@ def test_kat_hough3d_three_bins(pkg, gpu):
     kat_checks.hough3d_three_bins(f)
 
 
+def test_kat_activate_weights(pkg, gpu):
+    ctx, dev = gpu
+
+    def f(metric, feats, lrf, kp, cls, model, centre, k, clean_up, n_classes):
+        return pkg.capi.train_activate(ctx, metric, T(feats, dev), T(lrf, dev), T(kp[:, 0], dev), T(kp[:, 1], dev), T(kp[:, 2], dev), cls, model, centre,
+                                       k=k, clean_up=clean_up, n_classes=n_classes)
+    kat_checks.activate_weights(f)
+
+
+def test_kat_meanshift_step_and_double_reweight(pkg, gpu):
+    ctx, dev = gpu
+
+    def f(off, v, **kw):
+        out = pkg.capi.find_maxima(ctx, off, {k: T(a, dev) for k, a in v.items()}, **kw)
+        return {k: a.cpu().numpy() for k, a in out.items()}
+    kat_checks.meanshift_step_and_double_reweight(f)
+
+
+def test_kat_fpfh_three_points(pkg, gpu):
+    ctx, dev = gpu
+
+    def f(pts, nrm, kp, radius):
+        s = Scene(pkg, gpu, [(pts, nrm)], [kp.reshape(1, 3)], 0.4 * radius)
+        d, cnt = pkg.capi.fpfh33(ctx, s.cloud, s.kp_off, *s.tk, radius, want_counts=True)
+        assert int(cnt.cpu().numpy()[0]) == len(pts)
+        return d.cpu().numpy()[0]
+    kat_checks.fpfh_three_points(f)
+
+
+def test_kat_lrf_majority_sign(pkg, gpu):
+    ctx, dev = gpu
+
+    def f(pts, kp, radius):
+        s = Scene(pkg, gpu, [(pts, np.zeros_like(pts))], [kp.reshape(1, 3)], 0.4 * radius)
+        return pkg.capi.shot_lrf(ctx, s.cloud, s.kp_off, *s.tk, radius).cpu().numpy()[0]
+    kat_checks.lrf_majority_sign(f)
+
+
 @pytest.mark.parametrize("interp,bin_size,rel", [(True, 0.4, 0.6), (False, 0.4, 0.6), (True, 0.1, 0.3), (True, 0.25, 0.9)])
 def test_hough3d_matches_oracle(pkg, gpu, ora, interp, bin_size, rel):
     """VotingHough3D on the device against the oracle on ragged vote sets (empty object, slots without a vote, clutter, votes

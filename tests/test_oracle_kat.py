@@ -361,3 +361,29 @@ def test_max_filter_simple_keeps_the_heavier_of_two_colliding_classes(ora):
     b = ora.find_maxima([0, 9], v, n_classes=3, bandwidth=0.5, max_maxima=8, max_filter=1)
     assert a["n"][0] == 3 and b["n"][0] == 2 and b["cls"][0, :2].tolist() == [0, 2]
     np.testing.assert_allclose(b["weight"][0, :2], [4 / 6, 2 / 6], atol=1e-6)
+
+
+# ---- round-3 vectors -----------------------------------------------------------------------------------------------------------
+def test_activate_weights_vector(ora):
+    kat_checks.activate_weights(lambda metric, feats, lrf, kp, cls, model, centre, k, clean_up, n_classes:
+                                ora.activate(metric, feats, lrf, kp, cls, model, centre, k=k, clean_up=clean_up, n_classes=n_classes))
+
+
+def test_meanshift_step_and_double_reweight_vector(ora):
+    kat_checks.meanshift_step_and_double_reweight(ora.find_maxima)
+
+
+def test_fpfh_three_points_vector(ora):
+    def f(pts, nrm, kp, radius):
+        x, y, z = _soa(pts); nx, ny, nz = _soa(nrm)
+        d, cnt = ora.fpfh33([0, len(pts)], x, y, z, nx, ny, nz, [0, 1], [kp[0]], [kp[1]], [kp[2]], radius)
+        assert cnt[0] == len(pts)
+        return d[0]
+    kat_checks.fpfh_three_points(f)
+
+
+def test_lrf_majority_sign_vector(ora):
+    def f(pts, kp, radius):
+        x, y, z = _soa(pts)
+        return ora.shot_lrf([0, len(pts)], x, y, z, [0, 1], [kp[0]], [kp[1]], [kp[2]], radius)[0]
+    kat_checks.lrf_majority_sign(f)
