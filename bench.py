@@ -62,6 +62,10 @@ def parse_args(argv=None):
     ap.add_argument("--keypoints", type=int, default=0)
     ap.add_argument("--classes", type=int, default=0)
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive (value_end_to_end) leg")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo only for --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="FUNCTIONAL run of the N > 1 path on one GPU: every rank uses cuda:0 (needs --backend gloo: "
+                    "RCCL refuses two ranks on one device); exercises spawn -> shard -> per-rank training -> gather, measures nothing")
+    ap.add_argument("--emit-labels", action="store_true", help="add the predicted class of every object of the last step to the JSON line")
     return ap.parse_args(argv)
 
 
@@ -110,6 +114,8 @@ def visible_gpus():
 def spawn_ranks(args):
     """--gpus N without a launcher: start the N ranks as a child torch.distributed.run BEFORE this process touches a GPU."""
     have = visible_gpus()
+    if args.share_gpu:
+        have = None                                # every rank maps to cuda:0
     if have is not None and have < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible; refusing to run fewer ranks than asked\n")
         return 2
@@ -165,16 +171,26 @@ def main():
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the hot path has no CPU fallback"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dev = torch.device("cuda", local_rank)
+    if args.share_gpu and args.backend != "gloo":
+        sys.stderr.write("bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)\n")
+        sys.exit(2)
+    dev_index = 0 if args.share_gpu else local_rank
+    if dev_index >= torch.cuda.device_count():
+        sys.stderr.write(f"bench.py: rank {rank} has no GPU {dev_index} (visible: {torch.cuda.device_count()})\n")
+        sys.exit(2)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     distributed = launched
     if distributed:
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
         assert dist.get_world_size() == world
 
     pkg = ge.load_package()
     capi, pipeline, synthetic, shard = pkg.capi, pkg.pipeline, pkg.synthetic, pkg.shard
-    ctx = capi.Ctx(local_rank)            # on torch's current stream
+    ctx = capi.Ctx(dev_index)             # on torch's current stream
     cdef = CONFIGS[args.config]
     C = args.classes or cdef["classes"]
     G = args.objects or cdef["objects"]
@@ -247,7 +263,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if distributed:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -406,6 +422,10 @@ def main():
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in tm.items() if v[1] > 0},
             "knn_exact_fallback_last_launch": knn_fb, "accuracy_last_step": round(correct / max(1, total), 4), "train_seconds": round(t_train, 1),
         }
+        if args.share_gpu:
+            line["functional_test_only"] = "all ranks share cuda:0 over gloo: the value is NOT a scaling measurement"
+        if args.emit_labels:
+            line["labels_last_step"] = [int(x) for x in best.tolist()]
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()

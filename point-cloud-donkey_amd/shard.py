@@ -52,6 +52,13 @@ def all_gather_records(rec, world_size):
     import torch.distributed as dist
     if not dist.is_initialized():
         return rec
+    if dist.get_backend() == "gloo" and rec.is_cuda:
+        # functional runs of the N > 1 path on ONE GPU (bench.py --share-gpu: RCCL refuses two ranks on one device): the records
+        # travel through host memory; the data path proper (RCCL, device tensors) is the branch below
+        host = rec.contiguous().cpu()
+        out_h = torch.empty((world_size * host.shape[0], host.shape[1]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out_h, host)
+        return out_h.to(rec.device)
     out = torch.empty((world_size * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec.contiguous())
     return out

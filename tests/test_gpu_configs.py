@@ -193,3 +193,36 @@ def test_knn_rule_matches_oracle(pkg, gpu, ora):
     cb.set_word_class(np.zeros(n, np.uint32))            # one class everywhere -> the rule always accepts k1
     gi, _ = pkg.capi.knn_rule(ctx, cb, 0, torch.as_tensor(q).to(dev), 0.8)
     assert np.array_equal(gi.cpu().numpy(), ora.knn(0, words, q, 1)[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_functional():
+    """The N > 1 path of bench.py executed once on the hardware this box has: `--gpus 2` with both ranks on cuda:0 over gloo (RCCL
+    refuses two ranks on one device). Exercises spawn_ranks -> torch.distributed.run -> init_process_group -> per-rank training ->
+    plan_shard -> per-rank detect -> record all-gather -> every object exactly once (asserted inside bench.py) -> rank-0 JSON line.
+    A FUNCTIONAL test: the line says so, and its value is not a scaling number. Labels must equal the N = 1 run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--objects", "64", "--steps", "1", "--warmup", "0", "--no-e2e", "--cpu-objects", "0", "--emit-labels", "--train-per-class", "2"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(extra):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common + extra, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]                           # rank 0 prints ONE line
+        return json.loads(lines[0])
+    one = run([])
+    two = run(["--gpus", "2", "--backend", "gloo", "--share-gpu"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["collective_world_size"] == 2 and two["config"]["objects_per_step_this_rank"] == 32
+    assert "functional_test_only" in two
+    assert len(two["labels_last_step"]) == 64 and two["labels_last_step"] == one["labels_last_step"]
+    assert two["accuracy_last_step"] == one["accuracy_last_step"]
+    # a WORLD_SIZE that does not match --gpus is refused (exit 2), as the contract says
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common, cwd=root,
+                       env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "WORLD_SIZE" in p.stderr
