@@ -70,23 +70,23 @@ def parse_args(argv=None):
 
 
 CONFIGS = {
-    # objects: the real split sizes are 908 / 2468 / 153 / 2468; configs 2-4 default to a bounded part of the split so that the
-    # default run finishes within minutes (name: what the line says it measured)
+    # objects: the real split sizes 908 / 2468 / 153 / 2468 (ModelNet10 test, ModelNet40 test, 51 classes x 3 views, ModelNet40 test);
+    # a rank's shard is processed in launches of at most --batch objects
     1: dict(name="configs[1]: ModelNet10-like test split, 16384 pts, 1024 uniform keypoints/object, SHOT-352 (Radius 0.4, LRF 0.3), "
                  "exact kNN K=1 squared-L2, mean-shift bandwidth 0.6",
             classes=10, objects=908, points=16384, keypoints=1024, train_per_class=10, models=[dict(feature="SHOT")]),
     2: dict(name="configs[2]: ModelNet40-like, 2048 keypoints/object, SHOT-352, 10k-word codebook (seeded random subset of the training "
                  "features, the reference's UseRandomCodebook mechanism), exact kNN K=1 squared-L2",
-            classes=40, objects=256, points=16384, keypoints=2048, train_per_class=1,
+            classes=40, objects=2468, points=16384, keypoints=2048, train_per_class=1,
             models=[dict(feature="SHOT", use_random_codebook=True, random_codebook_size=10000)]),
     3: dict(name="configs[3]: Washington-like coloured partial views, CSHOT-1344, Radius/LRF 0.05, LeafSize 0.02, bandwidth 0.045, "
                  "chi-squared exact kNN K=1, 10k-word codebook",
-            classes=51, objects=48, points=8192, keypoints=0, train_per_class=1, dataset=dict(leaf=0.02, scale=0.15, with_color=True, partial_view=True),
+            classes=51, objects=153, points=8192, keypoints=0, train_per_class=1, dataset=dict(leaf=0.02, scale=0.15, with_color=True, partial_view=True),
             models=[dict(feature="CSHOT", radius=0.05, lrf_radius=0.05, distance="ChiSquared", bandwidth=0.045,
                          use_random_codebook=True, random_codebook_size=10000)]),
     4: dict(name="configs[4]: ModelNet40-like, 2048 keypoints/object, FPFH-33 + SHOT-352 as two models (class scores summed), 50k-word "
                  "codebooks, exact kNN K=1 squared-L2",
-            classes=40, objects=256, points=16384, keypoints=2048, train_per_class=1,
+            classes=40, objects=2468, points=16384, keypoints=2048, train_per_class=1,
             models=[dict(feature="FPFH", radius=0.3, use_random_codebook=True, random_codebook_size=50000),
                     dict(feature="SHOT", use_random_codebook=True, random_codebook_size=50000)]),
 }
@@ -142,9 +142,11 @@ def plan_shard(n_objects, rank, world, batch):
     return lo, hi, per, bounds
 
 
-def latest_traffic_json():
-    """beyond-L2 bytes per launch from the newest committed PMC pass of this very command (profiles/round*_pmc_traffic.json)"""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json")))
+def latest_traffic_json(config=1):
+    """beyond-L2 bytes per launch from the newest committed PMC pass of this very command (profiles/round*_pmc_traffic.json for the
+    headline config, profiles/round*_cfgN_pmc_traffic.json for --config N)"""
+    pat = "round*_pmc_traffic.json" if config == 1 else f"round*_cfg{config}_pmc_traffic.json"
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pat)) if config != 1 or "_cfg" not in os.path.basename(f))
     for f in reversed(files):
         try:
             return os.path.relpath(f, ROOT), json.load(open(f))
@@ -208,9 +210,12 @@ def main():
     order = sorted(range(n_train), key=lambda i: (train.label(i), i))
     recs, cbs, cfgs = [], [], []
     tb = [pipeline.DeviceBatch(train.batch(order[s:s + 32]), dev) for s in range(0, n_train, 32)]
-    for m in cdef["models"]:
+    ctxs = []
+    for mi, m in enumerate(cdef["models"]):
         cfg = pipeline.IsmConfig(k=1, n_classes=C, max_maxima=16, **m)
-        rec = pipeline.Recognizer(ctx, cfg)
+        mctx = ctx if mi == 0 else capi.Ctx(dev_index)        # one library context per model: separate kernel timers, same (torch current) stream
+        ctxs.append(mctx)
+        rec = pipeline.Recognizer(mctx, cfg)
         cbs.append(rec.train(tb))
         recs.append(rec); cfgs.append(cfg)
     del tb
@@ -249,8 +254,9 @@ def main():
     for i in range(args.warmup):
         g, _ = step(chunks)
     torch.cuda.synchronize()
-    ctx.timers_enable(True)
-    ctx.timers_reset()
+    for c_ in ctxs:
+        c_.timers_enable(True)
+        c_.timers_reset()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -273,70 +279,106 @@ def main():
     labels = torch.as_tensor([test.label(int(k)) for k in oi.tolist()], device=best.device)
     correct, total = int((best == labels).sum().item()), int(len(oi))
 
-    # ---- per-kernel device time (HIP events on the ctx stream, timed region only; this rank)
+    # ---- per-kernel device time (HIP events on the ctx stream, timed region only; this rank), one timer set per model
     names = ["grid", "lrf", "shot352", "cshot1344", "fpfh33", "knn", "knn_rotate", "knn_l2_mfma", "knn_chi2", "knn_rerank", "knn_stage2", "knn_fallback", "cast_votes", "maxima"]
-    tm = {n: ctx.timer(n) for n in names}
+    tms = [{n: c_.timer(n) for n in names} for c_ in ctxs]
+    tm = {n: (sum(t[n][0] for t in tms), sum(t[n][1] for t in tms)) for n in names}
     knn_fb = {"queries": int(ctx.timer("knn_flagged_queries")[0]), "slot_items": int(ctx.timer("knn_flagged_items")[0]),
               "stage2_queries": int(ctx.timer("knn_stage2_queries")[0])}
-    ctx.timers_enable(False)
+    for c_ in ctxs:
+        c_.timers_enable(False)
     rooflines = {}
     if rank == 0:
         # features actually searched (NaN rows removed) and neighbour visits come from one extra, untimed pass over the shard
-        for rec, cfg, nw in zip(recs, cfgs, n_words):
-            nq_sum = m_sum = nkp = 0
+        knn_lines, desc_lines = [], []
+        for rec, cfg, nw, tmm in zip(recs, cfgs, n_words, tms):
+            nq_sum = m_sum = nkp = npts = 0
             for b in chunks:
                 f = rec.compute_features(b, want_counts=True)
-                nq_sum += int(f["off"][-1]); m_sum += int(f["counts"].to(torch.int64).sum().item()); nkp += int(b.kp_off[-1])
-            launches = len(chunks) * args.steps
-            if cfg.distance == "Euclidean" and tm["knn_l2_mfma"][1] > 0 and len(recs) == 1:
-                ms_knn = tm["knn_l2_mfma"][0] / tm["knn_l2_mfma"][1]
-                nq_l = nq_sum / len(chunks)
-                # stage 1 runs on the m leading rotated coordinates of the codebook (csrc/pca.hip; m = dim when the codebook has no
-                # rotated image) plus a sampling pre-pass over every 16th codeword tile: `achieved` counts the flops ISSUED by those
-                # launches; the 2*Nq*Nc*dim figure of SURVEY 8(d) is reported beside it as `effective` and is NOT the fraction
-                m1 = rec.codebook.stage1_dims or cfg.dim
-                pre = (1.0 + 1.0 / 16.0) if (rec.codebook.stage1_dims and nw >= 128 * 256 and os.environ.get("ISMHIP_KNN_PREPASS", "1") != "0") else 1.0
-                flop = 2.0 * nq_l * nw * m1 * pre
+                nq_sum += int(f["off"][-1]); m_sum += int(f["counts"].to(torch.int64).sum().item()); nkp += int(b.kp_off[-1]); npts += int(b.pt_off[-1])
+            nq_l = nq_sum / len(chunks)
+            if cfg.distance == "Euclidean" and tmm["knn_l2_mfma"][1] > 0:
+                ms_knn = tmm["knn_l2_mfma"][0] / tmm["knn_l2_mfma"][1]
                 flop_eff = 2.0 * nq_l * nw * cfg.dim
                 knn_mode = os.environ.get("ISMHIP_KNN_MODE", "f16")
-                kname, peak, mult = {"f16": ("k_knn_l2_ring" if os.environ.get("ISMHIP_KNN_RING32") == "1" else "k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0),
-                                     "bf16x3": ("k_knn_l2_mfma16<bf16x3>", PEAK_F16_MFMA_TFLOPS, 3.0),
-                                     "f32": ("k_knn_l2_mfma", PEAK_FP32_MFMA_TFLOPS, 1.0)}.get(knn_mode, ("k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0))
-                if knn_mode != "f16":
-                    flop = flop_eff
-                ach = flop * mult / (ms_knn * 1e-3) / 1e12
-                rooflines["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                                         "frac": round(ach / peak, 4), "traffic": None, "flop_per_launch": flop * mult,
-                                         "ms_per_launch": round(ms_knn, 4), "queries_per_launch": nq_l,
-                                         "stage1_dims": m1, "prepass_share": round(pre - 1.0, 4),
-                                         "effective": {"flop_per_launch": flop_eff, "achieved": round(flop_eff / (ms_knn * 1e-3) / 1e12, 3),
-                                                       "note": "2*Nq*Nc*dim / stage-1 time: what an all-dimension search would have to sustain; not a fraction of any peak"},
-                                         "note": "candidate stage of the exact kNN: f16 MFMA scores over the leading rotated coordinates are lower bounds of "
-                                                 "the functor values; every returned neighbour is re-ranked with the exact f32 FLANN functor and proven, "
-                                                 "unproven queries are searched again in all dimensions (knn_stage2) (DESIGN.md §4.1)"}
-            if cfg.distance == "ChiSquared" and tm["knn_chi2"][1] > 0:
-                ms = tm["knn_chi2"][0] / tm["knn_chi2"][1]
-                flop = 5.0 * nq_sum / len(chunks) * nw * cfg.dim
-                ach = flop / (ms * 1e-3) / 1e12
-                rooflines["roofline"] = {"kernel": "k_knn_chi2", "bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_VALU_TFLOPS,
-                                         "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
-                                         "flop_per_launch": flop, "ms_per_launch": round(ms, 4), "queries_per_launch": nq_sum / len(chunks),
-                                         "note": "5 flop per (query, word, dim) element: sub, add, mul, rcp, fma (SURVEY §8d)"}
+                if cfg.dim <= 64 and knn_mode == "f16" and not rec.codebook.stage1_dims:
+                    # short descriptors (FPFH-33): the exact-f32 MFMA contraction is the candidate kernel
+                    kname, peak, flop, extra = "k_knn_l2_mfma", PEAK_FP32_MFMA_TFLOPS, flop_eff, {}
+                else:
+                    # stage 1 runs on the m leading rotated coordinates of the codebook (csrc/pca.hip; m = dim when the codebook has no
+                    # rotated image) plus a sampling pre-pass over every 16th codeword tile: `achieved` counts the flops ISSUED by
+                    # those launches; the 2*Nq*Nc*dim figure of SURVEY 8(d) is reported beside it as `effective`, NOT as the fraction
+                    m1 = rec.codebook.stage1_dims or cfg.dim
+                    pre = (1.0 + 1.0 / 16.0) if (rec.codebook.stage1_dims and rec.codebook.stage1_energy < 1.0 and nw > 127 * 256 and os.environ.get("ISMHIP_KNN_PREPASS", "1") != "0") else 1.0
+                    kname, peak, mult = {"f16": ("k_knn_l2_ring" if os.environ.get("ISMHIP_KNN_RING32") == "1" else "k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0),
+                                         "bf16x3": ("k_knn_l2_mfma16<bf16x3>", PEAK_F16_MFMA_TFLOPS, 3.0),
+                                         "f32": ("k_knn_l2_mfma", PEAK_FP32_MFMA_TFLOPS, 1.0)}.get(knn_mode, ("k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0))
+                    flop = 2.0 * nq_l * nw * m1 * pre if knn_mode == "f16" else flop_eff * mult
+                    extra = {"stage1_dims": m1, "prepass_share": round(pre - 1.0, 4),
+                             "effective": {"flop_per_launch": flop_eff, "achieved": round(flop_eff / (ms_knn * 1e-3) / 1e12, 3),
+                                           "note": "2*Nq*Nc*dim / stage-1 time: what an all-dimension search would have to sustain; not a fraction of any peak"}}
+                ach = flop / (ms_knn * 1e-3) / 1e12
+                knn_lines.append(dict({"kernel": kname, "feature": cfg.feature, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                                       "frac": round(ach / peak, 4), "traffic": None, "flop_per_launch": flop, "ms_per_launch": round(ms_knn, 4),
+                                       "queries_per_launch": nq_l, "codebook_words": nw,
+                                       "note": "candidate stage of the exact kNN: f16 MFMA scores over the leading rotated coordinates are lower bounds of "
+                                               "the functor values; every returned neighbour is re-ranked with the exact f32 FLANN functor and proven, "
+                                               "unproven queries are searched again in all dimensions (knn_stage2) (DESIGN.md 4.1)"}, **extra))
+            if cfg.distance == "ChiSquared" and tmm["knn_chi2"][1] > 0:
+                ms = tmm["knn_chi2"][0] / tmm["knn_chi2"][1]
+                hell = rec.codebook is not None and os.environ.get("ISMHIP_KNN_HELLINGER", "1") != "0"
+                if hell:
+                    flop = 2.0 * nq_l * nw * cfg.dim
+                    ach = flop / (ms * 1e-3) / 1e12
+                    knn_lines.append({"kernel": "k_knn_l2_ring16 / k_knn_l2_mfma16 on sqrt images (Hellinger candidates)", "feature": cfg.feature, "bound": "mfma",
+                                      "achieved": round(ach, 3), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4),
+                                      "traffic": None, "flop_per_launch": flop, "ms_per_launch": round(ms, 4), "queries_per_launch": nq_l, "codebook_words": nw,
+                                      "note": "chi-square candidates: |sqrt q - sqrt c|^2 <= chi2 as a dense f16 contraction; the exact chi-square functor runs "
+                                              "in the re-rank (knn_rerank) and in the list-and-evaluate stage of the unproven queries (knn_stage2), which are "
+                                              "latency-bound and carry most of this config's kNN time (kernel_ms_per_step)"})
+                else:
+                    flop = 5.0 * nq_l * nw * cfg.dim
+                    ach = flop / (ms * 1e-3) / 1e12
+                    knn_lines.append({"kernel": "k_knn_chi2", "feature": cfg.feature, "bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+                                      "flop_per_launch": flop, "ms_per_launch": round(ms, 4), "queries_per_launch": nq_l, "codebook_words": nw,
+                                      "note": "5 flop per (query, word, dim) element: sub, add, mul, rcp, fma (SURVEY 8d)"})
             tname = {"SHOT": "shot352", "CSHOT": "cshot1344", "FPFH": "fpfh33"}[cfg.feature]
-            if tm[tname][1] > 0 and cfg.feature != "FPFH":
-                ms_d = tm[tname][0] / tm[tname][1]
-                per_nb, per_kp = (24.0, 12 + 36 + 352 * 4) if cfg.feature == "SHOT" else (28.0, 12 + 36 + 4 + 1344 * 4)
-                bytes_d = (m_sum * per_nb + nkp * per_kp) / len(chunks)
+            if tmm[tname][1] > 0:
+                ms_d = tmm[tname][0] / tmm[tname][1]
+                if cfg.feature == "FPFH":
+                    # sum_{p in U} M_p*24 + |U|*132 + sum_k M_k*136 + K*132. U (surface points inside some keypoint ball) and M_p
+                    # are not returned by the call: U is taken as ALL points and M_p as the keypoints' mean neighbour count (both upper
+                    # estimates at radius 0.3 on unit-size objects with 2048 keypoints, where nearly every point is in U)
+                    mbar = m_sum / max(1, nkp)
+                    bytes_d = (npts * mbar * 24.0 + npts * 132.0 + m_sum * 136.0 + nkp * 132.0) / len(chunks)
+                    kern = "k_spfh + k_fpfh_sum + k_fpfh_mark"
+                else:
+                    per_nb, per_kp = (24.0, 12 + 36 + 352 * 4) if cfg.feature == "SHOT" else (28.0, 12 + 36 + 4 + 1344 * 4)
+                    bytes_d = (m_sum * per_nb + nkp * per_kp) / len(chunks)
+                    kern = "k_shot<%s>" % ("true" if cfg.feature == "CSHOT" else "false")
                 gbs = bytes_d / (ms_d * 1e-3) / 1e9
-                rooflines["roofline_shot"] = {"kernel": "k_shot<%s>" % ("true" if cfg.feature == "CSHOT" else "false"), "bound": "hbm",
-                                              "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                              "traffic": None, "bytes_per_launch": bytes_d, "ms_per_launch": round(ms_d, 4),
-                                              "mean_neighbours": round(m_sum / max(1, nkp), 1),
-                                              "lrf_plus_descriptor_ms_per_512_objects": round((tm["lrf"][0] + tm[tname][0]) / args.steps / max(1, hi - lo) * 512, 3)}
+                desc_lines.append({"kernel": kern, "feature": cfg.feature, "bound": "hbm", "model": "gather: every neighbour visit counted as one record read (SURVEY 8d); the "
+                                   "clouds are cache-resident, so this is L2/LDS-side throughput -- `traffic` (config 1: committed PMC pass) is what crosses the XCD L2s",
+                                   "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                   "traffic": None, "bytes_per_launch": bytes_d, "ms_per_launch": round(ms_d, 4),
+                                   "mean_neighbours": round(m_sum / max(1, nkp), 1),
+                                   "lrf_plus_descriptor_ms_per_512_objects": round((tmm["lrf"][0] + tmm[tname][0]) / args.steps / max(1, hi - lo) * 512, 3)})
+        # the dominant kernel of the step is the `roofline`; every other model / stage follows in `roofline_more`
+        knn_lines.sort(key=lambda r: -r["ms_per_launch"]); desc_lines.sort(key=lambda r: -r["ms_per_launch"])
+        if knn_lines and (not desc_lines or knn_lines[0]["ms_per_launch"] >= desc_lines[0]["ms_per_launch"] or args.config == 1):
+            rooflines["roofline"] = knn_lines[0]
+        elif desc_lines:
+            rooflines["roofline"] = desc_lines[0]
+        if desc_lines:
+            rooflines["roofline_shot"] = desc_lines[0]
+        rest = [r for r in knn_lines + desc_lines if r is not rooflines.get("roofline") and r is not rooflines.get("roofline_shot")]
+        if rest:
+            rooflines["roofline_more"] = rest
         # beyond-L2 bytes per launch come from the committed PMC passes of this very command (separate FETCH_SIZE / WRITE_SIZE
         # runs, gfx950 correction applied); they are NOT measured in the run that prints this line, and are null for other shapes
-        tf, tj = latest_traffic_json()
-        if tj and args.config == 1 and world == 1 and tj.get("objects") == G and tj.get("launches_per_step") == len(chunks) and not args.points and not args.keypoints:
+        tf, tj = latest_traffic_json(args.config)
+        if tj and world == 1 and tj.get("objects") == G and tj.get("launches_per_step") == len(chunks) and not args.points and not args.keypoints:
             for key in ("roofline", "roofline_shot"):
                 r = rooflines.get(key)
                 if r and r["kernel"] in tj:
@@ -381,26 +423,36 @@ def main():
 
     # ---- CPU baseline: the oracle on a bounded sample (rank 0, N = 1, headline config only)
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_objects > 0 and args.config == 1:
-        cfg, cb = cfgs[0], cbs[0]
+    if rank == 0 and world == 1 and args.cpu_objects > 0:
         ora = ge.load_oracle()
         n_thr = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16)     # the GPU box's CPU share for one GPU
         ora.set_num_threads(n_thr)
-        nb = test.batch(list(range(args.cpu_objects)))
+        n_cpu = min(G, args.cpu_objects if args.config == 1 else max(4, args.cpu_objects // (1 if args.config == 2 else 3)))   # FPFH / CSHOT are slower per object
+        nb = test.batch(list(range(n_cpu)))
         xyz, nrm, kp = nb["xyz"], nb["normals"], nb["kp"]
         t0 = time.perf_counter()
-        lrf = ora.shot_lrf(nb["pt_off"], xyz[:, 0], xyz[:, 1], xyz[:, 2], nb["kp_off"], kp[:, 0], kp[:, 1], kp[:, 2], cfg.lrf_radius)
-        desc, _ = ora.shot352(nb["pt_off"], xyz[:, 0], xyz[:, 1], xyz[:, 2], nrm[:, 0], nrm[:, 1], nrm[:, 2], nb["kp_off"],
-                              kp[:, 0], kp[:, 1], kp[:, 2], lrf, cfg.radius)
-        ok = ~np.isnan(desc).any(1)
-        idx, dd = ora.knn(cfg.metric, cb["words"], desc[ok], 1)
-        votes = ora.cast_votes(cb, cfg.weight_flags, lrf[ok], kp[ok, 0], kp[ok, 1], kp[ok, 2], idx, dd)
-        keep_off = np.concatenate([[0], np.cumsum([ok[nb["kp_off"][o]:nb["kp_off"][o + 1]].sum() for o in range(args.cpu_objects)])])
-        ora.find_maxima(keep_off.astype(np.uint32), votes, C, cfg.bandwidth, max_maxima=cfg.max_maxima)
+        stages = []
+        for cfg, cb in zip(cfgs, cbs):                         # the oracle's version of Recognizer.detect, model by model
+            lrf = ora.shot_lrf(nb["pt_off"], xyz[:, 0], xyz[:, 1], xyz[:, 2], nb["kp_off"], kp[:, 0], kp[:, 1], kp[:, 2], cfg.lrf_radius)
+            if cfg.feature == "SHOT":
+                desc, _ = ora.shot352(nb["pt_off"], xyz[:, 0], xyz[:, 1], xyz[:, 2], nrm[:, 0], nrm[:, 1], nrm[:, 2], nb["kp_off"],
+                                      kp[:, 0], kp[:, 1], kp[:, 2], lrf, cfg.radius)
+            elif cfg.feature == "CSHOT":
+                desc, _ = ora.cshot1344(nb["pt_off"], xyz[:, 0], xyz[:, 1], xyz[:, 2], nrm[:, 0], nrm[:, 1], nrm[:, 2], nb["rgba"], nb["kp_off"],
+                                        kp[:, 0], kp[:, 1], kp[:, 2], nb["kp_rgba"], lrf, cfg.radius)
+            else:
+                desc, _ = ora.fpfh33(nb["pt_off"], xyz[:, 0], xyz[:, 1], xyz[:, 2], nrm[:, 0], nrm[:, 1], nrm[:, 2], nb["kp_off"],
+                                     kp[:, 0], kp[:, 1], kp[:, 2], cfg.radius)
+            ok = ~np.isnan(desc).any(1) & ~np.isnan(lrf).any(1)
+            idx, dd = ora.knn(cfg.metric, cb["words"], desc[ok], 1)
+            votes = ora.cast_votes(cb, cfg.weight_flags, lrf[ok], kp[ok, 0], kp[ok, 1], kp[ok, 2], idx, dd)
+            keep_off = np.concatenate([[0], np.cumsum([ok[nb["kp_off"][o]:nb["kp_off"][o + 1]].sum() for o in range(n_cpu)])])
+            ora.find_maxima(keep_off.astype(np.uint32), votes, C, cfg.bandwidth, max_maxima=cfg.max_maxima)
+            stages.append(f"{cfg.feature}-{cfg.dim} + exact linear-search {cfg.distance} kNN over {int(cb['words'].shape[0])} words")
         t_cpu = time.perf_counter() - t0
-        cpu = {"value": round(args.cpu_objects / t_cpu, 4), "unit": "objects/s", "cores": ora.get_num_threads(), "kind": "port",
-               "sample": f"{args.cpu_objects} objects of the same workload (oracle: SHOT LRF+SHOT-352+exact linear-search kNN over {n_words[0]} words"
-                         f"+votes+mean-shift), {t_cpu:.1f} s, OpenMP over keypoints/queries as the reference; the reference's default "
+        cpu = {"value": round(n_cpu / t_cpu, 4), "unit": "objects/s", "cores": ora.get_num_threads(), "kind": "port",
+               "sample": f"{n_cpu} objects of the same workload (oracle: SHOT LRF + " + " and ".join(stages) +
+                         f" + votes + mean-shift), {t_cpu:.1f} s, OpenMP over keypoints/queries as the reference; the reference's default "
                          "kNN is an approximate 4-tree FLANN forest, so this is the exact-match (FLANNExactMatch) CPU cost"}
 
     n_objects = G * args.steps

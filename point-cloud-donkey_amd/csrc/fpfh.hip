@@ -8,6 +8,7 @@
 //   k_fpfh_sum  : per keypoint, FPFH = sum_nb SPFH(nb)/d^2, every 11-bin block rescaled to 100
 // Roofline (HBM gather model): sum_{p in U} M_p*24 + |U|*132 + sum_k M_k*136 + K*132 bytes.
 #include "common.h"
+#include <cstdlib>
 
 uint32_t* ism_upload_offsets(ismhip_ctx* ctx, int slot, const uint32_t* off_h, int n);
 
@@ -22,6 +23,7 @@ struct FpfhArgs {
     float* spfh;        // [n_pts*33]
     float* desc; uint32_t* count;
     uint32_t max_pts;
+    int dbg;            // env ISMHIP_FPFH_DBG (timing experiments, results invalid): 1 = k_spfh without the pair features
 };
 
 __global__ __launch_bounds__(256) void k_fpfh_mark(FpfhArgs a) {
@@ -63,7 +65,13 @@ __device__ __forceinline__ bool pair_features(float px, float py, float pz, floa
     float ax = pnx, ay = pny, az = pnz, bx = qnx, by = qny, bz = qnz;
     const float angle1 = ((ax * dx + ay * dy) + az * dz) / f4;
     const float angle2 = ((bx * dx + by * dy) + bz * dz) / f4;
-    if (acosf(fabsf(angle1)) > acosf(fabsf(angle2))) {
+    // PCL swaps the roles when acos|a1| > acos|a2|. acos is decreasing with |slope| >= 1, so when the two absolute cosines differ
+    // by more than 1e-5 (hundreds of float acosf errors) the order of the acos values is the reverse order of the cosines and no
+    // acosf is needed; inside that band (and only there) the reference's own comparison of the two acosf values decides.
+    const float c1 = fabsf(angle1), c2 = fabsf(angle2);
+    const float gap = c2 - c1;
+    const bool swap_roles = fabsf(gap) > 1e-5f ? gap > 0.f : acosf(c1) > acosf(c2);
+    if (swap_roles) {
         float t;
         t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; t = az; az = bz; bz = t;
         dx = -dx; dy = -dy; dz = -dz;
@@ -84,6 +92,7 @@ __device__ __forceinline__ int clamp_bin(int h) { return h < 0 ? 0 : (h > 10 ? 1
 __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
     __shared__ unsigned int s_hist[4][36];
     __shared__ WaveRows s_rows[4];
+    __shared__ float4 s_queue[4][128];      // queued neighbours: x, y, z, sorted index (bits)
     const int o = blockIdx.y;
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const uint32_t base = a.pt_off[o];
@@ -101,18 +110,14 @@ __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
     ball_cells(m, px, py, pz, a.radius, cr);
     const uint32_t* cs = a.cell_start + (size_t)o * ISM_GRID_STRIDE;
     const float d_pi = 1.0f / (2.0f * 3.14159265358979323846f);
-    uint32_t total = 0;
-    // flattened ball traversal (common.h): the candidate rows laid end to end, every lane busy; the pair features are ~170
-    // instructions per neighbour, so a half-empty wave per cell row was most of this kernel's time
-    ball_for_each(m, cs, cr, px, py, pz, a.radius, lane, s_rows[wv],
-                  [&](uint32_t t, bool v) { return v ? a.sp4[base + t] : make_float4(0.f, 0.f, 0.f, 0.f); },
-                  [&](const float4& qq, uint32_t t, bool v) {
-        if (!v) return;
-        const float qx = qq.x, qy = qq.y, qz = qq.z;
-        const float d2 = sqdist3(qx, qy, qz, px, py, pz);
-        if (!(d2 < a.r2)) return;
-        total++;
-        if (t == p) return;
+    uint32_t total = 0, qn_ = 0, qh = 0;
+    // The pair features cost several hundred instructions per neighbour (two sqrt, five divisions, atan2f, three double-precision
+    // bin formulas), and only about half of the candidates the sweep visits lie inside the ball: as in k_shot, the neighbours that
+    // pass are queued (128-entry circular LDS queue, ballot + prefix popcount) and a FULL wave of them does the arithmetic
+    // (measured per 128 objects x 16384 points, M ~ 900: k_spfh 20.0 -> see DESIGN.md §5).
+    auto pair_of = [&](bool act, uint32_t t, float qx, float qy, float qz) {
+        if (!act) return;
+        if (a.dbg == 1) { atomicAdd(&hist[t & 31], 1u); return; }
         float f1, f2, f3;
         const float4 qn = a.sn4[base + t];
         if (!pair_features(px, py, pz, pnx, pny, pnz, qx, qy, qz, qn.x, qn.y, qn.z, f1, f2, f3)) return;
@@ -121,8 +126,31 @@ __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
         const int h2 = clamp_bin((int)floor(11 * (((double)f2 + 1.0) * 0.5)));
         const int h3 = clamp_bin((int)floor(11 * (((double)f3 + 1.0) * 0.5)));
         atomicAdd(&hist[h1], 1u); atomicAdd(&hist[11 + h2], 1u); atomicAdd(&hist[22 + h3], 1u);
+    };
+    float4* sq = s_queue[wv];
+    // flattened ball traversal (common.h): the candidate rows laid end to end, every lane busy
+    ball_for_each(m, cs, cr, px, py, pz, a.radius, lane, s_rows[wv],
+                  [&](uint32_t t, bool v) { return v ? a.sp4[base + t] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                  [&](const float4& qq, uint32_t t, bool v) {
+        bool pass = false;
+        if (v) pass = sqdist3(qq.x, qq.y, qq.z, px, py, pz) < a.r2;
+        const unsigned long long mask = __ballot(pass);
+        total += __popcll(mask);
+        const bool enq = pass && t != p;                                     // the point itself is a neighbour (it counts) but no pair
+        const unsigned long long emask = __ballot(enq);
+        if (enq) sq[(qh + qn_ + __popcll(emask & ((1ull << lane) - 1ull))) & 127u] = make_float4(qq.x, qq.y, qq.z, __uint_as_float(t));
+        qn_ += __popcll(emask);
+        if (qn_ >= 64) {
+            const float4 e = sq[(qh + lane) & 127u];                         // LDS traffic of one wave is ordered: no barrier needed
+            pair_of(true, __float_as_uint(e.w), e.x, e.y, e.z);
+            qh = (qh + 64) & 127u; qn_ -= 64;
+        }
     });
-    total = (uint32_t)wave_sum_i((int)total);
+    if (qn_ > 0) {
+        const bool act = (uint32_t)lane < qn_;
+        const float4 e = sq[(qh + lane) & 127u];
+        pair_of(act, act ? __float_as_uint(e.w) : 0u, e.x, e.y, e.z);
+    }
     const float hist_incr = 100.0f / (float)(total - 1u);
     // a bin that received nothing stays 0 even when hist_incr = 100/0 (point alone in its ball), as in the reference's += loop
     if (lane < 33) a.spfh[(size_t)(base + p) * 33 + lane] = hist[lane] ? (float)hist[lane] * hist_incr : 0.f;
@@ -223,6 +251,7 @@ extern "C" int ismhip_fpfh33(ismhip_ctx* ctx, const ismhip_cloud* cloud, const u
     a.kp_off = ko; a.kx = kpx; a.ky = kpy; a.kz = kpz;
     a.radius = radius; a.r2 = (float)((double)radius * (double)radius);
     a.flag = flag; a.spfh = spfh; a.desc = desc_out; a.count = neighbour_count_out; a.max_pts = cloud->max_pts;
+    { const char* e = getenv("ISMHIP_FPFH_DBG"); a.dbg = e ? atoi(e) : 0; }
     TimerScope ts(ctx, "fpfh33");
     ISM_HIP(ctx, hipMemsetAsync(flag, 0, np, ctx->stream));
     hipLaunchKernelGGL(k_fpfh_mark, dim3((maxk + 3) / 4, n_obj), dim3(256), 0, ctx->stream, a);

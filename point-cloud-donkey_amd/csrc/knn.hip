@@ -1907,7 +1907,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     // short descriptors (FPFH-33: values up to 100, |q||c| ~ 1e4): the f16 error bound is of the order of the neighbour distances, most
     // proofs fail and the exact scan takes over (measured: 135 ms of scan per 524288 queries). The exact-f32 MFMA contraction costs
     // 2 Nq Nc D flop at ~125 TFLOP/s, which for D <= 64 is cheaper than the 16-bit kernels' fixed overheads -- and it proves everything.
-    const bool short_dim = cb->dim <= 64 && ctx->knn_mode == 0;
+    const bool short_dim = cb->dim <= 64 && ctx->knn_mode == 0 && !(use_pca && cb->pca_m > 0);     // (stage 1 of a short-descriptor codebook with an f16 stage-1 image: pca.hip)
     const int mode = cmetric != ISMHIP_METRIC_L2SQ ? -1 : (hell ? 0 : (short_dim ? 2 : (ctx->knn_mode == 0 && cb->words_f16 ? 0 : (ctx->knn_mode <= 1 && cb->words_bf16_hi ? 1 : 2))));
     const bool use_lp = mode == 0 || mode == 1;
     const bool big_tile = use_lp && nq >= 4096 && cb->n_words_pad >= 4096 && !ctx->knn_small_tile;      // 256x256 tile, 8 waves
@@ -2067,7 +2067,9 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 // sampling pre-pass (stage 1 of the two-stage search on the 256 x 256 kernel, codebooks of >= 128 tiles): the best score
                 // every query meets in every 16th codeword tile becomes the start threshold of all its lane slots (see the kernel)
                 const float* thr_init = nullptr; float* thr_out = nullptr; int tile_step = 1;
-                if (stage1 && ring16 && !half && !qpanel && ctx->knn_prepass && n_tiles_m >= 128 && ctx->knn_dbg == 0) {
+                // (not for an untruncated stage-1 image: with nothing left out there is no scale to relax the start value by, and the
+                // unrelaxed best of the sample is the nearest neighbour itself too often)
+                if (stage1 && ring16 && !half && !qpanel && ctx->knn_prepass && n_tiles_m >= 128 && ctx->knn_dbg == 0 && !(pca && cb->pca_resid2 <= 0.f)) {
                     float* thr0 = (float*)ism_scratch(ctx, SCR_KNN_THR0, (size_t)((nq + 255) / 256 * 256) * sizeof(float));
                     if (!thr0) return ISMHIP_ERR_NOMEM;
                     const void* pk = (const void*)k_knn_l2_ring16<T, 2, 0, 0, 1>;
@@ -2468,7 +2470,7 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
     const bool wide = k > 2 || (metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi && ctx->knn_mode <= 1 && !(cb->dim <= 64 && ctx->knn_mode == 0));
     // default for big squared-L2 launches with k <= 2 (every shipped configuration): the two-stage search (see run_knn_two_stage)
     if (metric == ISMHIP_METRIC_L2SQ && k <= 2 && ctx->knn_t == 0 && ctx->knn_mode == 0 && ctx->knn_two_stage && cb->words_f16t && nq >= 4096 &&
-        cb->n_words_pad >= 4096 && !ctx->knn_small_tile && !ctx->knn_no_ring && cb->dim > 64)
+        cb->n_words_pad >= 4096 && !ctx->knn_small_tile && !ctx->knn_no_ring && (cb->dim > 64 || cb->pca_m > 0))
         return run_knn_two_stage(ctx, cb, nq, q, k, idx_out, dist_out);
     // chi-square on histogram data: Hellinger candidates on the matrix cores (run_knn_chi2_hellinger); a batch with a negative element
     // keeps the VALU kernel

@@ -218,8 +218,24 @@ int ism_pca_rotate_queries(ismhip_ctx* ctx, const ismhip_codebook* cb, const flo
 int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
     cb->pca_m = 0;
     const int dp = cb->dim_pad;
-    if (ctx->knn_pca_m == 0 || !cb->words_f16t || dp < 128 || cb->n_words_pad < 4096) return ISMHIP_OK;
+    if (ctx->knn_pca_m == 0 || !cb->words_f16t || dp < 64 || cb->n_words_pad < 4096) return ISMHIP_OK;
     if (!(cb->max_norm2 > 0.f) || !(cb->max_norm2 < 1e30f)) return ISMHIP_OK;          // NaN / inf / all-zero codebooks: nothing to gain
+    // Short descriptors (FPFH-33: 64 padded dimensions, elements up to 100): nothing to truncate, but the SAME machinery with R = I
+    // replaces the exact-f32 MFMA contraction these codebooks otherwise need. The older error model charges the f16 rounding as
+    // 2 * 2^-11 |q||c| on the SQUARED distance (|q||c| ~ 2e4 for FPFH: larger than the neighbour distances themselves); here it enters
+    // as delta = 2^-11 |x| on the DISTANCE (triangle inequality), ~0.1 against distances of 5-20, and the f16 ring kernel proves
+    // nearly every query (configs[4]: the FPFH model's candidate stage 260 -> see DESIGN.md §5 ms per step).
+    const bool identity = dp <= 64;
+    std::vector<float> R;
+    int m = 0; double energy = 1.0, trace = 0.0;
+    if (identity) {
+        m = dp;
+        R.assign((size_t)m * dp, 0.f);
+        for (int j = 0; j < cb->dim; ++j) R[(size_t)j * dp + j] = 1.f;                 // rows beyond dim stay zero: padded coordinates
+        std::vector<float> nh(cb->n_words);
+        ISM_HIP(ctx, hipMemcpy(nh.data(), cb->word_norm, (size_t)cb->n_words * 4, hipMemcpyDeviceToHost));
+        for (float v : nh) trace += v;
+    } else {
     const int nb = dp / 32, n_pairs = nb * (nb + 1) / 2;
     const int n_chunks = std::max(1, std::min(64, cb->n_words / 1024));
     const int rows_per_chunk = (cb->n_words + n_chunks - 1) / n_chunks;
@@ -237,7 +253,7 @@ int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
         for (int i = 0; i < dp; ++i)
             for (int j = i / 32 * 32; j < dp; ++j) S[(size_t)i * dp + j] += (double)part[((size_t)c * dp + i) * dp + j];
     for (int i = 0; i < dp; ++i) for (int j = i + 1; j < dp; ++j) { const double v = i / 32 == j / 32 ? 0.5 * (S[(size_t)i * dp + j] + S[(size_t)j * dp + i]) : S[(size_t)i * dp + j]; S[(size_t)i * dp + j] = v; S[(size_t)j * dp + i] = v; }
-    double trace = 0; for (int i = 0; i < dp; ++i) trace += S[(size_t)i * dp + i];
+    for (int i = 0; i < dp; ++i) trace += S[(size_t)i * dp + i];
     if (!(trace > 0) || !std::isfinite(trace)) return ISMHIP_OK;
     jacobi_eig(dp, S, V, w);
     std::vector<int> order(dp); std::iota(order.begin(), order.end(), 0);
@@ -248,7 +264,7 @@ int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
     // all 352 (no rotated image) -> 0.1 %, 58.7 ms. If the rule leaves less than 64 dimensions saved, or needs more than the 256 the
     // rotation kernel is built for, the original image stays the stage-1 image.
     const int m_cap = std::min(256, dp);
-    int m = 0; double cum = 0, energy = 0;
+    double cum = 0; energy = 0;
     if (ctx->knn_pca_m > 0) {
         m = std::max(64, std::min(m_cap, (ctx->knn_pca_m + 31) / 32 * 32));
         for (int i = 0; i < m; ++i) energy += w[order[i]];
@@ -258,13 +274,14 @@ int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
         for (int i = 0; i < dp && !m; ++i) { cum += w[order[i]]; if ((i + 1) % 32 == 0 && i + 1 >= 64 && cum >= 0.97 * trace) { m = i + 1; energy = cum / trace; } }
         if (m == 0 || m > m_cap || m + 64 > dp) return ISMHIP_OK;
     }
-    std::vector<float> R((size_t)m * dp);
+    R.assign((size_t)m * dp, 0.f);
     for (int j = 0; j < m; ++j) for (int c = 0; c < dp; ++c) R[(size_t)j * dp + c] = c < cb->dim ? (float)V[(size_t)order[j] * dp + c] : 0.f;
+    }   // principal axes / identity
     // sigma_max(R)^2 <= 1 + |R R^T - I|_F and |R|_F, from the fp32 values that are uploaded
     double e2 = 0, fro2 = 0;
     for (int i = 0; i < m; ++i) for (int j = i; j < m; ++j) {
         double g = 0; for (int c = 0; c < dp; ++c) g += (double)R[(size_t)i * dp + c] * (double)R[(size_t)j * dp + c];
-        if (i == j) { fro2 += g; g -= 1.0; e2 += g * g; } else e2 += 2.0 * g * g;
+        if (i == j) { fro2 += g; if (g != 0.0) { g -= 1.0; e2 += g * g; } } else e2 += 2.0 * g * g;     // all-zero rows (padding) only shrink the image
     }
     const double sig2 = 1.0 + std::sqrt(e2), sig = std::sqrt(sig2), fro = std::sqrt(fro2);
     if (!(sig2 < 1.01)) return ISMHIP_OK;                                              // a basis this far from orthonormal is a bug, not a bound

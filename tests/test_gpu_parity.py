@@ -569,6 +569,34 @@ def test_knn_rotated_stage1_on_a_flat_spectrum_falls_back(pkg, gpu, ora, monkeyp
     cb.close()
 
 
+def test_knn_short_descriptors_take_the_f16_ring_with_identity_rotation(pkg, gpu, ora):
+    """FPFH-like rows (33 values up to 100, three blocks summing to 100) in a codebook big enough for the ring kernel: the stage-1
+    image is the f16 image itself (R = I, 64 padded coordinates) with the distance-side error bound of csrc/pca.hip instead of the
+    exact-f32 MFMA contraction. Answers bit-equal to the oracle; the bulk proven in stage 1."""
+    ctx, dev = gpu
+    rng = np.random.default_rng(33)
+    protos = rng.random((80, 33)).astype(np.float32) ** 2
+    def draw(n):
+        x = protos[rng.integers(0, 80, n)] * (0.6 + 0.8 * rng.random((n, 33)).astype(np.float32))
+        x = x.reshape(n, 3, 11); x = 100.0 * x / x.sum(-1, keepdims=True)
+        return x.reshape(n, 33).astype(np.float32)
+    words, q = draw(9000), draw(5000)
+    q[:4] = words[:4]
+    cb = _bare_cb(pkg, ctx, words)
+    assert cb.stage1_dims == 64 and cb.stage1_energy == 1.0
+    ctx.timers_enable(True)
+    try:
+        for k in (1, 2):
+            idx, dist = pkg.capi.knn(ctx, cb, 0, T(q, dev), k)
+            n2 = int(ctx.timer("knn_stage2_queries")[0])
+            widx, wdist = ora.knn(0, words, q, k)
+            assert np.array_equal(idx.cpu().numpy(), widx) and np.array_equal(dist.cpu().numpy(), wdist)
+            assert n2 < 1000, n2
+    finally:
+        ctx.timers_enable(False)
+    cb.close()
+
+
 def test_knn_ties_kat_and_ratio(pkg, gpu, ora):
     ctx, dev = gpu
     k = KAT["knn_ties"]

@@ -4,7 +4,9 @@
   locally        : python tools/make_profiles.py round2                    (copies the summaries into profiles/round2_*)"""
 import collections, csv, glob, json, os, shutil, sys
 
-SHORT = [("k_knn_l2_ring16", "k_knn_l2_ring16"), ("k_knn_l2_mfma16", "k_knn_l2_mfma16"), ("k_shot<false", "k_shot<false>"), ("k_shot<true", "k_shot<true>"),
+SHORT = [("k_knn_l2_ring16", "k_knn_l2_ring16"), ("k_knn_l2_mfma16", "k_knn_l2_mfma16"), ("k_knn_l2_mfma<", "k_knn_l2_mfma"), ("k_rotate_f16t", "k_rotate_f16t"),
+         ("k_knn_rerank_pca", "k_knn_rerank_pca"), ("k_knn_rerank_hell", "k_knn_rerank_hell"), ("k_hell_eval", "k_hell_eval"), ("k_spfh", "k_spfh"),
+         ("k_fpfh_sum", "k_fpfh_sum"), ("k_fpfh_mark", "k_fpfh_mark"), ("k_knn_chi2", "k_knn_chi2"), ("k_shot<false", "k_shot<false>"), ("k_shot<true", "k_shot<true>"),
          ("k_lrf_cov", "k_lrf_cov"), ("k_lrf_sign", "k_lrf_sign"), ("k_lrf_tie", "k_lrf_tie"), ("k_lrf_eig", "k_lrf_eig"), ("k_knn_rerank", "k_knn_rerank"),
          ("k_knn_fallback_merge", "k_knn_fallback_merge"), ("k_knn_fallback", "k_knn_fallback"), ("k_find_maxima", "k_find_maxima"), ("k_scatter", "k_scatter"),
          ("k_count", "k_count"), ("k_to_f16_tiled", "k_to_f16_tiled"), ("k_cast_votes", "k_cast_votes"), ("k_knn_merge_splits", "k_knn_merge_splits")]
@@ -17,17 +19,20 @@ def short(name):
     return None
 
 
-def condense(root):
+def condense(root, cfg=1):
+    sfx = "" if cfg == 1 else f"_cfg{cfg}"
     rows = []
-    for p in ("pmc_fetch_final", "pmc_write_final", "pmc_sq_finalA", "pmc_sq_finalB"):
+    for p in ("pmc_fetch_final" + sfx, "pmc_write_final" + sfx) + (("pmc_sq_finalA", "pmc_sq_finalB") if cfg == 1 else ()):
         acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set); meta = {}
         for f in glob.glob(os.path.join(root, p, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
                 if not k:
                     continue
-                if k == "k_knn_l2_ring16" and "<2," not in r["Kernel_Name"]:
+                if k == "k_knn_l2_ring16" and "<2," not in r["Kernel_Name"] and cfg != 3:
                     continue                                   # stage 1 of the search (T = 2) is the bench kernel; the training launch uses it too
+                if k == "k_knn_l2_ring16" and r["Kernel_Name"].rstrip(">) ").endswith(", 1"):
+                    k = "k_knn_l2_ring16<pre>"                 # the sampling pre-pass (PRE = 1) is listed apart from the main launch
                 k = (k, int(r.get("Grid_Size", 0) or 0))      # launches of different size (training, stage 2, the two bench chunks) stay apart
                 acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
                 meta[k] = (r.get("Grid_Size", ""), r.get("Workgroup_Size", ""), r.get("LDS_Block_Size", ""), r.get("VGPR_Count", ""))
@@ -40,44 +45,46 @@ def condense(root):
             for n, v in sorted(c.items()):
                 rows.append(dict(pass_=p, kernel=k[0], dispatches=len(cnt[k]), grid_threads=meta[k][0], workgroup=meta[k][1], lds_bytes=meta[k][2], vgprs=meta[k][3],
                                  counter=n, value_per_dispatch=v / len(cnt[k])))
-    with open(os.path.join(root, "pmc_condensed.csv"), "w", newline="") as f:
+    with open(os.path.join(root, f"pmc_condensed{sfx}.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()) if rows else ["pass_"])
         w.writeheader(); w.writerows(rows)
-    log = os.path.join(root, "prof_final.log")
+    log = os.path.join(root, f"prof_final{sfx}.log")
     if os.path.exists(log):
         lines = [l for l in open(log) if l.startswith('{"metric"')]
         if lines:
-            open(os.path.join(root, "prof_bench_line.json"), "w").write(lines[-1])
+            open(os.path.join(root, f"prof_bench_line{sfx}.json"), "w").write(lines[-1])
     print("condensed", len(rows), "rows")
 
 
-def publish(tag, root="gpurun_out", dst="profiles"):
+def publish(tag, cfg=1, root="gpurun_out", dst="profiles"):
+    sfx = "" if cfg == 1 else f"_cfg{cfg}"
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(root, "prof_final", "**", "*kernel_stats.csv"), recursive=True)
+    stats = glob.glob(os.path.join(root, "prof_final" + sfx, "**", "*kernel_stats.csv"), recursive=True)
     if stats:
-        shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
-    for src, name in (("pmc_condensed.csv", f"{tag}_pmc_bench_counters.csv"), ("prof_bench_line.json", f"{tag}_bench_line.json")):
+        shutil.copy(stats[0], os.path.join(dst, f"{tag}{sfx}_bench_kernel_stats.csv"))
+    for src, name in ((f"pmc_condensed{sfx}.csv", f"{tag}{sfx}_pmc_bench_counters.csv"), (f"prof_bench_line{sfx}.json", f"{tag}{sfx}_bench_line.json")):
         if os.path.exists(os.path.join(root, src)):
             shutil.copy(os.path.join(root, src), os.path.join(dst, name))
-    # beyond-L2 traffic per launch of the two roofline kernels: FETCH_SIZE (KiB, counts 64 B per 128-B request on gfx950 -> doubled,
+    # beyond-L2 traffic per launch of the roofline kernels: FETCH_SIZE (KiB, counts 64 B per 128-B request on gfx950 -> doubled,
     # MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KiB)
-    rows = list(csv.DictReader(open(os.path.join(root, "pmc_condensed.csv"))))
-    line = json.load(open(os.path.join(root, "prof_bench_line.json")))
-    out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --cpu-objects 0 --no-e2e --steps 2 --warmup 1",
+    rows = list(csv.DictReader(open(os.path.join(root, f"pmc_condensed{sfx}.csv"))))
+    line = json.load(open(os.path.join(root, f"prof_bench_line{sfx}.json")))
+    carg = "" if cfg == 1 else f" --config {cfg}"
+    out = {"command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --cpu-objects 0 --no-e2e{carg} --steps 2 --warmup 1",
            "note": "FETCH_SIZE/WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request and is doubled (MI355X_MICROARCH.md, HBM); "
                    "Infinity-Cache hits are included, so this is traffic beyond the XCD L2s, not DRAM alone",
            "objects": line["config"]["objects_per_step_all_gpus"], "launches_per_step": line["config"]["launches_per_step_per_gpu"]}
-    for k in ("k_shot<false>", "k_knn_l2_ring16", "k_lrf_cov", "k_lrf_sign"):
+    for k in sorted({r["kernel"] for r in rows}):
         f = [float(r["value_per_dispatch"]) for r in rows if r["kernel"] == k and r["counter"] == "FETCH_SIZE"]
         w = [float(r["value_per_dispatch"]) for r in rows if r["kernel"] == k and r["counter"] == "WRITE_SIZE"]
         if f and w:
             out[k] = {"fetch_kib_raw": f[0], "write_kib": w[0], "bytes_per_launch": (2 * f[0] + w[0]) * 1024}
-    json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-    print("published", tag, {k: v for k, v in out.items() if isinstance(v, dict)})
+    json.dump(out, open(os.path.join(dst, f"{tag}{sfx}_pmc_traffic.json"), "w"), indent=1)
+    print("published", tag, cfg, {k: round(v["bytes_per_launch"] / 1e9, 3) for k, v in out.items() if isinstance(v, dict)})
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "--condense":
-        condense(sys.argv[2])
+        condense(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     else:
-        publish(sys.argv[1])
+        publish(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1)
