@@ -143,3 +143,29 @@ def test_bench_refuses_more_ranks_than_gpus():
     env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29544")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_fpfh_fast_atan2_polynomial_error_is_far_below_the_guard_band():
+    """csrc/fpfh.hip::fast_atan2 (degree-13 odd polynomial on [0, 1] + octant folding), emulated in float32: its error must stay
+    far below FPFH_GUARD = 1e-4 of a bin (= 5.7e-5 rad), because pairs whose bin coordinate is further than the guard from a bin
+    boundary keep the FAST bin without ever running the reference's arithmetic."""
+    f = np.float32
+    c = [f(0.008097294718027115), f(-0.037751708179712296), f(0.08475969731807709), f(-0.13537675142288208), f(0.19895026087760925),
+         f(-0.3332797586917877), f(0.9999997019767761)]
+    rng = np.random.default_rng(0)
+    ang = np.concatenate([rng.uniform(-np.pi, np.pi, 400000), np.linspace(-np.pi, np.pi, 200001)])
+    rad = np.concatenate([rng.uniform(0.02, 1.0, 400000), np.full(200001, 0.5)])
+    x, y = (rad * np.cos(ang)).astype(f), (rad * np.sin(ang)).astype(f)
+    ax, ay = np.abs(x), np.abs(y)
+    a = (np.minimum(ax, ay) * (f(1) / np.maximum(ax, ay))).astype(f)
+    z = (a * a).astype(f)
+    p = np.full_like(z, c[0])
+    for ci in c[1:]:
+        p = (p * z + ci).astype(f)
+    r = (a * p).astype(f)
+    r = np.where(ay > ax, f(1.57079632679489662) - r, r).astype(f)
+    r = np.where(x < 0, f(3.14159265358979323846) - r, r).astype(f)
+    r = np.where(y < 0, -r, r)
+    err = np.abs(r.astype(np.float64) - np.arctan2(y.astype(np.float64), x.astype(np.float64)))
+    err = np.minimum(err, 2 * np.pi - err)
+    assert err.max() < 2e-6, err.max()
