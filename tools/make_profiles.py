@@ -2,7 +2,7 @@
   on the GPU box : python tools/make_profiles.py --condense gpurun_out     (per-kernel, per-dispatch averages -> gpurun_out/pmc_condensed.csv,
                                                                             bench line of the stats pass -> gpurun_out/prof_bench_line.json)
   locally        : python tools/make_profiles.py round2                    (copies the summaries into profiles/round2_*)"""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
 
 SHORT = [("k_knn_l2_ring16", "k_knn_l2_ring16"), ("k_knn_l2_mfma16", "k_knn_l2_mfma16"), ("k_knn_l2_mfma<", "k_knn_l2_mfma"), ("k_rotate_f16t", "k_rotate_f16t"),
          ("k_knn_rerank_pca", "k_knn_rerank_pca"), ("k_knn_rerank_hell", "k_knn_rerank_hell"), ("k_hell_eval", "k_hell_eval"), ("k_spfh", "k_spfh"),
@@ -31,7 +31,7 @@ def condense(root, cfg=1):
                     continue
                 if k == "k_knn_l2_ring16" and "<2," not in r["Kernel_Name"] and cfg != 3:
                     continue                                   # stage 1 of the search (T = 2) is the bench kernel; the training launch uses it too
-                if k == "k_knn_l2_ring16" and r["Kernel_Name"].rstrip(">) ").endswith(", 1"):
+                if k == "k_knn_l2_ring16" and re.search(r"k_knn_l2_ring16<\d+, \d+, \d+, \d+, 1>", r["Kernel_Name"]):
                     k = "k_knn_l2_ring16<pre>"                 # the sampling pre-pass (PRE = 1) is listed apart from the main launch
                 k = (k, int(r.get("Grid_Size", 0) or 0))      # launches of different size (training, stage 2, the two bench chunks) stay apart
                 acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
