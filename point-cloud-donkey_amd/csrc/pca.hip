@@ -218,7 +218,9 @@ int ism_pca_rotate_queries(ismhip_ctx* ctx, const ismhip_codebook* cb, const flo
 int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
     cb->pca_m = 0;
     const int dp = cb->dim_pad;
-    if (ctx->knn_pca_m == 0 || !cb->words_f16t || dp < 64 || cb->n_words_pad < 4096) return ISMHIP_OK;
+    // (descriptors longer than 512: the host eigen-solve is cubic in the length -- 352 dimensions ~1 s, 1344 tens of seconds -- and the only
+    // long descriptor of the path, CSHOT-1344, is searched with chi-square in every shipped configuration; ISMHIP_KNN_PCA_M > 0 overrides)
+    if (ctx->knn_pca_m == 0 || !cb->words_f16t || dp < 64 || cb->n_words_pad < 4096 || (dp > 512 && ctx->knn_pca_m < 0)) return ISMHIP_OK;
     if (!(cb->max_norm2 > 0.f) || !(cb->max_norm2 < 1e30f)) return ISMHIP_OK;          // NaN / inf / all-zero codebooks: nothing to gain
     // Short descriptors (FPFH-33: 64 padded dimensions, elements up to 100): nothing to truncate, but the SAME machinery with R = I
     // replaces the exact-f32 MFMA contraction these codebooks otherwise need. The older error model charges the f16 rounding as
