@@ -126,6 +126,7 @@ struct ismhip_ctx {
     bool knn_two_stage = true;   // env ISMHIP_KNN_TWOSTAGE=0: single-stage T = 4 search (A/B runs)
     bool knn_small_tile = false; // env ISMHIP_KNN_TILE128=1: keep the bf16x3 kernel on its 128x128 tile (A/B runs)
     bool knn_join = true;        // env ISMHIP_KNN_JOIN=0: every workgroup of the ring kernel sweeps its split from the first tile (A/B runs); default: joined streams
+    bool knn_qpanel2 = true;     // env ISMHIP_KNN_QPANEL2=0: stage 1 on <= 160 rotated coordinates WITHOUT the 256-query panel resident in LDS (A/B runs; default on: 27.5 -> 25.4 ms per bench launch)
     bool knn_qpanel = false;     // env ISMHIP_KNN_QPANEL=1: the ring kernel on 256 x 128 tiles with the query panel resident in LDS (A/B runs)
     bool knn_half = false;       // env ISMHIP_KNN_HALF=1: the ring kernel on 128 x 256 tiles, two workgroups per CU (A/B runs)
     bool knn_ring32 = false;     // env ISMHIP_KNN_RING32=1: the ring kernel on the 32x32x16 MFMA shape instead of 16x16x32 (A/B runs)

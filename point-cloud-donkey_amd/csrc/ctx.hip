@@ -68,6 +68,7 @@ static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out)
     { const char* e = getenv("ISMHIP_KNN_TWOSTAGE"); ctx->knn_two_stage = !(e && e[0] == '0'); }
     { const char* e = getenv("ISMHIP_KNN_JOIN"); ctx->knn_join = !(e && e[0] == '0'); }
     { const char* e = getenv("ISMHIP_KNN_QPANEL"); ctx->knn_qpanel = e && e[0] == '1'; }
+    { const char* e = getenv("ISMHIP_KNN_QPANEL2"); ctx->knn_qpanel2 = !(e && e[0] == '0'); }
     { const char* e = getenv("ISMHIP_KNN_HALF"); ctx->knn_half = e && e[0] == '1'; }
     { const char* e = getenv("ISMHIP_KNN_RING32"); ctx->knn_ring32 = e && e[0] == '1'; }
     { const char* e = getenv("ISMHIP_KNN_SPLITS"); ctx->knn_splits = e ? atoi(e) : 0; }

@@ -800,13 +800,17 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx, int cand_stride,
                                                           float* __restrict__ cand_bound, int bound_stride, unsigned int* __restrict__ stream_clock,
                                                           const float* __restrict__ thr_init, float* __restrict__ thr_out, int tile_step, float thr_relax) {
-    constexpr int WC = 4, MT = 8, NT = QP ? 2 : 4, KB = RG_KB, BM = WR * 128, BN = QP ? 128 : RG_BN;
+    constexpr int WC = 4, MT = 8, NT = QP == 1 ? 2 : 4, KB = RG_KB, BM = WR * 128, BN = QP == 1 ? 128 : RG_BN;
+    constexpr int PROWS = QP == 2 ? 256 : 128;                           // query rows of the resident panel
+    // QP = 2 (round 3; stage 1 on <= 160 rotated coordinates): the 256 x 256 tile WITH its whole query panel (256 queries x <= 5 slices,
+    // <= 80 KB) resident in LDS: the ring then streams codeword slices only (16 KB per step instead of 32 KB, half the DMA
+    // instructions); the panel did not fit next to a four-stage ring at 11 slices, and QP = 1 pays for it with half the queries per tile
     constexpr int STAGES = WR == 2 ? 4 : 3, STAGE_HALVES = (QP ? BM : BM + BN) * KB, CNS = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
     u16* ring = (u16*)knn_smem;                                        // [STAGES][BM + BN rows][32 halves] (QP: codeword rows only)
     float* sCn = (float*)(ring + STAGES * STAGE_HALVES);              // [4][CNS]: |c|^2 of four tiles (a DMA always delivers 256 floats)
     float* sThr = sCn + 4 * CNS;                                       // [8 waves][NT][64] (WR = 2 only)
-    u16* panel = (u16*)(sThr + 8 * NT * 64);                           // QP: [slices][128 queries][32 halves]
+    u16* panel = (u16*)(sThr + 8 * NT * 64);                           // QP: [slices][PROWS queries][32 halves]
     const float oscale = out_scale[0];
 
     const int tid = threadIdx.x;
@@ -847,9 +851,15 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
     const bool dma_a = QP || WR == 1 || wv < 4, dma_b = !QP && (WR == 1 || wv >= 4);
     const unsigned lane_off = (unsigned)(lane * 16);
     const int row_a = QP ? wv * 32 : (WR == 2 ? (wv & 3) * 64 : wv * 32), row_b = (wv & 3) * 64;
-    const char* qbase = QP ? (const char*)(qh + (size_t)(qtile >> 1) * nk * (256 * KB)) + ((qtile & 1) * 128 + wv * 16) * (KB * 2)
+    const char* qbase = QP == 2 ? (const char*)(qh + (size_t)qtile * nk * (256 * KB)) + (wv * 32) * (KB * 2)
+                      : QP ? (const char*)(qh + (size_t)(qtile >> 1) * nk * (256 * KB)) + ((qtile & 1) * 128 + wv * 16) * (KB * 2)
                            : (const char*)(qh + (size_t)qtile * nk * (BN * KB)) + row_b * (KB * 2);
-    if (QP) {            // the query panel: wave w brings rows 16 w .. 16 w + 15 of every slice
+    if (QP == 2) {       // the query panel: wave w brings rows 32 w .. 32 w + 31 of every slice (two 16-row pieces)
+        for (int s_ = 0; s_ < nk; ++s_) {
+            lds_dma16(qbase + (size_t)s_ * (256 * KB * 2) + lane_off, panel + (s_ * 256 + wv * 32) * KB);
+            lds_dma16(qbase + (size_t)s_ * (256 * KB * 2) + 16 * KB * 2 + lane_off, panel + (s_ * 256 + wv * 32 + 16) * KB);
+        }
+    } else if (QP) {     // the query panel: wave w brings rows 16 w .. 16 w + 15 of every slice
         for (int s_ = 0; s_ < nk; ++s_) lds_dma16(qbase + (size_t)s_ * (256 * KB * 2) + lane_off, panel + (s_ * 128 + wv * 16) * KB);
     }
     int pt = 0, pkc = 0, ps = 0;
@@ -914,7 +924,7 @@ __global__ __launch_bounds__(WR * 256, 2) void k_knn_l2_ring16(const u16* __rest
         gs = gn;
         if (!(DBG & 16) || g == 0) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bq[n] = *(const f16x8*)((QP ? panel + kc * (128 * KB) : st) + fragB + n * 16 * KB);
+        for (int n = 0; n < NT; ++n) bq[n] = *(const f16x8*)((QP ? panel + kc * (PROWS * KB) : st) + fragB + n * 16 * KB);
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
@@ -1920,6 +1930,8 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     const bool half = ring16 && ctx->knn_half;                         // 128 x 256 tile, two workgroups per CU (k_knn_l2_ring16<T, 1>)
     const bool qpanel = ring16 && !half && ctx->knn_qpanel && ((cb->dim + 15) / 16 + 1) / 2 <= 11;   // 256 x 128 tile, query panel resident in LDS
     if (qpanel) BNq = 128;
+    // 256 x 256 tile with the whole query panel resident (k_knn_l2_ring16<T, 2, 0, 2>): stage 1 on a rotated image of <= 160 coordinates
+    const bool qpanel2 = ring16 && !half && !qpanel && ctx->knn_qpanel2 && use_pca && cb->pca_m > 0 && cb->pca_m <= 160;
     const int BM = half ? 128 : BM0;
     const int slots = ring16 && !half ? 8 : 4;
     // stage 1 of the two-stage search on the rotated, truncated image (pca.hip): same kernel, pca_m / 32 slices instead of dim / 32
@@ -2019,7 +2031,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
             }
             if (use_ring) {
                 wh = xb->words_f16t;
-                const void* rk = ring16 ? (qpanel ? (const void*)k_knn_l2_ring16<T, 2, 0, 1> : half ? (const void*)k_knn_l2_ring16<T, 1, 0> : (const void*)k_knn_l2_ring16<T, 2, 0>) : (const void*)k_knn_l2_ring<T, 0>;
+                const void* rk = ring16 ? (qpanel2 ? (const void*)k_knn_l2_ring16<T, 2, 0, 2> : qpanel ? (const void*)k_knn_l2_ring16<T, 2, 0, 1> : half ? (const void*)k_knn_l2_ring16<T, 1, 0> : (const void*)k_knn_l2_ring16<T, 2, 0>) : (const void*)k_knn_l2_ring<T, 0>;
 #ifdef ISM_KNN_DBG_VARIANTS
                 if (ring16) switch (ctx->knn_dbg) {       // 1 no epilogue, 2 no MFMA, 4 no DMA, 16 no fragment reads, 32 no barrier, 64 pre-test only, 256 counters
                     case 1: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 1> : (const void*)k_knn_l2_ring16<T, 2, 1>; break;  case 2: rk = half ? (const void*)k_knn_l2_ring16<T, 1, 2> : (const void*)k_knn_l2_ring16<T, 2, 2>; break;
@@ -2039,7 +2051,8 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     default: break;
                 }
 #endif
-                const size_t rlds = qpanel ? (size_t)4 * 256 * RG_KB * sizeof(u16) + 4 * 256 * sizeof(float) + 8 * 2 * 64 * sizeof(float) + (size_t)ring_nk * 128 * RG_KB * sizeof(u16)
+                const size_t rlds = qpanel2 ? (size_t)4 * 256 * RG_KB * sizeof(u16) + 4 * 256 * sizeof(float) + 8 * 4 * 64 * sizeof(float) + (size_t)ring_nk * 256 * RG_KB * sizeof(u16)
+                                  : qpanel ? (size_t)4 * 256 * RG_KB * sizeof(u16) + 4 * 256 * sizeof(float) + 8 * 2 * 64 * sizeof(float) + (size_t)ring_nk * 128 * RG_KB * sizeof(u16)
                                   : half ? (size_t)3 * (128 + 256) * RG_KB * sizeof(u16) + 4 * 256 * sizeof(float)
                                          : (size_t)RG_STAGES * RG_STAGE_HALVES * sizeof(u16) + 4 * RG_BM * sizeof(float) + 8 * 4 * 64 * sizeof(float);
                 if (ctx->knn_dbg || !ctx->attr_done.count(rk)) {          // per device, so remembered per ctx

@@ -1158,19 +1158,22 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, ora, monkeypatch):
     wn = words.numpy()
     off = np.arange(n_words + 1, dtype=np.uint32)
     res = {}
-    modes = ("f16", "f16-nopca", "f16-pca192", "f16-ring32", "f16-nojoin", "f16-half", "f16-qpanel", "f32")
+    modes = ("f16", "f16-nopca", "f16-pca192", "f16-pca128noqp2", "f16-ring32", "f16-nojoin", "f16-half", "f16-qpanel", "f32")
     for mode in modes:
         monkeypatch.setenv("ISMHIP_KNN_MODE", mode.split("-")[0])
         if mode.endswith("nopca"):
             monkeypatch.setenv("ISMHIP_KNN_PCA_M", "0")                                       # stage 1 on all 352 dimensions
         elif mode.endswith("pca192"):
             monkeypatch.setenv("ISMHIP_KNN_PCA_M", "192")                                     # stage 1 forced onto 192 rotated coordinates
+        elif mode.endswith("pca128noqp2"):
+            monkeypatch.setenv("ISMHIP_KNN_PCA_M", "128")                                     # 128 coordinates, query panel NOT resident
         else:
             monkeypatch.delenv("ISMHIP_KNN_PCA_M", raising=False)
         monkeypatch.setenv("ISMHIP_KNN_RING32", "1" if mode.endswith("ring32") else "0")     # the 32x32x16 variant of the ring kernel
         monkeypatch.setenv("ISMHIP_KNN_JOIN", "0" if mode.endswith("nojoin") else "1")       # every workgroup sweeps its split from tile 0
         monkeypatch.setenv("ISMHIP_KNN_HALF", "1" if mode.endswith("half") else "0")         # 128 x 256 tiles, two workgroups per CU
         monkeypatch.setenv("ISMHIP_KNN_QPANEL", "1" if mode.endswith("qpanel") else "0")     # 256 x 128 tiles, query panel resident in LDS
+        monkeypatch.setenv("ISMHIP_KNN_QPANEL2", "0" if mode.endswith("noqp2") else "1")     # 256 x 256 tiles with the panel resident (default at <= 160 coordinates)
         ctx = pkg.capi.Ctx(0)
         cb = pkg.capi.Codebook(ctx, wn, off, np.zeros((n_words, 3), np.float32), np.zeros(n_words, np.uint32), np.zeros(n_words, np.uint32), 1,
                                np.ones(1, np.float32))
@@ -1178,7 +1181,7 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, ora, monkeypatch):
         idx, dist = pkg.capi.knn(ctx, cb, 0, q.to(dev), 2)
         res[mode] = (idx.cpu().numpy(), dist.cpu().numpy(), _knn_flagged(ctx), cb.stage1_dims)
         cb.close()
-    assert res["f16-nopca"][3] == 0 and res["f16-pca192"][3] == 192
+    assert res["f16-nopca"][3] == 0 and res["f16-pca192"][3] == 192 and res["f16-pca128noqp2"][3] == 128
     for m in modes[:-1]:
         assert np.array_equal(res[m][0], res["f32"][0]), m
         assert np.array_equal(res[m][1], res["f32"][1]), m
