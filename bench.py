@@ -306,10 +306,10 @@ def main():
                     kname, peak, flop, extra = "k_knn_l2_mfma", PEAK_FP32_MFMA_TFLOPS, flop_eff, {}
                 else:
                     # stage 1 runs on the m leading rotated coordinates of the codebook (csrc/pca.hip; m = dim when the codebook has no
-                    # rotated image) plus a sampling pre-pass over every 16th codeword tile: `achieved` counts the flops ISSUED by
+                    # rotated image) plus a sampling pre-pass over every 32nd codeword tile: `achieved` counts the flops ISSUED by
                     # those launches; the 2*Nq*Nc*dim figure of SURVEY 8(d) is reported beside it as `effective`, NOT as the fraction
                     m1 = rec.codebook.stage1_dims or cfg.dim
-                    pre = (1.0 + 1.0 / 16.0) if (rec.codebook.stage1_dims and rec.codebook.stage1_energy < 1.0 and nw > 127 * 256 and os.environ.get("ISMHIP_KNN_PREPASS", "1") != "0") else 1.0
+                    pre = (1.0 + 1.0 / float(os.environ.get("ISMHIP_KNN_PRE_STEP", "32"))) if (rec.codebook.stage1_dims and rec.codebook.stage1_energy < 1.0 and nw > 127 * 256 and os.environ.get("ISMHIP_KNN_PREPASS", "1") != "0") else 1.0
                     kname, peak, mult = {"f16": ("k_knn_l2_ring" if os.environ.get("ISMHIP_KNN_RING32") == "1" else "k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0),
                                          "bf16x3": ("k_knn_l2_mfma16<bf16x3>", PEAK_F16_MFMA_TFLOPS, 3.0),
                                          "f32": ("k_knn_l2_mfma", PEAK_FP32_MFMA_TFLOPS, 1.0)}.get(knn_mode, ("k_knn_l2_ring16", PEAK_F16_MFMA_TFLOPS, 1.0))

@@ -141,7 +141,8 @@ struct ismhip_ctx {
     bool knn_hell_emit = true;   // env ISMHIP_KNN_HELL_EMIT=0: queries the Hellinger proof leaves open go to the VALU kernel instead of the list-and-evaluate stage (A/B runs)
     bool knn_hellinger = true;   // env ISMHIP_KNN_HELLINGER=0: chi-square candidates by the VALU kernel k_knn_chi2 only (A/B runs)
     int knn_t1 = 2;              // env ISMHIP_KNN_T1 = 1 | 2: candidates kept per lane slot in stage 1 of the two-stage search (A/B runs)
-    float knn_pre_gamma = 1.5f;  // env ISMHIP_KNN_PRE_GAMMA: relaxation of the pre-pass start thresholds in units of the truncated second moment (A/B runs)
+    int knn_pre_step = 32;       // env ISMHIP_KNN_PRE_STEP: the sampling pre-pass sweeps every n-th codeword tile (measured with the resident query panel, kNN ms per bench launch at gamma 1.0: 8 -> 36.4, 16 -> 33.6, 32 -> 33.2; no pre-pass 34.7)
+    float knn_pre_gamma = 1.0f;  // env ISMHIP_KNN_PRE_GAMMA: relaxation of the pre-pass start thresholds in units of the truncated second moment (A/B runs)
     bool knn_prepass = true;     // env ISMHIP_KNN_PREPASS=0: stage 1 starts every candidate list cold instead of from the sampled pre-pass threshold (A/B runs)
     int knn_pca_m = -1;          // env ISMHIP_KNN_PCA_M: leading rotated coordinates of the stage-1 image (0 = no rotated image, -1 = chosen from the spectrum)
     uint32_t knn_pca_launches = 0;    // squared-L2 searches whose stage 1 ran on the rotated image (tests / bench)

@@ -2087,7 +2087,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     if (!thr0) return ISMHIP_ERR_NOMEM;
                     const void* pk = (const void*)k_knn_l2_ring16<T, 2, 0, 0, 1>;
                     if (!ctx->attr_done.count(pk)) { ISM_HIP(ctx, hipFuncSetAttribute(pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds)); ctx->attr_done.insert(pk); }
-                    int one = 1, all = n_tiles_m, step = 16; unsigned int* noclk = nullptr; const float* noinit = nullptr;
+                    int one = 1, all = n_tiles_m, step = ctx->knn_pre_step; unsigned int* noclk = nullptr; const float* noinit = nullptr;
                     // relaxation: gamma x the second moment the truncation leaves out (codeword + query side, taken as equal), in
                     // accumulator units (score / out_scale); the original image truncates nothing
                     float relax = 0.f;
