@@ -112,6 +112,12 @@ int  ismhip_estimate_normals(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius,
  * towards the viewpoint. orientation 0: towards (0,0,0) (method 0); 1: away from the object's centroid (method 1). Outputs as
  * ismhip_estimate_normals. */
 int  ismhip_estimate_normals_pca(ismhip_ctx* ctx, ismhip_cloud* cloud, float radius, int orientation, float* nx_out, float* ny_out, float* nz_out);
+/* ImplicitShapeModel::filterNormals (implicit_shape_model.cpp:1034-1075): the points whose normal holds a NaN leave their cloud, order
+ * kept, without the arrays leaving HBM. in / out: device SoA over all objects (out must not alias in; rgba may be NULL in both);
+ * pt_offsets_h_out[n_obj+1] (host) receives the new ranges. The call synchronises. */
+typedef struct ismhip_point_arrays { float *x, *y, *z, *nx, *ny, *nz; uint32_t* rgba; } ismhip_point_arrays;
+int  ismhip_filter_normals(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_h, const ismhip_point_arrays* in,
+                           const ismhip_point_arrays* out, uint32_t* pt_offsets_h_out);
 /* per-object centroid (features_shot.cpp:45-51) -> centroid_out[n_obj*3] */
 int  ismhip_cloud_centroids(ismhip_ctx* ctx, const ismhip_cloud* cloud, float* centroid_out);
 /* SingleObjectHelper::getModelRadius (voting/single_object_mode_helper.cpp:15-27): per object the largest distance of a (finite)

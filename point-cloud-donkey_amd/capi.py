@@ -25,7 +25,7 @@ EXPORTS = [
     "ismhip_timers_enable", "ismhip_timers_reset", "ismhip_timer_get",
     "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids", "ismhip_cloud_radii", "ismhip_estimate_normals", "ismhip_estimate_normals_pca",
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
-    "ismhip_compact_features", "ismhip_voxel_keypoints", "ismhip_gather_columns",
+    "ismhip_compact_features", "ismhip_filter_normals", "ismhip_voxel_keypoints", "ismhip_gather_columns",
     "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word", "ismhip_codebook_stage1_dims",
     "ismhip_knn", "ismhip_knn_ratio", "ismhip_knn_rule", "ismhip_cast_votes", "ismhip_find_maxima", "ismhip_hough3d_maxima", "ismhip_train_activate", "ismhip_kmeans",
 ]
@@ -282,6 +282,27 @@ def estimate_normals_pca(ctx, cloud, radius, orientation, nx, ny, nz):
     ctx.check(lib().ismhip_estimate_normals_pca(ctx._h, cloud._h, C.c_float(radius), C.c_int(orientation), _p(nx), _p(ny), _p(nz)), "ismhip_estimate_normals_pca")
     cloud._keep = getattr(cloud, "_keep", ()) + (nx, ny, nz)
     return nx, ny, nz
+
+
+class _PointArrays(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "y", "z", "nx", "ny", "nz", "rgba")]
+
+
+def filter_normals(ctx, pt_offsets, x, y, z, nx, ny, nz, rgba=None):
+    """ImplicitShapeModel::filterNormals on the device: returns (new_offsets numpy, x, y, z, nx, ny, nz, rgba or None) without the
+    points whose normal holds a NaN (order kept)"""
+    torch = _torch()
+    po = _u32(pt_offsets)
+    n_obj = len(po) - 1
+    ins = [x, y, z, nx, ny, nz] + ([rgba] if rgba is not None else [])
+    outs = [torch.empty_like(t) for t in ins]
+    a_in = _PointArrays(*[t.data_ptr() for t in ins], *([None] if rgba is None else []))
+    a_out = _PointArrays(*[t.data_ptr() for t in outs], *([None] if rgba is None else []))
+    new = np.zeros(n_obj + 1, dtype=np.uint32)
+    ctx.check(lib().ismhip_filter_normals(ctx._h, C.c_int(n_obj), _p(po), C.byref(a_in), C.byref(a_out), _p(new)), "ismhip_filter_normals")
+    m = int(new[-1])
+    outs = [t[:m] for t in outs]
+    return (new, *outs, *([None] if rgba is None else []))
 
 
 def voxel_keypoints(ctx, pt_offsets, x, y, z, leaf, rgba=None):

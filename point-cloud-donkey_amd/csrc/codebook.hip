@@ -171,11 +171,11 @@ int ismhip_codebook_create(ismhip_ctx* ctx, int n_words, int dim, const float* w
         cb->words_nonneg = nonneg;
         int rc = ism_codebook_split_bf16(ctx, cb, amax);
         if (rc != ISMHIP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(rc != ISMHIP_OK ? rc : ISMHIP_ERR_HIP, "codebook_create: bf16 split");
-        rc = ism_codebook_build_pca(ctx, cb);
+        if (!ctx->codebook_light) rc = ism_codebook_build_pca(ctx, cb);
         if (rc != ISMHIP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(rc != ISMHIP_OK ? rc : ISMHIP_ERR_HIP, "codebook_create: rotated image");
         // chi-square candidates on the matrix cores: 16-bit images, norms and scales of sqrt(words) in a shadow codebook (histogram
         // codebooks of descriptors longer than 64 only: short ones take the exact-f32 contraction for L2 and the VALU kernel for chi-square)
-        if (nonneg && dim > 64 && ctx->knn_hellinger && n_words >= 1024) {
+        if (nonneg && dim > 64 && ctx->knn_hellinger && n_words >= 1024 && !ctx->codebook_light) {
             ismhip_codebook* sh = new ismhip_codebook();
             cb->chi_shadow = sh;
             sh->n_words = n_words; sh->dim = dim; sh->dim_pad = cb->dim_pad; sh->n_words_pad = cb->n_words_pad; sh->n_classes = n_classes;

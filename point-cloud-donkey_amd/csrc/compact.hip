@@ -110,6 +110,61 @@ extern "C" int ismhip_compact_features(ismhip_ctx* ctx, int n_obj, const uint32_
 }
 
 
+// ---- ImplicitShapeModel::filterNormals (implicit_shape_model.cpp:1034-1075): the points whose estimated normal holds a NaN leave the
+//      cloud, order kept. The arrays stay in HBM: flag, per-object scan (k_scan_obj), gather into the output arrays.
+namespace {
+__global__ void k_keep_normals(uint32_t n, const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz, uint32_t* __restrict__ keep) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keep[i] = (isnan(nx[i]) || isnan(ny[i]) || isnan(nz[i])) ? 0u : 1u;
+}
+__global__ __launch_bounds__(256) void k_gather_points(const uint32_t* __restrict__ off, const uint32_t* __restrict__ new_off, const uint32_t* __restrict__ keep,
+                                                       const uint32_t* __restrict__ pos, ismhip_point_arrays in, ismhip_point_arrays out) {
+    const int o = blockIdx.y;
+    const uint32_t i = off[o] + blockIdx.x * 256 + threadIdx.x;
+    if (i >= off[o + 1] || !keep[i]) return;
+    const uint32_t d = new_off[o] + pos[i];
+    out.x[d] = in.x[i]; out.y[d] = in.y[i]; out.z[d] = in.z[i];
+    out.nx[d] = in.nx[i]; out.ny[d] = in.ny[i]; out.nz[d] = in.nz[i];
+    if (in.rgba && out.rgba) out.rgba[d] = in.rgba[i];
+}
+}  // namespace
+
+extern "C" int ismhip_filter_normals(ismhip_ctx* ctx, int n_obj, const uint32_t* pt_offsets_h, const ismhip_point_arrays* in,
+                                     const ismhip_point_arrays* out, uint32_t* pt_offsets_h_out) {
+    if (!ctx || n_obj <= 0 || !pt_offsets_h || !in || !out || !pt_offsets_h_out || !in->x || !in->y || !in->z || !in->nx || !in->ny || !in->nz ||
+        !out->x || !out->y || !out->z || !out->nx || !out->ny || !out->nz || (in->rgba && !out->rgba))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "filter_normals: bad argument");
+    if (in->x == out->x || in->y == out->y || in->z == out->z || in->nx == out->nx || in->ny == out->ny || in->nz == out->nz || (in->rgba && in->rgba == out->rgba))
+        return ism_set_err(ctx, ISMHIP_ERR_INVALID, "filter_normals: the output arrays must not alias the inputs");
+    const uint32_t n = pt_offsets_h[n_obj];
+    uint32_t maxn = 0;
+    for (int o = 0; o < n_obj; ++o) {
+        if (pt_offsets_h[o + 1] < pt_offsets_h[o]) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "filter_normals: offsets not monotone");
+        maxn = std::max(maxn, pt_offsets_h[o + 1] - pt_offsets_h[o]);
+    }
+    pt_offsets_h_out[0] = 0;
+    if (n == 0) { for (int o = 0; o < n_obj; ++o) pt_offsets_h_out[o + 1] = 0; return ISMHIP_OK; }
+    uint32_t* po = ism_upload_offsets(ctx, SCR_KP_OFF, pt_offsets_h, n_obj + 1);
+    uint32_t* keep = (uint32_t*)ism_scratch(ctx, SCR_COMPACT_KEEP, (size_t)n * 4);
+    uint32_t* pos = (uint32_t*)ism_scratch(ctx, SCR_COMPACT_POS, (size_t)n * 4);
+    uint32_t* cnt = (uint32_t*)ism_scratch(ctx, SCR_OBJ_COUNT, (size_t)(2 * n_obj + 2) * 4);
+    if (!po || !keep || !pos || !cnt) return ISMHIP_ERR_NOMEM;
+    hipLaunchKernelGGL(k_keep_normals, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, in->nx, in->ny, in->nz, keep);
+    ISM_CHECK_LAUNCH(ctx, "k_keep_normals");
+    hipLaunchKernelGGL(k_scan_obj, dim3(n_obj), dim3(256), 0, ctx->stream, po, keep, pos, cnt);
+    ISM_CHECK_LAUNCH(ctx, "k_scan_obj");
+    std::vector<uint32_t> cnt_h(n_obj);
+    ISM_HIP(ctx, hipMemcpyAsync(cnt_h.data(), cnt, (size_t)n_obj * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int o = 0; o < n_obj; ++o) pt_offsets_h_out[o + 1] = pt_offsets_h_out[o] + cnt_h[o];
+    uint32_t* new_off = cnt + n_obj;
+    ISM_HIP(ctx, hipMemcpyAsync(new_off, pt_offsets_h_out, (size_t)(n_obj + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gather_points, dim3((maxn + 255) / 256, n_obj), dim3(256), 0, ctx->stream, po, new_off, keep, pos, *in, *out);
+    ISM_CHECK_LAUNCH(ctx, "k_gather_points");
+    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host copy of the offsets is pageable memory read by the H2D above
+    return ISMHIP_OK;
+}
+
 // ---- partial descriptors: Codebook::castVotes with UsePartialShot (codebook/codebook.cpp:416-475) keeps the histograms of a subset
 //      of the 32 SHOT signatures (getSignatureMask, :952-1036); on the device that is a column gather of the descriptor matrix.
 namespace {

@@ -21,7 +21,7 @@
 #include <numeric>
 #include <vector>
 
-int ism_knn_only_codebook(ismhip_ctx* ctx, int n_words, int dim, const float* words_d, ismhip_codebook** out);   // train.hip
+int ism_knn_only_codebook(ismhip_ctx* ctx, int n_words, int dim, const float* words_d, ismhip_codebook** out, bool light);   // train.hip
 
 namespace {
 
@@ -296,7 +296,7 @@ extern "C" int ismhip_kmeans(ismhip_ctx* ctx, int metric, int n, int dim, const 
     // ---- Lloyd
     auto assign = [&](int32_t* idx, float* dist) -> int {
         ismhip_codebook* cb = nullptr;
-        int rc = ism_knn_only_codebook(ctx, kc, dim, centers_out, &cb);
+        int rc = ism_knn_only_codebook(ctx, kc, dim, centers_out, &cb, true);      // rebuilt every iteration: no stage-1 image
         if (rc != ISMHIP_OK) return rc;
         rc = ismhip_knn(ctx, cb, metric, n, desc, 1, idx, dist);
         if (rc == ISMHIP_OK && hipStreamSynchronize(st) != hipSuccess) rc = ism_set_err(ctx, ISMHIP_ERR_HIP, "kmeans: sync");

@@ -280,15 +280,20 @@ __global__ void k_tr_stats3(const uint32_t* __restrict__ n_votes_p, const uint32
 }  // namespace
 
 // a codebook that only serves ismhip_knn: rows from a device matrix, one dummy vote per word
-int ism_knn_only_codebook(ismhip_ctx* ctx, int n_words, int dim, const float* words_d, ismhip_codebook** out) {
+// light: a short-lived codebook (one k-means iteration): no rotated stage-1 image (a host eigen-solve of ~1 s) and no chi-square shadow
+int ism_knn_only_codebook(ismhip_ctx* ctx, int n_words, int dim, const float* words_d, ismhip_codebook** out, bool light) {
     std::vector<float> words_h((size_t)n_words * dim);
     ISM_HIP(ctx, hipMemcpyAsync(words_h.data(), words_d, words_h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<uint32_t> ones((size_t)n_words + 1); std::iota(ones.begin(), ones.end(), 0u);
     std::vector<float> zxyz((size_t)n_words * 3, 0.f), sig1(1, 1.f);
     std::vector<uint32_t> zc((size_t)n_words, 0u);
-    return ismhip_codebook_create(ctx, n_words, dim, words_h.data(), nullptr, ones.data(), zxyz.data(), nullptr, nullptr, zc.data(), zc.data(), nullptr, nullptr,
-                                  1, sig1.data(), out);
+    const bool was = ctx->codebook_light;
+    ctx->codebook_light = light;
+    const int rc = ismhip_codebook_create(ctx, n_words, dim, words_h.data(), nullptr, ones.data(), zxyz.data(), nullptr, nullptr, zc.data(), zc.data(), nullptr, nullptr,
+                                          1, sig1.data(), out);
+    ctx->codebook_light = was;
+    return rc;
 }
 
 extern "C" int ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim, const float* desc, const float* lrf9,
@@ -315,7 +320,7 @@ extern "C" int ismhip_train_activate(ismhip_ctx* ctx, int metric, int n, int dim
     const int nw_in = n_codewords;
     // ---- step 1a: every feature activates its k nearest codewords (exact, ties -> lowest row)
     ismhip_codebook* cb = nullptr;
-    int rc = ism_knn_only_codebook(ctx, nw_in, dim, codewords, &cb);
+    int rc = ism_knn_only_codebook(ctx, nw_in, dim, codewords, &cb, false);
     if (rc != ISMHIP_OK) return rc;
     // scratch: activation list + CSR work arrays, carved from one slot (two passes: size, then pointers)
     unsigned long long* term3_key = nullptr; int32_t* act = nullptr; float* actd = nullptr;

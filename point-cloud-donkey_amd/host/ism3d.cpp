@@ -43,6 +43,7 @@ struct DevBuf {
         if (hipMalloc(&p, want) != hipSuccess) throw RuntimeException("hipMalloc failed");
         bytes = want;
     }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(bytes, o.bytes); }
     template <typename T> T* as() { return reinterpret_cast<T*>(p); }
     template <typename T> const T* as() const { return reinterpret_cast<const T*>(p); }
 };
@@ -60,6 +61,7 @@ public:
     int n_obj = 0;
     std::vector<uint32_t> pt_off, kp_off;
     DevBuf x, y, z, nx, ny, nz, rgba, kx, ky, kz, krgba;
+    DevBuf fx, fy, fz, fnx, fny, fnz, frgba;      // second set of point arrays: target of ismhip_filter_normals, swapped in afterwards
     ismhip_cloud* cloud = nullptr;
     bool has_color = false;
     // vote space of the current batch (Voting::m_votes)
@@ -125,18 +127,25 @@ public:
         h2d(x, hx); h2d(y, hy); h2d(z, hz); h2d(nx, hnx); h2d(ny, hny); h2d(nz, hnz);
         has_color = with_color;
         if (with_color) h2d(rgba, hrgba);
+        if (!dev_kp) {
+            h2d(kx, hkx); h2d(ky, hky); h2d(kz, hkz);
+            if (with_color) h2d(krgba, hkrgba);
+        }
+        finishBatch(dev_kp, cell, device_leaf);
+    }
+    // the point arrays of the batch are in HBM (x..rgba, pt_off): keypoints (device voxel grid when dev_kp) and the search surface
+    void finishBatch(bool dev_kp, float cell, float device_leaf) {
+        const bool with_color = has_color;
+        if (cloud) { ismhip_cloud_destroy(ctx, cloud); cloud = nullptr; }
         if (dev_kp) {
             // KeypointsVoxelGrid::iComputeKeypoints on the device: centroids stay in HBM, only the per-object counts come back
-            const size_t n_pts = hx.size();
+            const size_t n_pts = pt_off.back();
             kx.reserve(std::max<size_t>(n_pts, 1) * 4); ky.reserve(std::max<size_t>(n_pts, 1) * 4); kz.reserve(std::max<size_t>(n_pts, 1) * 4);
             if (with_color) krgba.reserve(std::max<size_t>(n_pts, 1) * 4);
             kp_off.assign((size_t)n_obj + 1, 0);
             check(ismhip_voxel_keypoints(ctx, n_obj, pt_off.data(), x.as<float>(), y.as<float>(), z.as<float>(), with_color ? rgba.as<uint32_t>() : nullptr,
                                          device_leaf, (uint32_t)n_pts, kx.as<float>(), ky.as<float>(), kz.as<float>(),
                                          with_color ? krgba.as<uint32_t>() : nullptr, kp_off.data()), "ismhip_voxel_keypoints");
-        } else {
-            h2d(kx, hkx); h2d(ky, hky); h2d(kz, hkz);
-            if (with_color) h2d(krgba, hkrgba);
         }
         check(ismhip_cloud_create(ctx, n_obj, pt_off.data(), x.as<float>(), y.as<float>(), z.as<float>(), nx.as<float>(), ny.as<float>(),
                                   nz.as<float>(), with_color ? rgba.as<uint32_t>() : nullptr, cell, &cloud), "ismhip_cloud_create");
@@ -1110,13 +1119,68 @@ std::shared_ptr<DeviceFeatures> ImplicitShapeModel::computeFeatures(const std::v
     // points whose normal is NaN (filterNormals :1034-1075); the features are computed on those completed copies
     std::vector<const PointCloud*> clouds = clouds_in;
     std::vector<std::unique_ptr<PointCloud>> completed;
+    const float cell = std::min(m_feature_descriptor->getRadius(), m_feature_descriptor->getType() == "FPFH" ? m_feature_descriptor->getRadius()
+                                                                                                           : m_feature_descriptor->getReferenceFrameRadius()) * 0.4f;
+    // VoxelGrid keypoints are taken on the device with the batch (ismhip_voxel_keypoints); any other detector, or
+    // ISM3D_HOST_KEYPOINTS=1, runs the host implementation per object and uploads its result
+    const auto* vg = dynamic_cast<const KeypointsVoxelGrid*>(m_keypoints_detector.get());
+    const char* host_kp = getenv("ISM3D_HOST_KEYPOINTS");
+    const bool dev_kp = vg && !(host_kp && host_kp[0] == '1');
+    auto estimate = [&]() {
+        if (m_consistent_normals_method == 2)
+            s.check(ismhip_estimate_normals(s.ctx, s.cloud, m_normal_radius, s.nx.as<float>(), s.ny.as<float>(), s.nz.as<float>()), "ismhip_estimate_normals");
+        else                                                // :969-1003
+            s.check(ismhip_estimate_normals_pca(s.ctx, s.cloud, m_normal_radius, m_consistent_normals_method, s.nx.as<float>(), s.ny.as<float>(), s.nz.as<float>()),
+                    "ismhip_estimate_normals_pca");
+    };
     {
         std::vector<size_t> need;
         for (size_t i = 0; i < clouds.size(); ++i) if (!firstNormalValid(*clouds[i])) need.push_back(i);
+        if (!need.empty() && (m_consistent_normals_method < 0 || m_consistent_normals_method > 2))
+            throw RuntimeException("input cloud has no normals and ConsistentNormalsMethod " + std::to_string(m_consistent_normals_method) +
+                                   " is not built (built: 0 = PCA towards the origin, 1 = PCA away from the centroid, 2 = SHOT reference frames)");
+        const char* host_nf = getenv("ISM3D_HOST_NORMAL_FILTER");
+        if (need.size() == clouds.size() && dev_kp && !(host_nf && host_nf[0] == '1')) {
+            // every cloud of the batch needs normals and the keypoints are taken on the device: the points are uploaded once (with
+            // their colours), the normals are estimated, the NaN ones leave (ismhip_filter_normals) and the search surface of the
+            // descriptor stage is built over the compacted arrays -- nothing returns to the host in between
+            std::vector<std::unique_ptr<PointCloud>> tmp;
+            std::vector<const PointCloud*> part;
+            for (const PointCloud* src : clouds) {
+                tmp.emplace_back(new PointCloud(*src));
+                PointCloud& c = *tmp.back();
+                c.nx.assign(c.size(), 0.f); c.ny.assign(c.size(), 0.f); c.nz.assign(c.size(), 0.f);
+                part.push_back(&c);
+            }
+            const std::vector<KeypointSet> none(part.size());
+            const bool with_color = m_feature_descriptor->needsColor();
+            s.uploadBatch(part, &none, m_normal_radius * 0.5f, with_color);
+            estimate();
+            const size_t n_all = std::max<size_t>(s.pt_off.back(), 1);
+            DevBuf* dst[7] = {&s.fx, &s.fy, &s.fz, &s.fnx, &s.fny, &s.fnz, &s.frgba};
+            for (int a = 0; a < 7; ++a) if (a < 6 || with_color) dst[a]->reserve(n_all * 4);
+            const ismhip_point_arrays in = {s.x.as<float>(), s.y.as<float>(), s.z.as<float>(), s.nx.as<float>(), s.ny.as<float>(), s.nz.as<float>(),
+                                            with_color ? s.rgba.as<uint32_t>() : nullptr};
+            const ismhip_point_arrays out = {s.fx.as<float>(), s.fy.as<float>(), s.fz.as<float>(), s.fnx.as<float>(), s.fny.as<float>(), s.fnz.as<float>(),
+                                             with_color ? s.frgba.as<uint32_t>() : nullptr};
+            std::vector<uint32_t> new_off(s.pt_off.size());
+            s.check(ismhip_filter_normals(s.ctx, s.n_obj, s.pt_off.data(), &in, &out, new_off.data()), "ismhip_filter_normals");
+            s.x.swap(s.fx); s.y.swap(s.fy); s.z.swap(s.fz); s.nx.swap(s.fnx); s.ny.swap(s.fny); s.nz.swap(s.fnz);
+            if (with_color) s.rgba.swap(s.frgba);
+            s.pt_off = new_off;
+            auto t1 = std::chrono::steady_clock::now();
+            m_processing_times["normals"] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+            s.finishBatch(true, cell, vg->getLeafSize());
+            auto t2 = std::chrono::steady_clock::now();
+            m_processing_times["keypoints"] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+            auto f = (*m_feature_descriptor)(s);
+            s.sync();
+            m_processing_times["features"] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
+            return f;
+        }
         if (!need.empty()) {
-            if (m_consistent_normals_method < 0 || m_consistent_normals_method > 2)
-                throw RuntimeException("input cloud has no normals and ConsistentNormalsMethod " + std::to_string(m_consistent_normals_method) +
-                                       " is not built (built: 0 = PCA towards the origin, 1 = PCA away from the centroid, 2 = SHOT reference frames)");
+            // mixed batches and host-side keypoint detectors: the estimated normals come back, the filter runs here and the completed
+            // copies are uploaded with the rest
             std::vector<std::unique_ptr<PointCloud>> tmp;
             std::vector<const PointCloud*> part;
             for (size_t i : need) {
@@ -1127,11 +1191,7 @@ std::shared_ptr<DeviceFeatures> ImplicitShapeModel::computeFeatures(const std::v
             }
             const std::vector<KeypointSet> none(part.size());
             s.uploadBatch(part, &none, m_normal_radius * 0.5f, false);
-            if (m_consistent_normals_method == 2)
-                s.check(ismhip_estimate_normals(s.ctx, s.cloud, m_normal_radius, s.nx.as<float>(), s.ny.as<float>(), s.nz.as<float>()), "ismhip_estimate_normals");
-            else                                                // :969-1003
-                s.check(ismhip_estimate_normals_pca(s.ctx, s.cloud, m_normal_radius, m_consistent_normals_method, s.nx.as<float>(), s.ny.as<float>(), s.nz.as<float>()),
-                        "ismhip_estimate_normals_pca");
+            estimate();
             std::vector<float> hnx, hny, hnz;
             const size_t n_all = s.pt_off.back();
             s.d2h(hnx, s.nx, n_all); s.d2h(hny, s.ny, n_all); s.d2h(hnz, s.nz, n_all);
@@ -1152,14 +1212,8 @@ std::shared_ptr<DeviceFeatures> ImplicitShapeModel::computeFeatures(const std::v
             }
         }
     }
-    const float cell = std::min(m_feature_descriptor->getRadius(), m_feature_descriptor->getType() == "FPFH" ? m_feature_descriptor->getRadius()
-                                                                                                           : m_feature_descriptor->getReferenceFrameRadius()) * 0.4f;
-    // VoxelGrid keypoints are taken on the device with the batch (ismhip_voxel_keypoints); any other detector, or
-    // ISM3D_HOST_KEYPOINTS=1, runs the host implementation per object and uploads its result
-    const auto* vg = dynamic_cast<const KeypointsVoxelGrid*>(m_keypoints_detector.get());
-    const char* host_kp = getenv("ISM3D_HOST_KEYPOINTS");
     auto t1 = t0;
-    if (vg && !(host_kp && host_kp[0] == '1')) {
+    if (dev_kp) {
         s.uploadBatch(clouds, nullptr, cell, m_feature_descriptor->needsColor(), vg->getLeafSize());
         t1 = std::chrono::steady_clock::now();
     } else {

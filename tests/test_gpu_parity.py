@@ -192,6 +192,39 @@ def test_compact_features(pkg, gpu):
     np.testing.assert_array_equal(y.cpu().numpy(), kp[good, 1])
 
 
+def test_filter_normals_on_the_device(pkg, gpu):
+    """ImplicitShapeModel::filterNormals (implicit_shape_model.cpp:1034-1075): points whose normal holds a NaN in ANY component leave
+    their cloud, order kept; empty objects, an object that loses everything and objects longer than one scan block are covered."""
+    import torch
+    ctx, dev = gpu
+    rng = np.random.default_rng(11)
+    off = np.array([0, 700, 700, 705, 1500], np.uint32)
+    n = int(off[-1])
+    a = rng.random((n, 6)).astype(np.float32)
+    rgba = rng.integers(0, 1 << 24, n).astype(np.int32)
+    bad = rng.random(n) < 0.2
+    bad[700:705] = True                                  # the third object loses every point
+    comp = rng.integers(3, 6, n)
+    a[bad, comp[bad]] = np.nan
+    for with_rgba in (True, False):
+        cols = [T(np.ascontiguousarray(a[:, j]), dev) for j in range(6)]
+        got = pkg.capi.filter_normals(ctx, off, *cols, rgba=T(rgba, dev) if with_rgba else None)
+        keep = ~bad
+        want_off = [0] + [int(keep[:e].sum()) for e in off[1:]]
+        assert got[0].tolist() == want_off
+        for j in range(6):
+            np.testing.assert_array_equal(got[1 + j].cpu().numpy(), a[keep, j])
+        if with_rgba:
+            np.testing.assert_array_equal(got[7].cpu().numpy(), rgba[keep])
+        else:
+            assert got[7] is None
+    with pytest.raises(pkg.capi.IsmHipError, match="must not alias"):
+        x = T(np.ascontiguousarray(a[:, 0]), dev)
+        arr = pkg.capi._PointArrays(*([x.data_ptr()] * 6), None)
+        new = np.zeros(len(off), np.uint32)
+        ctx.check(pkg.capi.lib().ismhip_filter_normals(ctx._h, 4, pkg.capi._p(off), __import__("ctypes").byref(arr), __import__("ctypes").byref(arr), pkg.capi._p(new)), "ismhip_filter_normals")
+
+
 # ------------------------------------------------------------------------------------------------ kNN
 def _cb(pkg, gpu, words, n_classes=4, votes_per_word=1, seed=0):
     rng = np.random.default_rng(seed)

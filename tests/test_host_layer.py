@@ -494,7 +494,7 @@ def test_host_kmeans_clustering_matches_python_harness(pkg, gpu, tmp_path):
 
 
 @pytest.mark.gpu
-def test_host_clouds_without_normals_get_them_on_the_device(pkg, gpu):
+def test_host_clouds_without_normals_get_them_on_the_device(pkg, gpu, monkeypatch):
     """Inputs whose first normal is zero/NaN count as normal-less (implicit_shape_model.cpp:615-625): the host layer then estimates
     normals on the device (ConsistentNormalsMethod 2: inverted z axis of a SHOT frame with NormalRadius at every point), drops points
     with NaN normals and carries on. Trained and tested without a single input normal, the synthetic objects must still be told apart."""
@@ -510,6 +510,26 @@ def test_host_clouds_without_normals_get_them_on_the_device(pkg, gpu):
     nb = test.batch(range(6))
     got = m.detect_batch(nb["pt_off"], nb["xyz"], np.zeros_like(nb["normals"]), max_maxima=4)
     assert (got["cls"][:, 0] == nb["labels"]).all()
+    # the batch above never left HBM between normal estimation and description (ismhip_filter_normals); the host-side filter
+    # (mixed batches, host keypoint detectors) must give the same maxima
+    monkeypatch.setenv("ISM3D_HOST_NORMAL_FILTER", "1")
+    via_host = m.detect_batch(nb["pt_off"], nb["xyz"], np.zeros_like(nb["normals"]), max_maxima=4)
+    monkeypatch.delenv("ISM3D_HOST_NORMAL_FILTER")
+    for k in ("cls", "weight", "pos"):
+        if k in got:
+            np.testing.assert_array_equal(got[k], via_host[k])
+    # a sparse tail of isolated points: their frames are invalid (< 5 neighbours), their normals NaN, and they leave the cloud on the device
+    xyz2 = nb["xyz"].copy()
+    first = int(nb["pt_off"][1])
+    xyz2[first - 3:first] += np.array([[40, 0, 0], [0, 55, 0], [0, 0, 70]], np.float32)
+    got2 = m.detect_batch(nb["pt_off"], xyz2, np.zeros_like(nb["normals"]), max_maxima=4)
+    monkeypatch.setenv("ISM3D_HOST_NORMAL_FILTER", "1")
+    via_host2 = m.detect_batch(nb["pt_off"], xyz2, np.zeros_like(nb["normals"]), max_maxima=4)
+    monkeypatch.delenv("ISM3D_HOST_NORMAL_FILTER")
+    for k in ("cls", "weight", "pos"):
+        if k in got2:
+            np.testing.assert_array_equal(got2[k], via_host2[k])
+    assert (got2["cls"][:, 0] == nb["labels"]).all()
     m.config_from_json(_cfg(**{"Parameters/NormalRadius": 0.15, "Parameters/ConsistentNormalsMethod": 7}))
     with pytest.raises(hb.HostError, match="ConsistentNormalsMethod 7 is not built"):
         m.detect_batch(nb["pt_off"], nb["xyz"], np.zeros_like(nb["normals"]), max_maxima=4)
