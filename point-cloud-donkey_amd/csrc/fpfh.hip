@@ -23,7 +23,7 @@ struct FpfhArgs {
     float* spfh;        // [n_pts*33]
     float* desc; uint32_t* count;
     uint32_t max_pts;
-    int n_obj, nbx_kp, nbx_pt;   // XCD-local block map (common.h): an object's SPFH rows (2.2 MB at 16384 points) stay in ONE L2
+    int n_obj, nbx_kp;           // XCD-local block map (common.h) of k_fpfh_mark / k_fpfh_sum: an object's SPFH rows (2.2 MB at 16384 points) stay in ONE L2
     int dbg;            // env ISMHIP_FPFH_DBG (timing experiments, results invalid): 1 = k_spfh without the pair features, 2 = every pair by the exact arithmetic, 3 = fast arithmetic only (A/B runs: 21.1 / 21.1 / 23.0 ms per 128 objects -- the pair arithmetic is not what bounds k_spfh)
 };
 
@@ -159,12 +159,11 @@ __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
     __shared__ WaveRows s_rows[4];
     __shared__ float4 s_queue[4][128];      // queued neighbours: x, y, z, sorted index (bits)
     __shared__ float4 s_queue_n[4][128];    //                    their normals
-    int o, bx;
-    if (!xcd_object_block(a.nbx_pt, a.n_obj, o, bx)) return;
+    const int o = blockIdx.y;      // plain object-major order: the XCD-local map made this kernel 6 % SLOWER (A/B on one box, 823 objects: 127.0 vs 119.9 ms)
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const uint32_t base = a.pt_off[o];
     const uint32_t n = a.pt_off[o + 1] - base;
-    const uint32_t p = bx * 4 + wv;
+    const uint32_t p = blockIdx.x * 4 + wv;
     if (p >= n || !a.flag[base + p]) return;
     const float4 pp = a.sp4[base + p], pn = a.sn4[base + p];
     const float px = pp.x, py = pp.y, pz = pp.z;
@@ -347,13 +346,13 @@ extern "C" int ismhip_fpfh33(ismhip_ctx* ctx, const ismhip_cloud* cloud, const u
     TimerScope ts(ctx, "fpfh33");
     ISM_HIP(ctx, hipMemsetAsync(flag, 0, np, ctx->stream));
     // measured round 3 (configs[4], 823 objects per launch, plain (blocks, objects) grid): k_fpfh_sum pulled 74.8 GB per launch from
-    // beyond the L2s for 1.8 GB of SPFH rows -- every object's rows were wanted by all eight XCDs at once
-    a.n_obj = ctx->xcd_map ? n_obj : 0; a.nbx_kp = (int)((maxk + 3) / 4); a.nbx_pt = (int)((cloud->max_pts + 3) / 4);
+    // beyond the L2s for 1.8 GB of SPFH rows -- every object's rows were wanted by all eight XCDs at once. A/B on one box:
+    // k_fpfh_sum 23.4 -> 21.0 ms with the XCD-local map
+    a.n_obj = ctx->xcd_map ? n_obj : 0; a.nbx_kp = (int)((maxk + 3) / 4);
     const unsigned g_kp = ctx->xcd_map ? xcd_object_grid((unsigned)a.nbx_kp, n_obj) : (unsigned)a.nbx_kp * (unsigned)n_obj;
-    const unsigned g_pt = ctx->xcd_map ? xcd_object_grid((unsigned)a.nbx_pt, n_obj) : (unsigned)a.nbx_pt * (unsigned)n_obj;
     hipLaunchKernelGGL(k_fpfh_mark, dim3(g_kp), dim3(256), 0, ctx->stream, a);
     ISM_CHECK_LAUNCH(ctx, "k_fpfh_mark");
-    hipLaunchKernelGGL(k_spfh, dim3(g_pt), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_spfh, dim3((cloud->max_pts + 3) / 4, n_obj), dim3(256), 0, ctx->stream, a);
     ISM_CHECK_LAUNCH(ctx, "k_spfh");
     hipLaunchKernelGGL(k_fpfh_sum, dim3(g_kp), dim3(256), 0, ctx->stream, a);
     ISM_CHECK_LAUNCH(ctx, "k_fpfh_sum");
