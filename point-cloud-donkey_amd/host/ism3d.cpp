@@ -1136,6 +1136,12 @@ std::shared_ptr<DeviceFeatures> ImplicitShapeModel::computeFeatures(const std::v
     {
         std::vector<size_t> need;
         for (size_t i = 0; i < clouds.size(); ++i) if (!firstNormalValid(*clouds[i])) need.push_back(i);
+        for (size_t i : need)
+            if (clouds[i]->organized) {       // computeNormals :948-966 (pcl::IntegralImageNormalEstimation, AVERAGE_3D_GRADIENT) is not built
+                LOG_WARN("organized input cloud without normals: the reference estimates them from the depth image (IntegralImageNormalEstimation); "
+                         "here ConsistentNormalsMethod " << m_consistent_normals_method << " is used as for unorganized clouds -- the normals differ");
+                break;
+            }
         if (!need.empty() && (m_consistent_normals_method < 0 || m_consistent_normals_method > 2))
             throw RuntimeException("input cloud has no normals and ConsistentNormalsMethod " + std::to_string(m_consistent_normals_method) +
                                    " is not built (built: 0 = PCA towards the origin, 1 = PCA away from the centroid, 2 = SHOT reference frames)");

@@ -130,6 +130,7 @@ void JSONObject::addParameter(T& param, std::string name, T defaultValue) { m_pa
 struct PointCloud {          // NaN-free surface with normals (PointXYZRGBNormal split into SoA)
     std::vector<float> x, y, z, nx, ny, nz;
     std::vector<uint32_t> rgba;         // 0x00RRGGBB, empty when the cloud has no colour
+    bool organized = false;             // the file was a dense HEIGHT > 1 image: pcl::PointCloud::isOrganized() survives removeNaNFromPointCloud
     size_t size() const { return x.size(); }
     bool empty() const { return x.empty(); }
 };

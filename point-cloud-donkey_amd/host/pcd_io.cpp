@@ -54,7 +54,7 @@ std::shared_ptr<PointCloud> ImplicitShapeModel::loadPointCloud(const std::string
     std::ifstream in(file, std::ios::binary);
     if (!in) { std::cerr << "ERROR: could not load point cloud: " << file << std::endl; return nullptr; }
     std::vector<Field> fields;
-    size_t points = 0; std::string data;
+    size_t points = 0, height = 1; std::string data;
     std::string line;
     while (std::getline(in, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -67,6 +67,7 @@ std::shared_ptr<PointCloud> ImplicitShapeModel::loadPointCloud(const std::string
         else if (key == "COUNT") { for (auto& f : fields) ls >> f.count; }
         else if (key == "POINTS") ls >> points;
         else if (key == "WIDTH" && points == 0) { size_t w; ls >> w; points = w; }
+        else if (key == "HEIGHT") ls >> height;
         else if (key == "DATA") { ls >> data; break; }
     }
     if (fields.empty() || data.empty()) { std::cerr << "ERROR: malformed PCD header: " << file << std::endl; return nullptr; }
@@ -140,6 +141,8 @@ std::shared_ptr<PointCloud> ImplicitShapeModel::loadPointCloud(const std::string
             push(v, rgb);
         }
     } else { std::cerr << "ERROR: PCD DATA \"" << data << "\" is not built (ascii, binary, binary_compressed): " << file << std::endl; return nullptr; }
+    // pcl::removeNaNFromPointCloud keeps width x height only when nothing had to go: such a cloud stays "organized" in the reference
+    cloud->organized = height > 1 && cloud->size() == points;
     return cloud;
 }
 

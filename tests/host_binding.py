@@ -214,13 +214,14 @@ def write_pcd_compressed(path, xyz, normals, rgba=None):
         f.write(hdr.encode()); f.write(struct.pack("<II", len(comp), len(plain))); f.write(comp)
 
 
-def write_pcd(path, xyz, normals, rgba=None, binary=False):
+def write_pcd(path, xyz, normals, rgba=None, binary=False, height=1):
     n = len(xyz)
+    assert n % height == 0
     fields = ["x", "y", "z"] + (["rgb"] if rgba is not None else []) + ["normal_x", "normal_y", "normal_z", "curvature"]
     types = ["F", "F", "F"] + (["U"] if rgba is not None else []) + ["F", "F", "F", "F"]
-    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\nWIDTH %d\nHEIGHT 1\n"
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\nWIDTH %d\nHEIGHT %d\n"
            "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n") % (" ".join(fields), " ".join(["4"] * len(fields)), " ".join(types),
-                                                              " ".join(["1"] * len(fields)), n, n, "binary" if binary else "ascii")
+                                                              " ".join(["1"] * len(fields)), n // height, height, n, "binary" if binary else "ascii")
     with open(path, "wb") as f:
         f.write(hdr.encode())
         if binary:

@@ -545,6 +545,43 @@ def test_host_clouds_without_normals_get_them_on_the_device(pkg, gpu, monkeypatc
 
 
 @pytest.mark.gpu
+def test_host_detect_file_decides_normals_from_the_first_point(pkg, gpu, tmp_path, capfd):
+    """ImplicitShapeModel::detect(filename) (implicit_shape_model.cpp:556-573, 615-625): the cloud "has normals" when its FIRST point
+    carries one; otherwise they are estimated (on the device). A dense HEIGHT > 1 file stays organized in the reference, which then
+    takes IntegralImageNormalEstimation -- not built here: the unorganized method runs and says so."""
+    train, test = _dataset(pkg, 3, 9, 3)
+    order = sorted(range(9), key=lambda i: (train.label(i), i))
+    m = hb.Model()
+    m.config_from_json(_cfg(**{"Parameters/NormalRadius": 0.15}))
+    for i in order:
+        o = train.get(i)
+        m.add_training(o["xyz"], o["normals"], o["label"], i)
+    m.train()
+    for i in range(3):
+        o = test.get(i)
+        n = len(o["xyz"]) // 2 * 2
+        xyz, nrm = o["xyz"][:n], o["normals"][:n]
+        off = np.array([0, n], np.uint32)
+        with_n = str(tmp_path / f"with_{i}.pcd"); hb.write_pcd(with_n, xyz, nrm, binary=True)
+        cls, w = m.detect_file(with_n)
+        ref = m.detect_batch(off, xyz, nrm, max_maxima=4)
+        assert cls == o["label"] == ref["cls"][0, 0] and w == ref["weight"][0, 0]
+        # first normal zero -> every normal of the file is ignored and estimated again, exactly as for an all-zero input
+        first0 = nrm.copy(); first0[0] = 0
+        no_n = str(tmp_path / f"first0_{i}.pcd"); hb.write_pcd(no_n, xyz, first0, binary=True)
+        cls0, w0 = m.detect_file(no_n)
+        ref0 = m.detect_batch(off, xyz, np.zeros_like(nrm), max_maxima=4)
+        assert cls0 == ref0["cls"][0, 0] and w0 == ref0["weight"][0, 0]
+        capfd.readouterr()
+        org = str(tmp_path / f"organized_{i}.pcd"); hb.write_pcd(org, xyz, np.zeros_like(nrm), binary=True, height=2)
+        cls1, w1 = m.detect_file(org)
+        assert (cls1, w1) == (cls0, w0)
+        assert "organized input cloud without normals" in capfd.readouterr().out
+        m.detect_file(no_n)
+        assert "organized input cloud" not in capfd.readouterr().out
+
+
+@pytest.mark.gpu
 def test_eval_tool_end_to_end(pkg, tmp_path):
     train, test = _dataset(pkg, 3, 6, 6)
     names = ["chair", "table", "lamp"]
