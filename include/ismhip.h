@@ -171,6 +171,17 @@ int  ismhip_compact_features(ismhip_ctx* ctx, int n_obj, const uint32_t* kp_offs
                              float* kpx_out, float* kpy_out, float* kpz_out,
                              uint32_t* src_index_out, uint32_t* keep_offsets_h_out);
 
+/* The same filter for descriptor matrices written by ismhip_shot352 / ismhip_cshot1344 / ismhip_fpfh33, whose rows are NaN AS A WHOLE
+ * (invalid frame, empty neighbourhood, zero norm): one element per row is tested instead of the matrix, and when nothing is dropped
+ * *all_kept_out = 1, the *_out arrays are NOT written (the caller goes on with its input arrays; src_index_out, if given, is 0..nkp-1)
+ * and keep_offsets_h_out = kp_offsets_h. Otherwise exactly as ismhip_compact_features. */
+int  ismhip_compact_descriptor_rows(ismhip_ctx* ctx, int n_obj, const uint32_t* kp_offsets_h, int dim,
+                                    const float* desc, const float* lrf9,
+                                    const float* kpx, const float* kpy, const float* kpz,
+                                    float* desc_out, float* lrf9_out,
+                                    float* kpx_out, float* kpy_out, float* kpz_out,
+                                    uint32_t* src_index_out, uint32_t* keep_offsets_h_out, int* all_kept_out);
+
 /* ---- partial descriptors: Codebook::castVotes with UsePartialShot (codebook/codebook.cpp:416-475, mask :952-1036) keeps the
  *      histograms of some of the 32 SHOT signatures: dst[n_rows * n_cols] = src[:, cols_h] (cols_h host, ascending). */
 int  ismhip_gather_columns(ismhip_ctx* ctx, int n_rows, int dim_in, const float* src, int n_cols, const int32_t* cols_h, float* dst);

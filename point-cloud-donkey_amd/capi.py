@@ -25,7 +25,7 @@ EXPORTS = [
     "ismhip_timers_enable", "ismhip_timers_reset", "ismhip_timer_get",
     "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids", "ismhip_cloud_radii", "ismhip_estimate_normals", "ismhip_estimate_normals_pca",
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
-    "ismhip_compact_features", "ismhip_filter_normals", "ismhip_voxel_keypoints", "ismhip_gather_columns",
+    "ismhip_compact_features", "ismhip_compact_descriptor_rows", "ismhip_filter_normals", "ismhip_voxel_keypoints", "ismhip_gather_columns",
     "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word", "ismhip_codebook_stage1_dims",
     "ismhip_knn", "ismhip_knn_ratio", "ismhip_knn_rule", "ismhip_cast_votes", "ismhip_find_maxima", "ismhip_hough3d_maxima", "ismhip_train_activate", "ismhip_kmeans",
 ]
@@ -318,6 +318,28 @@ def voxel_keypoints(ctx, pt_offsets, x, y, z, leaf, rgba=None):
                                            _p(kx), _p(ky), _p(kz), _p(kc), _p(ko)), "ismhip_voxel_keypoints")
     m = int(ko[-1])
     return ko, kx[:m], ky[:m], kz[:m], (kc[:m] if kc is not None else None)
+
+
+def compact_descriptor_rows(ctx, kp_offsets, desc, lrf, kpx, kpy, kpz):
+    """compact_features for descriptor matrices of this library (rows are NaN as a whole): when nothing is dropped the INPUT tensors are
+    returned, no copy is made"""
+    torch = _torch()
+    ko = _u32(kp_offsets)
+    n_obj = len(ko) - 1
+    n, dim = desc.shape
+    d_o = torch.empty_like(desc)
+    l_o = torch.empty_like(lrf) if lrf is not None else None
+    x_o, y_o, z_o = torch.empty_like(kpx), torch.empty_like(kpy), torch.empty_like(kpz)
+    src = torch.empty((n,), dtype=torch.int32, device=desc.device)
+    keep = np.zeros(n_obj + 1, dtype=np.uint32)
+    all_kept = C.c_int(0)
+    ctx.check(lib().ismhip_compact_descriptor_rows(ctx._h, C.c_int(n_obj), _p(ko), C.c_int(dim), _p(desc), _p(lrf), _p(kpx), _p(kpy), _p(kpz),
+                                                   _p(d_o), _p(l_o), _p(x_o), _p(y_o), _p(z_o), _p(src), _p(keep), C.byref(all_kept)),
+              "ismhip_compact_descriptor_rows")
+    if all_kept.value:
+        return keep, desc, lrf, kpx, kpy, kpz, src
+    m = int(keep[-1])
+    return keep, d_o[:m], (l_o[:m] if l_o is not None else None), x_o[:m], y_o[:m], z_o[:m], src[:m]
 
 
 def compact_features(ctx, kp_offsets, desc, lrf, kpx, kpy, kpz):

@@ -22,6 +22,20 @@ __global__ __launch_bounds__(256) void k_keep(int nkp, int dim, const float* __r
     if (lane == 0) keep[k] = m == 0ull ? 1u : 0u;
 }
 
+// the same decision from ONE element per row: rows that are NaN as a whole (what shot.hip / fpfh.hip write for an invalid frame, an
+// empty neighbourhood or a zero norm) -- the 1.3 GB descriptor matrix of a 908-object batch is not read again just to be tested
+__global__ void k_keep_rows(int nkp, int dim, const float* __restrict__ desc, const float* __restrict__ lrf, uint32_t* __restrict__ keep) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nkp) return;
+    bool bad = isnan(desc[(size_t)k * dim]);
+    if (lrf) bad |= !isfinite(lrf[(size_t)k * 9]) || !isfinite(lrf[(size_t)k * 9 + 3]) || !isfinite(lrf[(size_t)k * 9 + 6]);
+    keep[k] = bad ? 0u : 1u;
+}
+__global__ void k_iota(uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
 // one block per object: exclusive scan of keep[] over the object's rows -> dst position inside the object, count per object
 __global__ __launch_bounds__(256) void k_scan_obj(const uint32_t* __restrict__ kp_off, const uint32_t* __restrict__ keep,
                                                   uint32_t* __restrict__ pos, uint32_t* __restrict__ obj_count) {
@@ -70,12 +84,13 @@ __global__ __launch_bounds__(256) void k_gather(const uint32_t* __restrict__ kp_
 
 }  // namespace
 
-extern "C" int ismhip_compact_features(ismhip_ctx* ctx, int n_obj, const uint32_t* kp_offsets_h, int dim,
-                                       const float* desc, const float* lrf9,
-                                       const float* kpx, const float* kpy, const float* kpz,
-                                       float* desc_out, float* lrf9_out,
-                                       float* kpx_out, float* kpy_out, float* kpz_out,
-                                       uint32_t* src_index_out, uint32_t* keep_offsets_h_out) {
+static int compact_features(ismhip_ctx* ctx, int n_obj, const uint32_t* kp_offsets_h, int dim,
+                            const float* desc, const float* lrf9,
+                            const float* kpx, const float* kpy, const float* kpz,
+                            float* desc_out, float* lrf9_out,
+                            float* kpx_out, float* kpy_out, float* kpz_out,
+                            uint32_t* src_index_out, uint32_t* keep_offsets_h_out, bool whole_rows, int* all_kept_out) {
+    if (all_kept_out) *all_kept_out = 0;
     if (!ctx || n_obj <= 0 || !kp_offsets_h || dim <= 0 || !desc || !kpx || !kpy || !kpz || !desc_out || !kpx_out || !kpy_out ||
         !kpz_out || !keep_offsets_h_out)
         return ism_set_err(ctx, ISMHIP_ERR_INVALID, "compact_features: bad argument");
@@ -92,7 +107,8 @@ extern "C" int ismhip_compact_features(ismhip_ctx* ctx, int n_obj, const uint32_
     uint32_t* pos = (uint32_t*)ism_scratch(ctx, SCR_COMPACT_POS, (size_t)nkp * 4);
     uint32_t* cnt = (uint32_t*)ism_scratch(ctx, SCR_OBJ_COUNT, (size_t)(2 * n_obj + 2) * 4);
     if (!ko || !keep || !pos || !cnt) return ISMHIP_ERR_NOMEM;
-    hipLaunchKernelGGL(k_keep, dim3((nkp + 3) / 4), dim3(256), 0, ctx->stream, (int)nkp, dim, desc, lrf9, keep);
+    if (whole_rows) hipLaunchKernelGGL(k_keep_rows, dim3((nkp + 255) / 256), dim3(256), 0, ctx->stream, (int)nkp, dim, desc, lrf9, keep);
+    else hipLaunchKernelGGL(k_keep, dim3((nkp + 3) / 4), dim3(256), 0, ctx->stream, (int)nkp, dim, desc, lrf9, keep);
     ISM_CHECK_LAUNCH(ctx, "k_keep");
     hipLaunchKernelGGL(k_scan_obj, dim3(n_obj), dim3(256), 0, ctx->stream, ko, keep, pos, cnt);
     ISM_CHECK_LAUNCH(ctx, "k_scan_obj");
@@ -100,6 +116,15 @@ extern "C" int ismhip_compact_features(ismhip_ctx* ctx, int n_obj, const uint32_
     ISM_HIP(ctx, hipMemcpyAsync(cnt_h.data(), cnt, (size_t)n_obj * 4, hipMemcpyDeviceToHost, ctx->stream));
     ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int o = 0; o < n_obj; ++o) keep_offsets_h_out[o + 1] = keep_offsets_h_out[o] + cnt_h[o];
+    if (all_kept_out && keep_offsets_h_out[n_obj] == nkp) {
+        // nothing to drop: the caller keeps using its input arrays (no 2.6 GB copy of the descriptor matrix onto itself)
+        *all_kept_out = 1;
+        if (src_index_out) {
+            hipLaunchKernelGGL(k_iota, dim3((nkp + 255) / 256), dim3(256), 0, ctx->stream, nkp, src_index_out);
+            ISM_CHECK_LAUNCH(ctx, "k_iota");
+        }
+        return ISMHIP_OK;
+    }
     uint32_t* new_off = cnt + n_obj;
     ISM_HIP(ctx, hipMemcpyAsync(new_off, keep_offsets_h_out, (size_t)(n_obj + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_gather, dim3((maxk + 3) / 4, n_obj), dim3(256), 0, ctx->stream, ko, new_off, keep, pos, dim, desc, lrf9,
@@ -109,6 +134,25 @@ extern "C" int ismhip_compact_features(ismhip_ctx* ctx, int n_obj, const uint32_
     return ISMHIP_OK;
 }
 
+extern "C" int ismhip_compact_features(ismhip_ctx* ctx, int n_obj, const uint32_t* kp_offsets_h, int dim,
+                                       const float* desc, const float* lrf9,
+                                       const float* kpx, const float* kpy, const float* kpz,
+                                       float* desc_out, float* lrf9_out,
+                                       float* kpx_out, float* kpy_out, float* kpz_out,
+                                       uint32_t* src_index_out, uint32_t* keep_offsets_h_out) {
+    return compact_features(ctx, n_obj, kp_offsets_h, dim, desc, lrf9, kpx, kpy, kpz, desc_out, lrf9_out, kpx_out, kpy_out, kpz_out, src_index_out,
+                            keep_offsets_h_out, false, nullptr);
+}
+extern "C" int ismhip_compact_descriptor_rows(ismhip_ctx* ctx, int n_obj, const uint32_t* kp_offsets_h, int dim,
+                                              const float* desc, const float* lrf9,
+                                              const float* kpx, const float* kpy, const float* kpz,
+                                              float* desc_out, float* lrf9_out,
+                                              float* kpx_out, float* kpy_out, float* kpz_out,
+                                              uint32_t* src_index_out, uint32_t* keep_offsets_h_out, int* all_kept_out) {
+    if (!all_kept_out) return ism_set_err(ctx, ISMHIP_ERR_INVALID, "compact_descriptor_rows: all_kept_out is NULL");
+    return compact_features(ctx, n_obj, kp_offsets_h, dim, desc, lrf9, kpx, kpy, kpz, desc_out, lrf9_out, kpx_out, kpy_out, kpz_out, src_index_out,
+                            keep_offsets_h_out, true, all_kept_out);
+}
 
 // ---- ImplicitShapeModel::filterNormals (implicit_shape_model.cpp:1034-1075): the points whose estimated normal holds a NaN leave the
 //      cloud, order kept. The arrays stay in HBM: flag, per-object scan (k_scan_obj), gather into the output arrays.

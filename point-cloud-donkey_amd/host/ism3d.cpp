@@ -295,9 +295,20 @@ std::shared_ptr<DeviceFeatures> Features::operator()(DeviceSession& s) const {  
     // invalid frames and NaN descriptors are dropped, order preserved (features.cpp:66-76, implicit_shape_model.cpp:1276-1308)
     f->desc.reserve((size_t)nkp * D * 4); f->lrf.reserve((size_t)nkp * 9 * 4);
     f->kx.reserve((size_t)nkp * 4); f->ky.reserve((size_t)nkp * 4); f->kz.reserve((size_t)nkp * 4); f->src.reserve((size_t)nkp * 4);
-    s.check(ismhip_compact_features(s.ctx, s.n_obj, s.kp_off.data(), D, s.raw_desc.as<float>(), s.raw_lrf.as<float>(), s.kx.as<float>(),
-                                    s.ky.as<float>(), s.kz.as<float>(), f->desc.as<float>(), f->lrf.as<float>(), f->kx.as<float>(),
-                                    f->ky.as<float>(), f->kz.as<float>(), f->src.as<uint32_t>(), f->off.data()), "ismhip_compact_features");
+    int all_kept = 0;
+    s.check(ismhip_compact_descriptor_rows(s.ctx, s.n_obj, s.kp_off.data(), D, s.raw_desc.as<float>(), s.raw_lrf.as<float>(), s.kx.as<float>(),
+                                           s.ky.as<float>(), s.kz.as<float>(), f->desc.as<float>(), f->lrf.as<float>(), f->kx.as<float>(),
+                                           f->ky.as<float>(), f->kz.as<float>(), f->src.as<uint32_t>(), f->off.data(), &all_kept),
+            "ismhip_compact_descriptor_rows");
+    if (all_kept) {
+        // nothing was dropped and nothing was copied: the raw matrices become the features, the keypoints are duplicated (12 bytes each)
+        f->desc.swap(s.raw_desc); f->lrf.swap(s.raw_lrf);
+        s.sync();
+        if (nkp && (hipMemcpy(f->kx.p, s.kx.p, (size_t)nkp * 4, hipMemcpyDeviceToDevice) != hipSuccess ||
+                    hipMemcpy(f->ky.p, s.ky.p, (size_t)nkp * 4, hipMemcpyDeviceToDevice) != hipSuccess ||
+                    hipMemcpy(f->kz.p, s.kz.p, (size_t)nkp * 4, hipMemcpyDeviceToDevice) != hipSuccess))
+            throw RuntimeException("hipMemcpy D2D failed");
+    }
     f->n = f->off.back();
     if (f->n < nkp) LOG_WARN("discarded " << (nkp - f->n) << " keypoint(s) with invalid reference frame or NaN descriptor");
     LOG_INFO("obtained " << f->n << " " << getType() << " descriptors");

@@ -171,7 +171,7 @@ class Recognizer:
         else:
             # FPFH ignores the frames for description, but keypoints with an invalid frame are still dropped first
             desc, cnt = capi.fpfh33(ctx, cloud, b.kp_off, b.kx, b.ky, b.kz, c.radius, want_counts=True)
-        keep, desc, lrf, kx, ky, kz, src = capi.compact_features(ctx, b.kp_off, desc, lrf, b.kx, b.ky, b.kz)
+        keep, desc, lrf, kx, ky, kz, src = capi.compact_descriptor_rows(ctx, b.kp_off, desc, lrf, b.kx, b.ky, b.kz)
         out = dict(off=keep, desc=desc, lrf=lrf, kx=kx, ky=ky, kz=kz, src=src, cloud=cloud)
         if want_counts:
             out["counts"] = cnt

@@ -192,6 +192,32 @@ def test_compact_features(pkg, gpu):
     np.testing.assert_array_equal(y.cpu().numpy(), kp[good, 1])
 
 
+def test_compact_descriptor_rows(pkg, gpu):
+    """ismhip_compact_descriptor_rows: rows that are NaN as a whole (what the descriptor kernels write) are dropped like
+    ismhip_compact_features drops them; when nothing goes, the input tensors come back untouched and uncopied."""
+    import torch
+    ctx, dev = gpu
+    rng = np.random.default_rng(8)
+    kp_off = np.array([0, 300, 300, 1000, 1100], np.uint32)
+    desc = rng.random((1100, 352)).astype(np.float32)
+    lrf = rng.random((1100, 9)).astype(np.float32)
+    kp = rng.random((1100, 3)).astype(np.float32)
+    args = lambda d, l: (ctx, kp_off, T(d, dev), T(l, dev), T(kp[:, 0].copy(), dev), T(kp[:, 1].copy(), dev), T(kp[:, 2].copy(), dev))
+    a = args(desc, lrf)
+    keep, d, l, x, y, z, src = pkg.capi.compact_descriptor_rows(*a)
+    assert keep.tolist() == kp_off.tolist() and d.data_ptr() == a[2].data_ptr() and l.data_ptr() == a[3].data_ptr() and x.data_ptr() == a[4].data_ptr()
+    assert np.array_equal(src.cpu().numpy(), np.arange(1100))
+    bad_rows = rng.choice(1100, 90, replace=False)
+    desc2, lrf2 = desc.copy(), lrf.copy()
+    desc2[bad_rows[:50]] = np.nan
+    lrf2[bad_rows[50:70], 3] = np.nan; lrf2[bad_rows[70:], 6] = np.inf
+    got = pkg.capi.compact_descriptor_rows(*args(desc2, lrf2))
+    want = pkg.capi.compact_features(*args(desc2, lrf2))
+    assert got[0].tolist() == want[0].tolist() and int(got[0][-1]) == 1100 - 90
+    for g, w in zip(got[1:], want[1:]):
+        np.testing.assert_array_equal(g.cpu().numpy(), w.cpu().numpy())
+
+
 def test_filter_normals_on_the_device(pkg, gpu):
     """ImplicitShapeModel::filterNormals (implicit_shape_model.cpp:1034-1075): points whose normal holds a NaN in ANY component leave
     their cloud, order kept; empty objects, an object that loses everything and objects longer than one scan block are covered."""
