@@ -344,7 +344,9 @@ struct WaveRows {
     uint32_t rows_before[ISM_ROWS_CAP / 64];      // NG > 1 only: rows that ended before block b (window-relative)
 };
 // L(i, valid) loads and returns the point record (issued one sweep AHEAD of its use, so the next 64 candidates are in flight
-// while the current ones are processed); F(record, i, valid) consumes it. i = object-local sorted point index.
+// while the current ones are processed); F(record, i, valid) consumes it. i = object-local sorted point index; a lane without a
+// candidate gets i = 0 (a valid index: the sweep only runs when a row holds points), so L may load unconditionally -- a conditional
+// load costs an exec-mask branch and a zero fill of the record per block -- and F must not use the record when valid is false.
 // NG = 1: the wave sweeps the flat list 64 consecutive candidates at a time (fully coalesced: 1 KB per load instruction).
 // NG = 8: the list is cut into 8 contiguous segments and every group of 8 lanes walks its own segment (128 B per group and
 //         load: still whole cache lines). The 64 candidates a wave looks at together then come from 8 DISTANT parts of the ball

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_spfh(FpfhArgs a) {
     // every candidate one block ahead of their use (the normal of a candidate that fails the radius test is wasted bandwidth, but a
     // dependent 16-byte gather per queued neighbour, issued when it is needed, was latency the wave could not hide)
     ball_for_each(m, cs, cr, px, py, pz, a.radius, lane, s_rows[wv],
-                  [&](uint32_t t, bool v) { PN r; r.p = v ? a.sp4[base + t] : make_float4(0.f, 0.f, 0.f, 0.f); r.n = v ? a.sn4[base + t] : make_float4(0.f, 0.f, 0.f, 0.f); return r; },
+                  [&](uint32_t t, bool) { PN r; r.p = a.sp4[base + t]; r.n = a.sn4[base + t]; return r; },
                   [&](const PN& rec, uint32_t t, bool v) {
         const float4 qq = rec.p;
         bool pass = false;

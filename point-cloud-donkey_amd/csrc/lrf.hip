@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_lrf_cov(CloudView cv, const uint32_t* _
     const double rd = (double)radius;
     __shared__ WaveRows s_rows[4];
     ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6],
-                  [&](uint32_t t, bool v) { return v ? cv.sp4[base + t] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                  [&](uint32_t t, bool) { return cv.sp4[base + t]; },
                   [&](const float4& p, uint32_t, bool v) {
         if (!v) return;
         const float px = p.x, py = p.y, pz = p.z;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 4) void k_lrf_sign(CloudView cv, const uint32_
     int plusT = 0, plusN = 0;
     __shared__ WaveRows s_rows[4];
     ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6],
-                  [&](uint32_t t, bool v) { return v ? cv.sp4[base + t] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                  [&](uint32_t t, bool) { return cv.sp4[base + t]; },
                   [&](const float4& p, uint32_t, bool v) {
         if (!v) return;
         const float px = p.x, py = p.y, pz = p.z;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void k_lrf_tie(CloudView cv, const float* __res
         const uint32_t cap = r.valid <= TIE_LDS_KEYS ? (uint32_t)TIE_LDS_KEYS : key_cap;
         uint32_t n = 0;
         ball_for_each(m, cs, cr, cx, cy, cz, radius, lane, s_rows[threadIdx.x >> 6],
-                      [&](uint32_t i, bool v) { return v ? cv.sp4[base + i] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                      [&](uint32_t i, bool) { return cv.sp4[base + i]; },
                       [&](const float4& p, uint32_t, bool v) {
             bool pass = false; float d2 = 0.f; uint32_t orig = 0;
             if (v) {
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void k_pca_normals(CloudView cv, float radius,
     __shared__ WaveRows s_rows[4];
     if (ball_cells(m, q.x, q.y, q.z, radius, cr))
         ball_for_each(m, cs, cr, q.x, q.y, q.z, radius, lane, s_rows[threadIdx.x >> 6],
-                      [&](uint32_t t, bool v) { return v ? cv.sp4[base + t] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                      [&](uint32_t t, bool) { return cv.sp4[base + t]; },
                       [&](const float4& p, uint32_t, bool v) {
             if (!v) return;
             if (sqdist3(p.x, p.y, p.z, q.x, q.y, q.z) < r2) {

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, COLOR ? 2 : 6) void k_shot(ShotArgs a) {
     uint32_t qn = 0, qh = 0, total = 0;
     // 16 interleaved segments: measured 4.18 (contiguous) -> 3.27 (8 segments) -> 2.96 ms (16 interleaved) per 256 objects; 32 lose to coalescing
     ball_for_each<(VAR & 2) ? 1 : 16, true>(m, cs, cr, cx, cy, cz, a.radius, lane, sm.rows[wv],
-                  [&](uint32_t i, bool v) { return v ? a.sp4[base + i] : make_float4(0.f, 0.f, 0.f, 0.f); },
+                  [&](uint32_t i, bool) { return a.sp4[base + i]; },      // invalid lanes carry index 0 (common.h): no branch, no zero fill
                   [&](const float4& p, uint32_t i, bool v) {
         bool pass = false; float dx = 0, dy = 0, dz = 0, d2 = 0;
         if (v) {
