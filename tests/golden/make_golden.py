@@ -565,8 +565,57 @@ def lrf_majority_sign():
     return dict(points=pts.tolist(), keypoint=[0, 0, 0], radius=r, expected=np.concatenate([x, y, z]).tolist(), counts=[3, 2, 4, 1], tol=2e-6)
 
 
+def pca_normals_slab():
+    """Round 3, KAT E: PCA normals (pcl::NormalEstimationOMPWithEigVals as ImplicitShapeModel::computeNormals drives it,
+    implicit_shape_model.cpp:969-1011) on two parallel 9 x 9 grids z = +0.5 and z = -0.5 (spacing 0.1) plus two isolated points.
+    NormalRadius 0.25 never reaches the other plane, so every neighbourhood is exactly planar: the smallest eigenvector is +-e_z whatever the
+    summation order. Orientation 0 (ConsistentNormalsMethod 0) flips it TOWARDS the viewpoint (0, 0, 0): (0, 0, -1) on the upper plane,
+    (0, 0, +1) on the lower one; orientation 1 (method 1) points it AWAY from the cloud's centroid -- the origin, because the two isolated
+    points are a mirror pair -- i.e. the opposite signs. A point with fewer than three neighbours inside the radius (the isolated ones:
+    only themselves) has no normal: NaN in all components."""
+    g = np.arange(-4, 5) * 0.1
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    top = np.stack([X.ravel(), Y.ravel(), np.full(81, 0.5)], 1)
+    bot = np.stack([X.ravel(), Y.ravel(), np.full(81, -0.5)], 1)
+    lone = np.asarray([[3.0, 0.0, 0.0], [-3.0, 0.0, 0.0]])              # a mirror pair keeps the centroid at the origin; each is alone in its ball
+    pts = np.concatenate([top, bot, lone])
+    assert np.allclose(pts.mean(0), 0)
+    towards = np.concatenate([np.tile([0, 0, -1.0], (81, 1)), np.tile([0, 0, 1.0], (81, 1)), np.full((2, 3), np.nan)])
+    return dict(points=pts.tolist(), radius=0.25, towards_origin=[[None if np.isnan(v) else v for v in r] for r in towards.tolist()], tol=2e-6)
+
+
+def kmeans_two_blobs():
+    """Round 3, KAT F: ClusteringKMeans (clustering/clustering_kmeans.cpp -> flann::hierarchicalClustering, branching = number of clusters,
+    one level) on two groups of four 2-d points, 14 apart with a spread of 2. Whatever the initial centres (they are drawn, so the vector
+    cannot name them), the result must be a FIXED POINT of Lloyd's iteration: every centre the mean of its members, every point with its
+    nearest centre, the reported distance the squared distance to it. From initial centres in different groups (15 of the 28 pairs of
+    points, and what k-means++ / Gonzales seeding pick here: the second centre is the point farthest from, or drawn by squared distance
+    from, the first) that fixed point is the global optimum: centres (1, 1) and (11, 11), every point at squared distance 2. The pairs
+    listed in `stuck` are the same-group starts from which Lloyd stops in a worse fixed point (worked below) -- k-means is not required
+    to escape them, and the check accepts them only as fixed points."""
+    a = [[0, 0], [0, 2], [2, 0], [2, 2]]
+    b = [[10, 10], [10, 12], [12, 10], [12, 12]]
+    pts = np.asarray(a + b, float)
+    good, stuck = 0, []
+    for i in range(8):                                                    # Lloyd from every pair of points as initial centres
+        for j in range(i + 1, 8):
+            c = pts[[i, j]].copy()
+            for _ in range(20):
+                asg = ((pts[:, None, :] - c[None]) ** 2).sum(2).argmin(1)
+                c = np.stack([pts[asg == t].mean(0) for t in range(2)])
+            if sorted(map(tuple, c.tolist())) == [(1.0, 1.0), (11.0, 11.0)]:
+                good += 1
+            else:
+                stuck.append([i, j])
+            if (i < 4) != (j < 4):
+                assert sorted(map(tuple, c.tolist())) == [(1.0, 1.0), (11.0, 11.0)], (i, j, c)
+    assert good >= 16
+    return dict(points=pts.tolist(), centres=[[1, 1], [11, 11]], groups=[0, 0, 0, 0, 1, 1, 1, 1], sqdist=2.0, stuck=stuck)
+
+
 def main():
-    kat = dict(shot_sector_centres=shot_sector_centres(), lrf_paraboloid=lrf_paraboloid(), rgb2lab=rgb2lab_cases(),
+    kat = dict(pca_normals_slab=pca_normals_slab(), kmeans_two_blobs=kmeans_two_blobs(),
+               shot_sector_centres=shot_sector_centres(), lrf_paraboloid=lrf_paraboloid(), rgb2lab=rgb2lab_cases(),
                fpfh_two_points=fpfh_two_points(), distances=distances(), rotations=rotations(), seeds_order=seeds_order(),
                voxel_grid=voxel_grid(), knn_ties=knn_ties(), shot_off_centre=shot_off_centre(), cshot_colour_pairs=cshot_colour_pairs(),
                cast_votes_vector=cast_votes_vector(), knn_rule_table=knn_rule_table(), maxima_thresholds=maxima_thresholds(),

@@ -151,3 +151,39 @@ def lrf_majority_sign(shot_lrf):
     k = KAT["lrf_majority_sign"]
     f = np.asarray(shot_lrf(np.asarray(k["points"], np.float32), np.asarray(k["keypoint"], np.float32), k["radius"]))
     np.testing.assert_allclose(f, k["expected"], atol=k["tol"])
+
+
+def pca_normals_slab(pca_normals):
+    """pca_normals(points, radius, orientation) -> [n, 3] (orientation 0: towards the origin, 1: away from the centroid)"""
+    k = KAT["pca_normals_slab"]
+    pts = np.asarray(k["points"], np.float32)
+    want = np.asarray([[np.nan if v is None else v for v in r] for r in k["towards_origin"]], np.float64)
+    for orientation, sign in ((0, 1.0), (1, -1.0)):
+        got = np.asarray(pca_normals(pts, k["radius"], orientation), np.float64)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        fin = ~np.isnan(want[:, 0])
+        np.testing.assert_allclose(got[fin], sign * want[fin], atol=k["tol"])
+
+
+def kmeans_two_blobs(kmeans):
+    """kmeans(points [n, dim], n_clusters, centers_init (0 random, 1 Gonzales, 2 k-means++), seed) -> (centres [m, dim], assign [n], sqdist [n])"""
+    k = KAT["kmeans_two_blobs"]
+    pts = np.asarray(k["points"], np.float32)
+    optimum = 0
+    for init in (0, 1, 2):
+        for seed in range(6):
+            c, asg, d = kmeans(pts, 2, init, seed)
+            c, asg, d = np.asarray(c, np.float64), np.asarray(asg), np.asarray(d, np.float64)
+            assert c.shape == (2, 2)
+            all_d = ((pts[:, None, :].astype(np.float64) - c[None]) ** 2).sum(2)
+            np.testing.assert_allclose(d, all_d[np.arange(8), asg], atol=1e-5)                    # the distance reported is the one to the assigned centre
+            assert (all_d[np.arange(8), asg] <= all_d.min(1) + 1e-5).all()                        # ... which is a nearest one
+            for t in range(2):                                                                     # every centre is the mean of its members
+                assert (asg == t).any()
+                np.testing.assert_allclose(c[t], pts[asg == t].mean(0), atol=1e-5)
+            if sorted(map(tuple, np.round(c, 5).tolist())) == sorted(map(tuple, np.asarray(k["centres"], float).tolist())):
+                optimum += 1
+                assert len(set(asg[:4])) == 1 and len(set(asg[4:])) == 1 and asg[0] != asg[4]
+                np.testing.assert_allclose(d, k["sqdist"], atol=1e-5)
+    # Gonzales picks the farthest point as the second centre: always the other group -> always the optimum; the drawn seedings mostly
+    assert optimum >= 12, optimum

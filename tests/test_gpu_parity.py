@@ -1506,6 +1506,27 @@ def test_kat_lrf_majority_sign(pkg, gpu):
     kat_checks.lrf_majority_sign(f)
 
 
+def test_kat_pca_normals_slab(pkg, gpu):
+    import torch
+    ctx, dev = gpu
+
+    def f(pts, radius, orientation):
+        s = Scene(pkg, gpu, [(pts, np.zeros_like(pts))], [np.zeros((0, 3), np.float32)], 0.5 * radius)
+        n = [torch.empty(len(pts), dtype=torch.float32, device=dev) for _ in range(3)]
+        pkg.capi.estimate_normals_pca(ctx, s.cloud, radius, orientation, *n)
+        return np.stack([t.cpu().numpy() for t in n], 1)
+    kat_checks.pca_normals_slab(f)
+
+
+def test_kat_kmeans_two_blobs(pkg, gpu):
+    ctx, dev = gpu
+
+    def f(pts, n_clusters, init, seed):
+        c, asg, d, _ = pkg.capi.kmeans(ctx, 0, T(pts, dev), n_clusters, centers_init=init, seed=seed)
+        return c.cpu().numpy(), asg.cpu().numpy(), d.cpu().numpy()
+    kat_checks.kmeans_two_blobs(f)
+
+
 @pytest.mark.parametrize("interp,bin_size,rel", [(True, 0.4, 0.6), (False, 0.4, 0.6), (True, 0.1, 0.3), (True, 0.25, 0.9)])
 def test_hough3d_matches_oracle(pkg, gpu, ora, interp, bin_size, rel):
     """VotingHough3D on the device against the oracle on ragged vote sets (empty object, slots without a vote, clutter, votes

@@ -387,3 +387,17 @@ def test_lrf_majority_sign_vector(ora):
         x, y, z = _soa(pts)
         return ora.shot_lrf([0, len(pts)], x, y, z, [0, 1], [kp[0]], [kp[1]], [kp[2]], radius)[0]
     kat_checks.lrf_majority_sign(f)
+
+
+def test_pca_normals_slab_vector(ora):
+    def f(pts, radius, orientation):
+        x, y, z = _soa(pts)
+        return ora.pca_normals([0, len(pts)], x, y, z, radius, orientation)
+    kat_checks.pca_normals_slab(f)
+
+
+def test_kmeans_two_blobs_vector(ora):
+    def f(pts, n_clusters, init, seed):
+        c, asg, d, _ = ora.kmeans(0, pts, n_clusters, centers_init=init, seed=seed)
+        return c, asg, d
+    kat_checks.kmeans_two_blobs(f)
