@@ -145,6 +145,7 @@ struct ismhip_ctx {
     float knn_pre_gamma = 1.0f;  // env ISMHIP_KNN_PRE_GAMMA: relaxation of the pre-pass start thresholds in units of the truncated second moment (A/B runs)
     bool knn_prepass = true;     // env ISMHIP_KNN_PREPASS=0: stage 1 starts every candidate list cold instead of from the sampled pre-pass threshold (A/B runs)
     int knn_pca_m = -1;          // env ISMHIP_KNN_PCA_M: leading rotated coordinates of the stage-1 image (0 = no rotated image, -1 = chosen from the spectrum)
+    bool knn_stage2_t4 = false;       // env ISMHIP_KNN_STAGE2_T4=1: partial stage-2 chunks on the 256-query tiles of full ones (A/B runs)
     bool codebook_light = false;      // set around ismhip_codebook_create by ism_knn_only_codebook: skip the rotated image and the chi-square shadow
     uint32_t knn_pca_launches = 0;    // squared-L2 searches whose stage 1 ran on the rotated image (tests / bench)
     int knn_mode = 0;            // env ISMHIP_KNN_MODE = f16 (0, default) | bf16x3 (1) | f32 (2): squared-L2 candidate kernel (A/B runs, tests)

@@ -79,6 +79,7 @@ static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out)
     { const char* e = getenv("ISMHIP_KNN_HELL_EMIT"); ctx->knn_hell_emit = !(e && e[0] == '0'); }
     { const char* e = getenv("ISMHIP_KNN_HELLINGER"); ctx->knn_hellinger = !(e && e[0] == '0'); }
     { const char* e = getenv("ISMHIP_KNN_T1"); if (e) ctx->knn_t1 = atoi(e); }
+    { const char* e = getenv("ISMHIP_KNN_STAGE2_T4"); if (e) ctx->knn_stage2_t4 = atoi(e) != 0; }
     { const char* e = getenv("ISMHIP_KNN_PRE_STEP"); if (e && atoi(e) > 0) ctx->knn_pre_step = atoi(e); }
     { const char* e = getenv("ISMHIP_KNN_PRE_GAMMA"); if (e) ctx->knn_pre_gamma = (float)atof(e); }
     { const char* e = getenv("ISMHIP_KNN_PREPASS"); ctx->knn_prepass = !(e && e[0] == '0'); }

@@ -2234,7 +2234,15 @@ int run_knn_two_stage(ismhip_ctx* ctx, const ismhip_codebook* cb, int nq, const 
     // queries) takes the merged-splits kernel that fills the chip with splits instead of query tiles.
     for (int o = 0; o < n2;) {
         const int left = n2 - o, n = left >= 32768 ? left / 32768 * 32768 : left;
+        // a chunk below one full round (a shard of the split on N GPUs: 8 300 stage-2 queries per rank at N = 8) is 33 query tiles x 2
+        // codebook splits = 66 workgroups on 256 CUs (2.17 ms for 8 300 queries, 2.24 for 16 600). Two candidates per lane slot instead
+        // of four would allow four splits, but 1 % of these queries then fail their proof in a whole split and the exact scan costs
+        // more than was won (measured: 9.18 vs 9.39 ms per step of 114 objects, 17.6 vs 15.0 of 227). The 128-query tile variant
+        // (k_knn_l2_ring16<T, 1>: four lane slots per split, so four splits at T = 4) doubles the workgroups twice over instead.
+        const bool was_half = ctx->knn_half;
+        if (n >= 4096 && n < 32768 && !ctx->knn_stage2_t4) ctx->knn_half = true;
         rc = run_knn<4>(ctx, cb, ISMHIP_METRIC_L2SQ, n, q2 + (size_t)o * cb->dim, k, idx2 + (size_t)o * k, dist2 + (size_t)o * k, nullptr, "knn_stage2", n < 4096);
+        ctx->knn_half = was_half;
         if (rc != ISMHIP_OK) return rc;
         o += n;
     }
