@@ -211,6 +211,8 @@ int  ismhip_codebook_max_votes_per_word(const ismhip_codebook* cb);
  * all dimensions). Speed only -- every ismhip_knn answer is the exact functor minimum either way. energy_out (may be NULL): share
  * of the codebook's second moment those coordinates hold. */
 int  ismhip_codebook_stage1_dims(const ismhip_codebook* cb, float* energy_out);
+/* The same for the image the queries whose stage-1 proof failed are searched on again (0: all dimensions). */
+int  ismhip_codebook_stage2_dims(const ismhip_codebook* cb, float* energy_out);
 
 /* ---- activation: ActivationStrategyKNN::activateKNN (activation_strategy/activation_strategy_knn.h:41-126)
  *      with FLANNExactMatch semantics (SearchParams(-1)): exact k nearest codewords, ascending distance,

@@ -26,7 +26,7 @@ EXPORTS = [
     "ismhip_cloud_create", "ismhip_cloud_destroy", "ismhip_cloud_centroids", "ismhip_cloud_radii", "ismhip_estimate_normals", "ismhip_estimate_normals_pca",
     "ismhip_shot_lrf", "ismhip_shot352", "ismhip_cshot1344", "ismhip_fpfh33", "ismhip_center_dist",
     "ismhip_compact_features", "ismhip_compact_descriptor_rows", "ismhip_filter_normals", "ismhip_voxel_keypoints", "ismhip_gather_columns",
-    "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word", "ismhip_codebook_stage1_dims",
+    "ismhip_codebook_create", "ismhip_codebook_set_word_class", "ismhip_codebook_destroy", "ismhip_codebook_max_votes_per_word", "ismhip_codebook_stage1_dims", "ismhip_codebook_stage2_dims",
     "ismhip_knn", "ismhip_knn_ratio", "ismhip_knn_rule", "ismhip_cast_votes", "ismhip_find_maxima", "ismhip_hough3d_maxima", "ismhip_train_activate", "ismhip_kmeans",
 ]
 
@@ -185,6 +185,8 @@ class Codebook:
         e = C.c_float(1.0)
         self.stage1_dims = int(lib().ismhip_codebook_stage1_dims(self._h, C.byref(e)))     # 0: squared-L2 candidates on all dimensions
         self.stage1_energy = float(e.value)
+        self.stage2_dims = int(lib().ismhip_codebook_stage2_dims(self._h, C.byref(e)))     # 0: stage 2 of the squared-L2 search on all dimensions
+        self.stage2_energy = float(e.value)
 
     def set_word_class(self, word_class):
         self.ctx.check(lib().ismhip_codebook_set_word_class(self.ctx._h, self._h, _p(_u32(word_class))), "ismhip_codebook_set_word_class")

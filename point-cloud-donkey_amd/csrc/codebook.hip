@@ -240,8 +240,14 @@ int ismhip_codebook_set_word_class(ismhip_ctx* ctx, ismhip_codebook* cb, const u
 int ismhip_codebook_max_votes_per_word(const ismhip_codebook* cb) { return cb ? cb->max_votes : ISMHIP_ERR_INVALID; }
 int ismhip_codebook_stage1_dims(const ismhip_codebook* cb, float* energy_out) {
     if (!cb) return ISMHIP_ERR_INVALID;
-    if (energy_out) *energy_out = cb->pca_m > 0 ? cb->pca_energy : 1.0f;
-    return cb->pca_m;
+    if (energy_out) *energy_out = cb->pca.m > 0 ? cb->pca.energy : 1.0f;
+    return cb->pca.m;
+}
+
+int ismhip_codebook_stage2_dims(const ismhip_codebook* cb, float* energy_out) {
+    if (!cb) return ISMHIP_ERR_INVALID;
+    if (energy_out) *energy_out = cb->pca2.m > 0 ? cb->pca2.energy : 1.0f;
+    return cb->pca2.m;
 }
 
 int ismhip_cast_votes(ismhip_ctx* ctx, const ismhip_codebook* cb, uint32_t weight_flags,

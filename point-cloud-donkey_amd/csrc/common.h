@@ -52,6 +52,24 @@ struct ismhip_cloud {
     size_t cap_pts = 0; int cap_obj = 0; bool cap_color = false;
 };
 
+// A rotated, truncated f16 image of a codebook. Rows of R = the m leading eigenvectors of the codebook's second-moment matrix
+// (orthonormal up to the error folded into inv_sig2), so |R (q - c)|^2 <= sigma_max(R)^2 |q - c|^2: a score over the leading m rotated
+// coordinates is a LOWER bound of the functor value.
+struct PcaImage {
+    int m = 0;                       // leading rotated coordinates kept (multiple of 32); 0: not built
+    float* R = nullptr;              // [m x dim_pad] fp32, row j = j-th basis vector (zero in the padding columns)
+    unsigned short* f16t = nullptr;  // f16 image of R c (scale sc) in the ring kernel's streaming layout [tile][m/32][256][32]
+    float* cn_scaled = nullptr;      // [n_words_pad + 256] |c^|^2 / out_scale of that image (-inf for padding rows): the ring kernel's C operand
+    float* osc = nullptr;            // device scalars: [0] out_scale = -2 / (sq sc)
+    float sq = 1.f, sc = 1.f;        // power-of-two f16 scales of the query / codebook images (the query scale is FIXED per codebook)
+    float cmax2 = 0.f;               // max |c^|^2 over the real rows (c^ = image / sc)
+    float inv_sig2 = 1.f;            // 1 / (upper bound of sigma_max(R)^2), rounded down
+    float d_rel = 0.f;               // |x^ - R x|_2 <= d_rel |x|_2 + dq_abs (queries) / dc_abs (codewords): rotation + f16 rounding
+    float dq_abs = 0.f, dc_abs = 0.f;
+    float resid2 = 0.f;              // mean second moment per codeword OUTSIDE the leading m coordinates (the pre-pass relaxes its start thresholds by it)
+    float energy = 0.f;              // share of the codebook's second moment in the leading m coordinates (diagnostic)
+};
+
 struct ismhip_codebook {
     int n_words = 0, dim = 0, dim_pad = 0, n_votes = 0, max_votes = 0, n_classes = 0;
     float* words = nullptr;          // [n_words_pad * dim_pad] row-major, zero padded (MFMA tile friendly)
@@ -80,21 +98,10 @@ struct ismhip_codebook {
     // images, norms and scales of sqrt(words); its fp32 words are not kept. Only for codebooks without negative / NaN elements.
     ismhip_codebook* chi_shadow = nullptr;
     uint32_t* shadow_perm = nullptr; // (in the shadow) [n_words] codebook row of every shadow row
-    // ---- rotated, truncated stage-1 image of the squared-L2 search (pca.hip; pca_m == 0: not built) ----------------------------
-    // rows of R = the pca_m leading eigenvectors of the codebook's second-moment matrix (orthonormal up to pca_orth_err), so
-    // |R (q - c)|^2 <= sigma_max(R)^2 |q - c|^2: a score over the leading pca_m rotated coordinates is a LOWER bound of the functor value
-    int pca_m = 0;                   // leading rotated coordinates kept (multiple of 32)
-    float* pca_R = nullptr;          // [pca_m x dim_pad] fp32, row j = j-th basis vector (zero in the padding columns)
-    unsigned short* pca_f16t = nullptr;   // f16 image of R c (scale pca_sc) in the ring kernel's streaming layout [tile][pca_m/32][256][32]
-    float* pca_cn_scaled = nullptr;  // [n_words_pad + 256] |c^|^2 / out_scale of that image (-inf for padding rows): the ring kernel's C operand
-    float* pca_osc = nullptr;        // device scalars: [0] out_scale = -2 / (pca_sq pca_sc)
-    float pca_sq = 1.f, pca_sc = 1.f;     // power-of-two f16 scales of the query / codebook images (the query scale is FIXED per codebook)
-    float pca_cmax2 = 0.f;           // max |c^|^2 over the real rows (c^ = image / pca_sc)
-    float pca_inv_sig2 = 1.f;        // 1 / (upper bound of sigma_max(R)^2), rounded down
-    float pca_d_rel = 0.f;           // |x^ - R x|_2 <= pca_d_rel |x|_2 + pca_dq_abs (queries) / pca_dc_abs (codewords): rotation + f16 rounding
-    float pca_dq_abs = 0.f, pca_dc_abs = 0.f;
-    float pca_resid2 = 0.f;          // mean second moment per codeword OUTSIDE the leading pca_m coordinates (the pre-pass relaxes its start thresholds by it)
-    float pca_energy = 0.f;          // share of the codebook's second moment in the leading pca_m coordinates (diagnostic)
+    // ---- rotated, truncated images of the squared-L2 search (pca.hip; m == 0: not built) ---------------------------------------------
+    // pca: the stage-1 image (leading coordinates that hold 97 % of the second moment); pca2: a longer one (99.7 %) for stage 2, the
+    // queries whose stage-1 proof failed -- both cut from the same eigenbasis
+    PcaImage pca, pca2;
 };
 
 struct TimerAcc {
@@ -147,6 +154,7 @@ struct ismhip_ctx {
     int knn_pca_m = -1;          // env ISMHIP_KNN_PCA_M: leading rotated coordinates of the stage-1 image (0 = no rotated image, -1 = chosen from the spectrum)
     bool knn_stage2_t4 = false;       // env ISMHIP_KNN_STAGE2_T4=1: partial stage-2 chunks on the 256-query tiles of full ones (A/B runs)
     bool codebook_light = false;      // set around ismhip_codebook_create by ism_knn_only_codebook: skip the rotated image and the chi-square shadow
+    int knn_pca_m2 = -1;         // env ISMHIP_KNN_PCA_M2: coordinates of the stage-2 image (0 = stage 2 on all dimensions, -1 = chosen from the spectrum)
     uint32_t knn_pca_launches = 0;    // squared-L2 searches whose stage 1 ran on the rotated image (tests / bench)
     int knn_mode = 0;            // env ISMHIP_KNN_MODE = f16 (0, default) | bf16x3 (1) | f32 (2): squared-L2 candidate kernel (A/B runs, tests)
 };

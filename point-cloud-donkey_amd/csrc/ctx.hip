@@ -84,6 +84,7 @@ static int ctx_create_impl(int device, void* stream, bool own, ismhip_ctx** out)
     { const char* e = getenv("ISMHIP_KNN_PRE_GAMMA"); if (e) ctx->knn_pre_gamma = (float)atof(e); }
     { const char* e = getenv("ISMHIP_KNN_PREPASS"); ctx->knn_prepass = !(e && e[0] == '0'); }
     { const char* e = getenv("ISMHIP_KNN_PCA_M"); ctx->knn_pca_m = e ? atoi(e) : -1; }
+    { const char* e = getenv("ISMHIP_KNN_PCA_M2"); ctx->knn_pca_m2 = e ? atoi(e) : -1; }
     { const char* e = getenv("ISMHIP_KNN_TILE128"); ctx->knn_small_tile = e && e[0] == '1'; }
     if (!own) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
     else {

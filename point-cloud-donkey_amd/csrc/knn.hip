@@ -21,7 +21,7 @@
 //     adversarial inputs (un-normalised magnitudes, hundreds of near-duplicates): it keeps the answer exact in every case.
 #include "common.h"
 
-int ism_pca_rotate_queries(ismhip_ctx* ctx, const ismhip_codebook* cb, const float* q, int nq, int ldq, unsigned short* dst);   // pca.hip
+int ism_pca_rotate_queries(ismhip_ctx* ctx, const ismhip_codebook* cb, const PcaImage* P, const float* q, int nq, int ldq, unsigned short* dst);   // pca.hip
 
 namespace {
 
@@ -1895,7 +1895,7 @@ __global__ void k_rule(int nq, float thr, const int32_t* __restrict__ idx3, cons
 struct KnnStage1 { uint32_t* flag_count; uint32_t* qrec; };
 template <int T>
 int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, const float* q, int k,
-            int32_t* idx_out, float* dist_out, KnnStage1* stage1 = nullptr, const char* tname = nullptr, bool many_splits = false, bool use_pca = false, const float* hell_q = nullptr) {
+            int32_t* idx_out, float* dist_out, KnnStage1* stage1 = nullptr, const char* tname = nullptr, bool many_splits = false, int use_pca = 0 /* 1: stage-1 image, 2: stage-2 image */, const float* hell_q = nullptr) {
     // hell_q != nullptr (chi-square only): candidates come from the squared-L2 kernels run on the SQUARE-ROOT images (Hellinger lower
     // bound, see k_knn_rerank_lb): xb = the shadow codebook that owns those images, hell_q = sqrt(q) rows of dim_pad floats
     const bool hell = hell_q != nullptr && metric == ISMHIP_METRIC_CHI2 && cb->chi_shadow;
@@ -1917,7 +1917,8 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     // short descriptors (FPFH-33: values up to 100, |q||c| ~ 1e4): the f16 error bound is of the order of the neighbour distances, most
     // proofs fail and the exact scan takes over (measured: 135 ms of scan per 524288 queries). The exact-f32 MFMA contraction costs
     // 2 Nq Nc D flop at ~125 TFLOP/s, which for D <= 64 is cheaper than the 16-bit kernels' fixed overheads -- and it proves everything.
-    const bool short_dim = cb->dim <= 64 && ctx->knn_mode == 0 && !(use_pca && cb->pca_m > 0);     // (stage 1 of a short-descriptor codebook with an f16 stage-1 image: pca.hip)
+    const PcaImage& PI = use_pca == 2 ? cb->pca2 : cb->pca;
+    const bool short_dim = cb->dim <= 64 && ctx->knn_mode == 0 && !(use_pca && PI.m > 0);     // (stage 1 of a short-descriptor codebook with an f16 stage-1 image: pca.hip)
     const int mode = cmetric != ISMHIP_METRIC_L2SQ ? -1 : (hell ? 0 : (short_dim ? 2 : (ctx->knn_mode == 0 && cb->words_f16 ? 0 : (ctx->knn_mode <= 1 && cb->words_bf16_hi ? 1 : 2))));
     const bool use_lp = mode == 0 || mode == 1;
     const bool big_tile = use_lp && nq >= 4096 && cb->n_words_pad >= 4096 && !ctx->knn_small_tile;      // 256x256 tile, 8 waves
@@ -1931,12 +1932,12 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     const bool qpanel = ring16 && !half && ctx->knn_qpanel && ((cb->dim + 15) / 16 + 1) / 2 <= 11;   // 256 x 128 tile, query panel resident in LDS
     if (qpanel) BNq = 128;
     // 256 x 256 tile with the whole query panel resident (k_knn_l2_ring16<T, 2, 0, 2>): stage 1 on a rotated image of <= 160 coordinates
-    const bool qpanel2 = ring16 && !half && !qpanel && ctx->knn_qpanel2 && use_pca && cb->pca_m > 0 && cb->pca_m <= 160;
+    const bool qpanel2 = ring16 && !half && !qpanel && ctx->knn_qpanel2 && use_pca && PI.m > 0 && PI.m <= 160;
     const int BM = half ? 128 : BM0;
     const int slots = ring16 && !half ? 8 : 4;
     // stage 1 of the two-stage search on the rotated, truncated image (pca.hip): same kernel, pca_m / 32 slices instead of dim / 32
-    const bool pca = use_pca && use_ring && cb->pca_m > 0;
-    const int ring_nk = pca ? cb->pca_m / 32 : ((cb->dim + 15) / 16 + 1) / 2;   // 32-k slices per row in the tiled images
+    const bool pca = use_pca && use_ring && PI.m > 0;
+    const int ring_nk = pca ? PI.m / 32 : ((cb->dim + 15) / 16 + 1) / 2;   // 32-k slices per row in the tiled images
     const bool merged = many_splits && cmetric == ISMHIP_METRIC_L2SQ && use_lp && !big_tile;
     if (cmetric == ISMHIP_METRIC_L2SQ) {
         const int n_qt = (nq + BNq - 1) / BNq, n_mt = cb->n_words_pad / BM;
@@ -1993,7 +1994,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
         q_lo = q_hi + tot;
         if (pca) {
             TimerScope tr(ctx, "knn_rotate");
-            const int rc = ism_pca_rotate_queries(ctx, cb, qq, nq, ldq, q_hi);
+            const int rc = ism_pca_rotate_queries(ctx, cb, &PI, qq, nq, ldq, q_hi);
             if (rc != ISMHIP_OK) return rc;
             ++ctx->knn_pca_launches;
         } else if (mode == 0) {
@@ -2061,7 +2062,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 }
                 const float* osc = (const float*)(qsc + 1);
                 const float* word_norm;
-                if (pca) { wh = cb->pca_f16t; osc = cb->pca_osc; word_norm = cb->pca_cn_scaled; }      // scales fixed per codebook: the C operand is precomputed
+                if (pca) { wh = PI.f16t; osc = PI.osc; word_norm = PI.cn_scaled; }      // scales fixed per codebook: the C operand is precomputed
                 else {
                     float* cn_scaled = (float*)ism_scratch(ctx, SCR_QNORM2, ((size_t)cb->n_words_pad + 256) * sizeof(float));   // the |c|^2 DMA of a 128-row tile reads 256 floats
                     if (!cn_scaled) return ISMHIP_ERR_NOMEM;
@@ -2069,7 +2070,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     ISM_CHECK_LAUNCH(ctx, "k_scale_norms");
                     word_norm = cn_scaled;
                 }
-                int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = pca ? cb->pca_m / 16 : (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
+                int n_tiles_m = cb->n_words_pad / BM, ld16 = cb->ld16, k_steps = pca ? PI.m / 16 : (cb->dim + 15) / 16, nq_ = nq, tps = tiles_per_split, nsp = n_splits, ncand = n_cand, nb = n_bound;
                 const u16* qh_ = q_hi;
                 unsigned int* clock = nullptr;                                   // joined codeword streams (k_knn_l2_ring16), one clock per (XCD, split)
                 if (ring16 && ctx->knn_join) {
@@ -2082,7 +2083,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                 const float* thr_init = nullptr; float* thr_out = nullptr; int tile_step = 1;
                 // (not for an untruncated stage-1 image: with nothing left out there is no scale to relax the start value by, and the
                 // unrelaxed best of the sample is the nearest neighbour itself too often)
-                if (stage1 && ring16 && !half && !qpanel && ctx->knn_prepass && n_tiles_m >= 128 && ctx->knn_dbg == 0 && !(pca && cb->pca_resid2 <= 0.f)) {
+                if (stage1 && ring16 && !half && !qpanel && ctx->knn_prepass && n_tiles_m >= 128 && ctx->knn_dbg == 0 && !(pca && PI.resid2 <= 0.f)) {
                     float* thr0 = (float*)ism_scratch(ctx, SCR_KNN_THR0, (size_t)((nq + 255) / 256 * 256) * sizeof(float));
                     if (!thr0) return ISMHIP_ERR_NOMEM;
                     const void* pk = (const void*)k_knn_l2_ring16<T, 2, 0, 0, 1>;
@@ -2091,7 +2092,7 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
                     // relaxation: gamma x the second moment the truncation leaves out (codeword + query side, taken as equal), in
                     // accumulator units (score / out_scale); the original image truncates nothing
                     float relax = 0.f;
-                    if (pca) relax = -ctx->knn_pre_gamma * 2.0f * cb->pca_resid2 * (cb->pca_sq * cb->pca_sc * 0.5f);
+                    if (pca) relax = -ctx->knn_pre_gamma * 2.0f * PI.resid2 * (PI.sq * PI.sc * 0.5f);
                     void* pargs[] = {&wh, &word_norm, &n_tiles_m, &ld16, &k_steps, &qh_, &nq_, &osc, &all, &one, &cand_val, &cand_idx, &ncand, &cand_bound, &nb, &noclk, &noinit, &thr0, &step, &relax};
                     ISM_HIP(ctx, hipLaunchKernel(pk, dim3(8 * ((n_qt + 7) / 8)), dim3(512), pargs, rlds, ctx->stream));
                     ISM_CHECK_LAUNCH(ctx, "k_knn_l2_ring16<pre>");
@@ -2151,15 +2152,15 @@ int run_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, cons
     TimerScope trr(ctx, "knn_rerank");
     if (pca) {
         PcaVerify pv;
-        const float acc_rel = 1.01f * (float)cb->pca_m * 1.1920929e-07f;            // accumulation only: products of f16 values are exact in fp32
-        pv.qimg = q_hi; pv.nk = ring_nk; pv.inv_sq2 = 1.0f / (cb->pca_sq * cb->pca_sq);
-        pv.inv_sig2 = cb->pca_inv_sig2; pv.d_rel = cb->pca_d_rel; pv.dq_abs = cb->pca_dq_abs;
-        pv.dc = (cb->pca_d_rel * sqrtf(cb->max_norm2) + cb->pca_dc_abs) * 1.00001f;
-        pv.cmax2 = cb->pca_cmax2;
+        const float acc_rel = 1.01f * (float)PI.m * 1.1920929e-07f;            // accumulation only: products of f16 values are exact in fp32
+        pv.qimg = q_hi; pv.nk = ring_nk; pv.inv_sq2 = 1.0f / (PI.sq * PI.sq);
+        pv.inv_sig2 = PI.inv_sig2; pv.d_rel = PI.d_rel; pv.dq_abs = PI.dq_abs;
+        pv.dc = (PI.d_rel * sqrtf(cb->max_norm2) + PI.dc_abs) * 1.00001f;
+        pv.cmax2 = PI.cmax2;
         // subnormal f16 operands may be flushed to zero by the matrix cores: |dq_i| <= 2^-14 / sq, |dc_i| <= 2^-14 / sc per element
-        const float fq = 6.103515625e-05f / cb->pca_sq, fc = 6.103515625e-05f / cb->pca_sc, sm = sqrtf((float)cb->pca_m);
-        pv.eps_c2 = (17.f * KNN_U + 1.01f * (float)(cb->pca_m + 1) * 1.1920929e-07f) * cb->pca_cmax2 + 2.02f * (sm * fq * sqrtf(cb->pca_cmax2) + sm * sm * fq * fc);
-        pv.dot2 = 2.f * acc_rel + 2.f * KNN_U + 2.02f * sm * fc / sqrtf(cb->pca_cmax2);
+        const float fq = 6.103515625e-05f / PI.sq, fc = 6.103515625e-05f / PI.sc, sm = sqrtf((float)PI.m);
+        pv.eps_c2 = (17.f * KNN_U + 1.01f * (float)(PI.m + 1) * 1.1920929e-07f) * PI.cmax2 + 2.02f * (sm * fq * sqrtf(PI.cmax2) + sm * sm * fq * fc);
+        pv.dot2 = 2.f * acc_rel + 2.f * KNN_U + 2.02f * sm * fc / sqrtf(PI.cmax2);
         pv.ku = vp.ku;
         hipLaunchKernelGGL(k_knn_rerank_pca, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, cb->words, cb->dim, cb->dim_pad, cb->n_words,
                            qq, nq, ldq, cand_idx, cand_val, n_cand, n_cand, cand_bound, n_bound, pv, k, idx_out, dist_out, flag_count, qrec, items);
@@ -2240,8 +2241,10 @@ int run_knn_two_stage(ismhip_ctx* ctx, const ismhip_codebook* cb, int nq, const 
         // more than was won (measured: 9.18 vs 9.39 ms per step of 114 objects, 17.6 vs 15.0 of 227). The 128-query tile variant
         // (k_knn_l2_ring16<T, 1>: four lane slots per split, so four splits at T = 4) doubles the workgroups twice over instead.
         const bool was_half = ctx->knn_half;
-        if (n >= 4096 && n < 32768 && !ctx->knn_stage2_t4) ctx->knn_half = true;
-        rc = run_knn<4>(ctx, cb, ISMHIP_METRIC_L2SQ, n, q2 + (size_t)o * cb->dim, k, idx2 + (size_t)o * k, dist2 + (size_t)o * k, nullptr, "knn_stage2", n < 4096);
+        // (the stage-2 image, if the codebook has one: 8 slices per tile instead of 11 on the bench data; its tiles are short enough)
+        const int lvl2 = cb->pca2.m > 0 && !(n < 4096) ? 2 : 0;
+        if (n >= 4096 && n < 32768 && !ctx->knn_stage2_t4 && lvl2 == 0) ctx->knn_half = true;
+        rc = run_knn<4>(ctx, cb, ISMHIP_METRIC_L2SQ, n, q2 + (size_t)o * cb->dim, k, idx2 + (size_t)o * k, dist2 + (size_t)o * k, nullptr, "knn_stage2", n < 4096, lvl2);
         ctx->knn_half = was_half;
         if (rc != ISMHIP_OK) return rc;
         o += n;
@@ -2491,7 +2494,7 @@ int ismhip_knn(ismhip_ctx* ctx, const ismhip_codebook* cb, int metric, int nq, c
     const bool wide = k > 2 || (metric == ISMHIP_METRIC_L2SQ && cb->words_bf16_hi && ctx->knn_mode <= 1 && !(cb->dim <= 64 && ctx->knn_mode == 0));
     // default for big squared-L2 launches with k <= 2 (every shipped configuration): the two-stage search (see run_knn_two_stage)
     if (metric == ISMHIP_METRIC_L2SQ && k <= 2 && ctx->knn_t == 0 && ctx->knn_mode == 0 && ctx->knn_two_stage && cb->words_f16t && nq >= 4096 &&
-        cb->n_words_pad >= 4096 && !ctx->knn_small_tile && !ctx->knn_no_ring && (cb->dim > 64 || cb->pca_m > 0))
+        cb->n_words_pad >= 4096 && !ctx->knn_small_tile && !ctx->knn_no_ring && (cb->dim > 64 || cb->pca.m > 0))
         return run_knn_two_stage(ctx, cb, nq, q, k, idx_out, dist_out);
     // chi-square on histogram data: Hellinger candidates on the matrix cores (run_knn_chi2_hellinger); a batch with a negative element
     // keeps the VALU kernel

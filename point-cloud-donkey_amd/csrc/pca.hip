@@ -209,14 +209,64 @@ int launch_rotate(ismhip_ctx* ctx, const float* x, int n, int ldx, int kdim, con
 }  // namespace
 
 // the query batch -> rotated f16 image (stage 1 of the two-stage search); q rows of ldq >= dim_pad floats, zero beyond dim
-int ism_pca_rotate_queries(ismhip_ctx* ctx, const ismhip_codebook* cb, const float* q, int nq, int ldq, unsigned short* dst) {
-    return launch_rotate(ctx, q, nq, ldq, cb->dim_pad, cb->pca_R, cb->pca_m, cb->pca_sq, dst);
+int ism_pca_rotate_queries(ismhip_ctx* ctx, const ismhip_codebook* cb, const PcaImage* P, const float* q, int nq, int ldq, unsigned short* dst) {
+    return launch_rotate(ctx, q, nq, ldq, cb->dim_pad, P->R, P->m, P->sq, dst);
+}
+
+// One image from the leading m rows of the eigenbasis (R: [m x dim_pad] fp32 as uploaded): scales, error constants, the f16 image in the
+// ring kernel's layout and its |c^|^2 row. Leaves P.m == 0 (never an error) when the image cannot be trusted.
+static int build_image(ismhip_ctx* ctx, ismhip_codebook* cb, PcaImage& P, const std::vector<float>& R, int m, double energy, double trace) {
+    const int dp = cb->dim_pad;
+    P.m = 0;
+    // sigma_max(R)^2 <= 1 + |R R^T - I|_F and |R|_F, from the fp32 values that are uploaded
+    double e2 = 0, fro2 = 0;
+    for (int i = 0; i < m; ++i) for (int j = i; j < m; ++j) {
+        double g = 0; for (int c = 0; c < dp; ++c) g += (double)R[(size_t)i * dp + c] * (double)R[(size_t)j * dp + c];
+        if (i == j) { fro2 += g; if (g != 0.0) { g -= 1.0; e2 += g * g; } } else e2 += 2.0 * g * g;     // all-zero rows (padding) only shrink the image
+    }
+    const double sig2 = 1.0 + std::sqrt(e2), sig = std::sqrt(sig2), fro = std::sqrt(fro2);
+    if (!(sig2 < 1.01)) return ISMHIP_OK;                                              // a basis this far from orthonormal is a bug, not a bound
+    const double cmax = std::sqrt((double)cb->max_norm2);
+    P.sc = f16_scale_of_bound((float)(1.001 * sig * cmax));
+    P.sq = f16_scale_of_bound((float)(2.002 * sig * cmax));
+    const double gamma = 1.01 * dp * 1.1920929e-07;                                    // fp32 rotation: K adds of relative error <= 2^-23, any order
+    P.d_rel = (float)(1.001 * (gamma * fro + 4.8828125e-04 * (sig + gamma * fro)));
+    P.dq_abs = (float)(1.001 * std::sqrt((double)m) * 6.103515625e-05 / P.sq);
+    P.dc_abs = (float)(1.001 * std::sqrt((double)m) * 6.103515625e-05 / P.sc);
+    P.inv_sig2 = (float)((1.0 / sig2) * (1.0 - 1e-6));
+    P.energy = (float)energy;
+    P.resid2 = (float)((1.0 - energy) * trace / (double)cb->n_words);
+    const int nk = m / 32, n_tiles = cb->n_words_pad / 256;
+    if (hipMalloc((void**)&P.R, R.size() * sizeof(float)) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook rotation matrix");
+    ISM_HIP(ctx, hipMemcpy(P.R, R.data(), R.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (hipMalloc((void**)&P.f16t, (size_t)n_tiles * nk * 8192 * sizeof(u16)) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook rotated f16 image");
+    if (hipMalloc((void**)&P.cn_scaled, ((size_t)cb->n_words_pad + 256) * sizeof(float) + 16) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook rotated norms");
+    P.osc = P.cn_scaled + cb->n_words_pad + 256;
+    P.m = m;
+    int rc = launch_rotate(ctx, cb->words, cb->n_words_pad, dp, dp, P.R, m, P.sc, P.f16t);
+    if (rc != ISMHIP_OK) { P.m = 0; return rc; }
+    float* sumsq_d = (float*)ism_scratch(ctx, SCR_PCA, (size_t)cb->n_words_pad * sizeof(float));
+    if (!sumsq_d) { P.m = 0; return ISMHIP_ERR_NOMEM; }
+    ISM_HIP(ctx, hipMemsetAsync(P.cn_scaled, 0, ((size_t)cb->n_words_pad + 256) * sizeof(float), ctx->stream));
+    const float cn_factor = P.sq / (2.0f * P.sc);                          // |c^|^2 / out_scale = -(sum h^2 / sc^2) sq sc / 2: powers of two, exact
+    hipLaunchKernelGGL(k_f16t_norms, dim3((cb->n_words_pad + 3) / 4), dim3(256), 0, ctx->stream, P.f16t, cb->n_words_pad, cb->n_words, nk, cn_factor, sumsq_d, P.cn_scaled);
+    ISM_CHECK_LAUNCH(ctx, "k_f16t_norms");
+    std::vector<float> ss(cb->n_words);
+    ISM_HIP(ctx, hipMemcpyAsync(ss.data(), sumsq_d, (size_t)cb->n_words * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    const float osc = -2.0f / (P.sq * P.sc);
+    ISM_HIP(ctx, hipMemcpyAsync(P.osc, &osc, sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float mx = 0.f;
+    for (float v : ss) mx = v > mx || v != v ? v : mx;
+    P.cmax2 = mx / (P.sc * P.sc) * 1.00001f;
+    if (!(P.cmax2 < 1e30f)) P.m = 0;                                        // overflowed image: keep the original path
+    return ISMHIP_OK;
 }
 
 // Builds the rotated image of a codebook (called once from ismhip_codebook_create, after the fp32 words and their norms exist).
-// Leaves cb->pca_m == 0 when the codebook does not qualify or its spectrum is too flat to pay; never an error for that.
+// Leaves cb->pca.m == 0 when the codebook does not qualify or its spectrum is too flat to pay; never an error for that.
 int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
-    cb->pca_m = 0;
+    cb->pca.m = 0; cb->pca2.m = 0;
     const int dp = cb->dim_pad;
     // (descriptors longer than 512: the host eigen-solve is cubic in the length -- 352 dimensions ~1 s, 1344 tens of seconds -- and the only
     // long descriptor of the path, CSHOT-1344, is searched with chi-square in every shipped configuration; ISMHIP_KNN_PCA_M > 0 overrides)
@@ -229,6 +279,7 @@ int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
     // nearly every query (configs[4]: the FPFH model's candidate stage 260 -> see DESIGN.md §5 ms per step).
     const bool identity = dp <= 64;
     std::vector<float> R;
+    std::vector<double> w_sorted, V_sorted;                                            // eigenvalues (descending) and their vectors, row by row
     int m = 0; double energy = 1.0, trace = 0.0;
     if (identity) {
         m = dp;
@@ -260,6 +311,8 @@ int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
     jacobi_eig(dp, S, V, w);
     std::vector<int> order(dp); std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w[a] > w[b]; });
+    w_sorted.resize(dp); V_sorted.resize((size_t)dp * dp);
+    for (int j = 0; j < dp; ++j) { w_sorted[j] = w[order[j]]; std::copy(V.begin() + (size_t)order[j] * dp, V.begin() + (size_t)(order[j] + 1) * dp, V_sorted.begin() + (size_t)j * dp); }
     // leading coordinates kept: forced (ISMHIP_KNN_PCA_M), else the smallest multiple of 32 that holds 97 % of the second moment. Bench
     // data (929 792 queries x 102 400 words, measured): 128 of 352 coordinates -> 7.0 % of the queries fail the stage-1 proof and are
     // searched again in all dimensions, kNN 35.6 ms per launch; 160 -> 3.0 %, 36.4 ms; 192 -> 1.0 %, 42.9 ms; 96 -> 14.5 %, 38.6 ms;
@@ -279,54 +332,29 @@ int ism_codebook_build_pca(ismhip_ctx* ctx, ismhip_codebook* cb) {
     R.assign((size_t)m * dp, 0.f);
     for (int j = 0; j < m; ++j) for (int c = 0; c < dp; ++c) R[(size_t)j * dp + c] = c < cb->dim ? (float)V[(size_t)order[j] * dp + c] : 0.f;
     }   // principal axes / identity
-    // sigma_max(R)^2 <= 1 + |R R^T - I|_F and |R|_F, from the fp32 values that are uploaded
-    double e2 = 0, fro2 = 0;
-    for (int i = 0; i < m; ++i) for (int j = i; j < m; ++j) {
-        double g = 0; for (int c = 0; c < dp; ++c) g += (double)R[(size_t)i * dp + c] * (double)R[(size_t)j * dp + c];
-        if (i == j) { fro2 += g; if (g != 0.0) { g -= 1.0; e2 += g * g; } } else e2 += 2.0 * g * g;     // all-zero rows (padding) only shrink the image
+    int rc = build_image(ctx, cb, cb->pca, R, m, energy, trace);
+    if (rc != ISMHIP_OK || cb->pca.m == 0 || identity || ctx->knn_pca_m2 == 0) return rc;
+    // Stage 2 (the queries whose stage-1 proof failed) on a LONGER prefix of the same basis instead of all dimensions: the smallest
+    // multiple of 32 beyond m + 32 that holds 99.7 % of the second moment (bench data: 256 of 352 coordinates, 8 slices per tile
+    // instead of 11), if that still saves 64 dimensions; what it cannot prove goes to the exact scan as before.
+    int m2 = 0; double cum2 = 0, energy2 = 0;
+    if (ctx->knn_pca_m2 > 0) m2 = std::max(m + 32, std::min(std::min(256, dp), (ctx->knn_pca_m2 + 31) / 32 * 32));
+    for (int i = 0; i < dp; ++i) {
+        cum2 += w_sorted[i];
+        if (m2 == 0 && (i + 1) % 32 == 0 && i + 1 >= m + 64 && cum2 >= 0.997 * trace) m2 = i + 1;
+        if (m2 && i + 1 == m2) energy2 = cum2 / trace;
     }
-    const double sig2 = 1.0 + std::sqrt(e2), sig = std::sqrt(sig2), fro = std::sqrt(fro2);
-    if (!(sig2 < 1.01)) return ISMHIP_OK;                                              // a basis this far from orthonormal is a bug, not a bound
-    const double cmax = std::sqrt((double)cb->max_norm2);
-    cb->pca_sc = f16_scale_of_bound((float)(1.001 * sig * cmax));
-    cb->pca_sq = f16_scale_of_bound((float)(2.002 * sig * cmax));
-    const double gamma = 1.01 * dp * 1.1920929e-07;                                    // fp32 rotation: K adds of relative error <= 2^-23, any order
-    cb->pca_d_rel = (float)(1.001 * (gamma * fro + 4.8828125e-04 * (sig + gamma * fro)));
-    cb->pca_dq_abs = (float)(1.001 * std::sqrt((double)m) * 6.103515625e-05 / cb->pca_sq);
-    cb->pca_dc_abs = (float)(1.001 * std::sqrt((double)m) * 6.103515625e-05 / cb->pca_sc);
-    cb->pca_inv_sig2 = (float)((1.0 / sig2) * (1.0 - 1e-6));
-    cb->pca_energy = (float)energy;
-    cb->pca_resid2 = (float)((1.0 - energy) * trace / (double)cb->n_words);
-    const int nk = m / 32, n_tiles = cb->n_words_pad / 256;
-    if (hipMalloc((void**)&cb->pca_R, R.size() * sizeof(float)) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook rotation matrix");
-    ISM_HIP(ctx, hipMemcpy(cb->pca_R, R.data(), R.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (hipMalloc((void**)&cb->pca_f16t, (size_t)n_tiles * nk * 8192 * sizeof(u16)) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook rotated f16 image");
-    if (hipMalloc((void**)&cb->pca_cn_scaled, ((size_t)cb->n_words_pad + 256) * sizeof(float) + 16) != hipSuccess) return ism_set_err(ctx, ISMHIP_ERR_NOMEM, "codebook rotated norms");
-    cb->pca_osc = cb->pca_cn_scaled + cb->n_words_pad + 256;
-    cb->pca_m = m;
-    int rc = launch_rotate(ctx, cb->words, cb->n_words_pad, dp, dp, cb->pca_R, m, cb->pca_sc, cb->pca_f16t);
-    if (rc != ISMHIP_OK) { cb->pca_m = 0; return rc; }
-    float* sumsq_d = (float*)ism_scratch(ctx, SCR_PCA, (size_t)cb->n_words_pad * sizeof(float));
-    if (!sumsq_d) { cb->pca_m = 0; return ISMHIP_ERR_NOMEM; }
-    ISM_HIP(ctx, hipMemsetAsync(cb->pca_cn_scaled, 0, ((size_t)cb->n_words_pad + 256) * sizeof(float), ctx->stream));
-    const float cn_factor = cb->pca_sq / (2.0f * cb->pca_sc);                          // |c^|^2 / out_scale = -(sum h^2 / sc^2) sq sc / 2: powers of two, exact
-    hipLaunchKernelGGL(k_f16t_norms, dim3((cb->n_words_pad + 3) / 4), dim3(256), 0, ctx->stream, cb->pca_f16t, cb->n_words_pad, cb->n_words, nk, cn_factor, sumsq_d, cb->pca_cn_scaled);
-    ISM_CHECK_LAUNCH(ctx, "k_f16t_norms");
-    std::vector<float> ss(cb->n_words);
-    ISM_HIP(ctx, hipMemcpyAsync(ss.data(), sumsq_d, (size_t)cb->n_words * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    const float osc = -2.0f / (cb->pca_sq * cb->pca_sc);
-    ISM_HIP(ctx, hipMemcpyAsync(cb->pca_osc, &osc, sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    ISM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    float mx = 0.f;
-    for (float v : ss) mx = v > mx || v != v ? v : mx;
-    cb->pca_cmax2 = mx / (cb->pca_sc * cb->pca_sc) * 1.00001f;
-    if (!(cb->pca_cmax2 < 1e30f)) cb->pca_m = 0;                                        // overflowed image: keep the original path
-    return ISMHIP_OK;
+    if (m2 == 0 || m2 > std::min(256, dp) || (m2 + 64 > dp && ctx->knn_pca_m2 < 0)) return ISMHIP_OK;
+    std::vector<float> R2((size_t)m2 * dp, 0.f);
+    for (int j = 0; j < m2; ++j) for (int c2 = 0; c2 < dp; ++c2) R2[(size_t)j * dp + c2] = c2 < cb->dim ? (float)V_sorted[(size_t)j * dp + c2] : 0.f;
+    return build_image(ctx, cb, cb->pca2, R2, m2, energy2, trace);
 }
 
 void ism_codebook_free_pca(ismhip_codebook* cb) {
-    if (cb->pca_R) (void)hipFree(cb->pca_R);
-    if (cb->pca_f16t) (void)hipFree(cb->pca_f16t);
-    if (cb->pca_cn_scaled) (void)hipFree(cb->pca_cn_scaled);
-    cb->pca_R = nullptr; cb->pca_f16t = nullptr; cb->pca_cn_scaled = nullptr; cb->pca_osc = nullptr; cb->pca_m = 0;
+    for (PcaImage* P : {&cb->pca, &cb->pca2}) {
+        if (P->R) (void)hipFree(P->R);
+        if (P->f16t) (void)hipFree(P->f16t);
+        if (P->cn_scaled) (void)hipFree(P->cn_scaled);
+        *P = PcaImage();
+    }
 }

@@ -1217,7 +1217,7 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, ora, monkeypatch):
     wn = words.numpy()
     off = np.arange(n_words + 1, dtype=np.uint32)
     res = {}
-    modes = ("f16", "f16-nopca", "f16-pca192", "f16-pca128noqp2", "f16-ring32", "f16-nojoin", "f16-half", "f16-qpanel", "f32")
+    modes = ("f16", "f16-nopca", "f16-pca192", "f16-pca128noqp2", "f16-m2off", "f16-m2x224", "f16-ring32", "f16-nojoin", "f16-half", "f16-qpanel", "f32")
     for mode in modes:
         monkeypatch.setenv("ISMHIP_KNN_MODE", mode.split("-")[0])
         if mode.endswith("nopca"):
@@ -1228,6 +1228,12 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, ora, monkeypatch):
             monkeypatch.setenv("ISMHIP_KNN_PCA_M", "128")                                     # 128 coordinates, query panel NOT resident
         else:
             monkeypatch.delenv("ISMHIP_KNN_PCA_M", raising=False)
+        if mode.endswith("m2off"):
+            monkeypatch.setenv("ISMHIP_KNN_PCA_M2", "0")                                      # stage 2 on all 352 dimensions
+        elif mode.endswith("m2x224"):
+            monkeypatch.setenv("ISMHIP_KNN_PCA_M", "128"); monkeypatch.setenv("ISMHIP_KNN_PCA_M2", "224")   # stage 1 / 2 forced onto 128 / 224 coordinates
+        else:
+            monkeypatch.delenv("ISMHIP_KNN_PCA_M2", raising=False)
         monkeypatch.setenv("ISMHIP_KNN_RING32", "1" if mode.endswith("ring32") else "0")     # the 32x32x16 variant of the ring kernel
         monkeypatch.setenv("ISMHIP_KNN_JOIN", "0" if mode.endswith("nojoin") else "1")       # every workgroup sweeps its split from tile 0
         monkeypatch.setenv("ISMHIP_KNN_HALF", "1" if mode.endswith("half") else "0")         # 128 x 256 tiles, two workgroups per CU
@@ -1238,18 +1244,19 @@ def test_knn_bench_scale_modes_agree(pkg, gpu, ora, monkeypatch):
                                np.ones(1, np.float32))
         ctx.timers_enable(True)
         idx, dist = pkg.capi.knn(ctx, cb, 0, q.to(dev), 2)
-        res[mode] = (idx.cpu().numpy(), dist.cpu().numpy(), _knn_flagged(ctx), cb.stage1_dims)
+        res[mode] = (idx.cpu().numpy(), dist.cpu().numpy(), _knn_flagged(ctx), cb.stage1_dims, cb.stage2_dims)
         cb.close()
     assert res["f16-nopca"][3] == 0 and res["f16-pca192"][3] == 192 and res["f16-pca128noqp2"][3] == 128
+    assert res["f16-m2off"][4] == 0 and res["f16-m2x224"][3:5] == (128, 224) and res["f16-nopca"][4] == 0
     for m in modes[:-1]:
         assert np.array_equal(res[m][0], res["f32"][0]), m
         assert np.array_equal(res[m][1], res["f32"][1]), m
     # the oracle leg: every 64th query against all 102 400 words on the CPU
     sel = np.arange(0, nq, 64)
     widx, wdist = ora.knn(0, wn, q.numpy()[sel], 2)
-    for m in ("f16", "f16-pca192", "f32"):
+    for m in ("f16", "f16-pca192", "f16-m2x224", "f32"):
         assert np.array_equal(res[m][0][sel], widx) and np.array_equal(res[m][1][sel], wdist), m
-    i16, d16, flagged, _ = res["f16"]
+    i16, d16, flagged, _, _ = res["f16"]
     assert np.array_equal(i16[:20, 0], np.arange(20)) and (d16[:20, 0] == 0).all()
     assert np.array_equal(i16[10:20, 1], np.arange(50000, 50010)) and (d16[10:20, 1] == 0).all()    # the duplicate is the second neighbour
     assert (d16[:, 0] <= d16[:, 1]).all()
