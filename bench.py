@@ -323,7 +323,7 @@ def main():
                                        "queries_per_launch": nq_l, "codebook_words": nw,
                                        "note": "candidate stage of the exact kNN: f16 MFMA scores over the leading rotated coordinates are lower bounds of "
                                                "the functor values; every returned neighbour is re-ranked with the exact f32 FLANN functor and proven, "
-                                               "unproven queries are searched again in all dimensions (knn_stage2) (DESIGN.md 4.1)"}, **extra))
+                                               "unproven queries are searched again on a longer rotated image or in all dimensions (knn_stage2) and, failing that, by the exact scan (DESIGN.md 4.1)"}, **extra))
             if cfg.distance == "ChiSquared" and tmm["knn_chi2"][1] > 0:
                 ms = tmm["knn_chi2"][0] / tmm["knn_chi2"][1]
                 hell = rec.codebook is not None and os.environ.get("ISMHIP_KNN_HELLINGER", "1") != "0"
