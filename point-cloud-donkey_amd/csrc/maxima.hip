@@ -8,7 +8,8 @@
 // seeds come from a 64-bit (z,y,x) cell-key bitonic sort (the reference's std::map order), every wave shifts one
 // seed at a time with its 64 lanes striding the votes, and the order-dependent greedy passes (average, suppress)
 // run on one lane exactly as the reference's loops do. Votes of a class are taken in slot order.
-// Not built (as in the oracle): RANSAC vote filter, global features, single-object max types, quaternion averaging.
+// Round 3: single-object max types (one density estimate at the cloud centroid), MaxFilterType "Merge", AverageRotation (quaternion
+// scatter matrix -> dominant eigenvector). Not built (as in the oracle): RANSAC vote filter, global features.
 #include "common.h"
 #include <cstring>
 
