@@ -53,7 +53,7 @@ extern "C" {
 #define ISMHIP_SUPPRESS_SUPPRESS 1
 #define ISMHIP_SUPPRESS_NONE     2
 /* inter-class maxima filter: voting/maxima_handler.cpp:272-296 ("Simple" = greedy non-maximum suppression over ALL classes inside
- * the search radius, suppressNeighborMaxima2 :227-268; "Merge" = mergeAndFilterMaxima :300-..., merging the maxima of the SAME class inside the radius first) */
+ * the search radius, suppressNeighborMaxima2 :227-268; "Merge" = mergeAndFilterMaxima :298-..., merging the maxima of the SAME class inside the radius first) */
 #define ISMHIP_MAXFILTER_NONE   0
 #define ISMHIP_MAXFILTER_SIMPLE 1
 #define ISMHIP_MAXFILTER_MERGE  2
