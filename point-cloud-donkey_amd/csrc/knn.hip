@@ -2241,9 +2241,9 @@ int run_knn_two_stage(ismhip_ctx* ctx, const ismhip_codebook* cb, int nq, const 
         // more than was won (measured: 9.18 vs 9.39 ms per step of 114 objects, 17.6 vs 15.0 of 227). The 128-query tile variant
         // (k_knn_l2_ring16<T, 1>: four lane slots per split, so four splits at T = 4) doubles the workgroups twice over instead.
         const bool was_half = ctx->knn_half;
-        // (the stage-2 image, if the codebook has one: 8 slices per tile instead of 11 on the bench data; its tiles are short enough)
+        // (on the stage-2 image, if the codebook has one: 8 slices per tile instead of 11 on the bench data)
         const int lvl2 = cb->pca2.m > 0 && !(n < 4096) ? 2 : 0;
-        if (n >= 4096 && n < 32768 && !ctx->knn_stage2_t4 && lvl2 == 0) ctx->knn_half = true;
+        if (n >= 4096 && n < 32768 && !ctx->knn_stage2_t4) ctx->knn_half = true;
         rc = run_knn<4>(ctx, cb, ISMHIP_METRIC_L2SQ, n, q2 + (size_t)o * cb->dim, k, idx2 + (size_t)o * k, dist2 + (size_t)o * k, nullptr, "knn_stage2", n < 4096, lvl2);
         ctx->knn_half = was_half;
         if (rc != ISMHIP_OK) return rc;
