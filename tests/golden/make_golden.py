@@ -8,6 +8,7 @@ path is then pinned against the oracle and against these same vectors.
     python tests/golden/make_golden.py        # rewrites tests/golden/kat.json
 """
 import json
+import sys
 import os
 
 import numpy as np
@@ -622,9 +623,10 @@ def main():
                hough3d_three_bins=hough3d_three_bins(), activate_weights=activate_weights(),
                meanshift_step_and_double_reweight=meanshift_step_and_double_reweight(), fpfh_three_points=fpfh_three_points(),
                lrf_majority_sign=lrf_majority_sign())
-    with open(OUT, "w") as f:
+    out = sys.argv[1] if len(sys.argv) > 1 else OUT
+    with open(out, "w") as f:
         json.dump(kat, f, indent=1)
-    print("wrote", OUT)
+    print("wrote", out)
 
 
 if __name__ == "__main__":

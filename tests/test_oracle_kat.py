@@ -401,3 +401,14 @@ def test_kmeans_two_blobs_vector(ora):
         c, asg, d, _ = ora.kmeans(0, pts, n_clusters, centers_init=init, seed=seed)
         return c, asg, d
     kat_checks.kmeans_two_blobs(f)
+
+
+def test_kat_json_is_what_the_committed_script_writes(tmp_path):
+    """tests/golden/kat.json must be exactly the output of tests/golden/make_golden.py (closed-form numpy, no oracle, no HIP): a vector
+    nobody can regenerate is not a fixture."""
+    import json, os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "kat.json")
+    r = subprocess.run([sys.executable, os.path.join(here, "golden", "make_golden.py"), out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert json.load(open(out)) == json.load(open(os.path.join(here, "golden", "kat.json")))
